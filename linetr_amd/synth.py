@@ -1,0 +1,219 @@
+"""Deterministic synthetic inputs for the LineTR hot path.
+
+The reference's pretrained blobs (models/weights/LineTR_weight.pth,
+superpoint_v1.pth) are absent from the checkout and cv2/LSD is not installed,
+so every test, golden fixture and benchmark here runs on *seeded* weights,
+KeyLine stand-ins and dense maps.  Everything is generated from
+``numpy.random.RandomState`` (bit-stable across numpy versions) except the
+cfg2/cfg3 dense maps, which follow BASELINE.md §3's recipe
+(``torch.Generator().manual_seed(seed)`` on CPU).
+
+Nothing in this module touches the GPU or the oracle.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+# ----------------------------------------------------------------------------
+# KeyLine stand-in (the attributes change_cv2_T_np reads:
+# /root/reference/models/line_process.py:206-220)
+# ----------------------------------------------------------------------------
+
+
+class KeyLine:
+    """Minimal stand-in for cv2.line_descriptor.KeyLine (attrs are Python floats of f32 values)."""
+
+    __slots__ = ("startPointX", "startPointY", "endPointX", "endPointY", "lineLength", "octave")
+
+    def __init__(self, sx, sy, ex, ey, length=None, octave=0):
+        self.startPointX = float(np.float32(sx))
+        self.startPointY = float(np.float32(sy))
+        self.endPointX = float(np.float32(ex))
+        self.endPointY = float(np.float32(ey))
+        if length is None:
+            length = np.float32(math.hypot(self.endPointX - self.startPointX,
+                                           self.endPointY - self.startPointY))
+        self.lineLength = float(np.float32(length))
+        self.octave = int(octave)
+
+    def as_row(self):
+        return [self.startPointX, self.startPointY, self.endPointX, self.endPointY,
+                self.lineLength, float(self.octave)]
+
+
+def keylines_to_array(klines_cv) -> np.ndarray:
+    """[K,6] float64 rows (spx, spy, epx, epy, lineLength, octave) from KeyLine-like objects."""
+    if len(klines_cv) == 0:
+        return np.zeros((0, 6), dtype=np.float64)
+    return np.asarray([[l.startPointX, l.startPointY, l.endPointX, l.endPointY,
+                        l.lineLength, float(l.octave)] for l in klines_cv], dtype=np.float64)
+
+
+def array_to_keylines(arr) -> list:
+    return [KeyLine(r[0], r[1], r[2], r[3], r[4], int(r[5])) for r in np.asarray(arr)]
+
+
+def synth_lines(seed: int, n_lines: int = 200, height: int = 480, width: int = 640,
+                len_lo: float = 17.0, len_hi: float = 167.0, margin: float = 10.0) -> np.ndarray:
+    """BASELINE.md §3 cfg2 recipe: start ~U(margin box), length ~U(len_lo,len_hi), angle ~U(0,2pi),
+    rejected unless the end point also lies inside the margin; coords rounded to f32, octave 0,
+    lineLength = f32(hypot).  Returns [n_lines,6] float64 (values exactly representable in f32)."""
+    rs = np.random.RandomState(seed)
+    rows = []
+    while len(rows) < n_lines:
+        sx = rs.uniform(margin, width - margin)
+        sy = rs.uniform(margin, height - margin)
+        ln = rs.uniform(len_lo, len_hi)
+        th = rs.uniform(0.0, 2.0 * math.pi)
+        ex = sx + ln * math.cos(th)
+        ey = sy + ln * math.sin(th)
+        if not (margin <= ex <= width - margin and margin <= ey <= height - margin):
+            continue
+        sx, sy, ex, ey = (float(np.float32(v)) for v in (sx, sy, ex, ey))
+        length = float(np.float32(math.hypot(ex - sx, ey - sy)))
+        rows.append([sx, sy, ex, ey, length, 0.0])
+    return np.asarray(rows, dtype=np.float64)
+
+
+def synth_dense_maps(seed: int, height: int = 480, width: int = 640, dim: int = 256):
+    """cfg2 recipe: dense_descriptor = normalize(randn(1,256,H/8,W/8)), dense_score = rand(1,H,W)
+    from torch.Generator().manual_seed(seed) (CPU tensors, f32)."""
+    import torch
+    g = torch.Generator().manual_seed(int(seed))
+    dd = torch.randn(1, dim, height // 8, width // 8, generator=g)
+    dd = torch.nn.functional.normalize(dd, p=2, dim=1)
+    ds = torch.rand(1, height, width, generator=g)
+    return dd, ds
+
+
+def synth_dense_maps_np(seed: int, height: int, width: int, dim: int = 256):
+    """numpy-only variant (used by the committed golden fixtures so they never depend on torch's RNG)."""
+    rs = np.random.RandomState(seed)
+    dd = rs.standard_normal((1, dim, height // 8, width // 8)).astype(np.float32)
+    dd /= np.maximum(np.sqrt((dd.astype(np.float64) ** 2).sum(1, keepdims=True)), 1e-12).astype(np.float32)
+    ds = rs.uniform(0.0, 1.0, (1, height, width)).astype(np.float32)
+    return dd, ds
+
+
+def jitter_pair(lines: np.ndarray, seed: int, sigma: float = 0.3):
+    """A 'matching-meaningful' second view: a random permutation of the same lines with sub-pixel
+    endpoint jitter.  Returns (lines1[K,6], perm) with lines1[i] ~ lines[perm[i]]."""
+    rs = np.random.RandomState(seed)
+    perm = rs.permutation(len(lines))
+    out = lines[perm].copy()
+    out[:, :4] += rs.normal(0.0, sigma, (len(lines), 4))
+    out[:, :4] = out[:, :4].astype(np.float32).astype(np.float64)
+    out[:, 4] = np.hypot(out[:, 2] - out[:, 0], out[:, 3] - out[:, 1]).astype(np.float32).astype(np.float64)
+    return out, perm
+
+
+# ----------------------------------------------------------------------------
+# Seeded state_dict with the layout of SURVEY.md Appendix B
+# (/root/reference/models/line_transformer.py:207-218 builds these modules)
+# ----------------------------------------------------------------------------
+
+
+def state_dict_spec(n_desc_layers: int = 1, d: int = 256, enc=(32, 64, 128, 256), d_inner: int = 1024,
+                    n_sig_layers: int = 7):
+    """Ordered (name, shape, kind) list in torch's state_dict order."""
+    spec = [("klenc.cls_token", (1, 1, 1, d), "randn")]
+
+    def mlp(prefix, chans):
+        n = len(chans)
+        idx = 0
+        for i in range(1, n):
+            spec.append((f"{prefix}.{idx}.weight", (chans[i], chans[i - 1], 1), "w"))
+            spec.append((f"{prefix}.{idx}.bias", (chans[i],), "b_last" if i == n - 1 else "b"))
+            idx += 1
+            if i < n - 1:
+                spec.append((f"{prefix}.{idx}.weight", (chans[i],), "gamma"))
+                spec.append((f"{prefix}.{idx}.bias", (chans[i],), "beta"))
+                spec.append((f"{prefix}.{idx}.running_mean", (chans[i],), "rmean"))
+                spec.append((f"{prefix}.{idx}.running_var", (chans[i],), "rvar"))
+                spec.append((f"{prefix}.{idx}.num_batches_tracked", (), "nbt"))
+                idx += 2  # BN + ReLU
+
+    mlp("klenc.line_position_enc.encoder", [5, *enc, d])
+    mlp("klenc.word_position_enc.encoder", [3, *enc, d])
+    for i in range(n_desc_layers):
+        p = f"klenc.desc_layers.{i}"
+        for nm in ("w_qs", "w_ks", "w_vs", "fc"):
+            spec.append((f"{p}.slf_attn.{nm}.weight", (d, d), "w"))
+            spec.append((f"{p}.slf_attn.{nm}.bias", (d,), "b"))
+        spec.append((f"{p}.slf_attn.layer_norm.weight", (d,), "gamma"))
+        spec.append((f"{p}.slf_attn.layer_norm.bias", (d,), "beta"))
+        spec.append((f"{p}.pos_ffn.w_1.weight", (d_inner, d), "w"))
+        spec.append((f"{p}.pos_ffn.w_1.bias", (d_inner,), "b"))
+        spec.append((f"{p}.pos_ffn.w_2.weight", (d, d_inner), "w"))
+        spec.append((f"{p}.pos_ffn.w_2.bias", (d,), "b"))
+        spec.append((f"{p}.pos_ffn.layer_norm.weight", (d,), "gamma"))
+        spec.append((f"{p}.pos_ffn.layer_norm.bias", (d,), "beta"))
+    for l in range(n_sig_layers):
+        p = f"selfattn.layers.{l}"
+        spec.append((f"{p}.attn.merge.weight", (d, d, 1), "w"))
+        spec.append((f"{p}.attn.merge.bias", (d,), "b"))
+        for j in range(3):
+            spec.append((f"{p}.attn.proj.{j}.weight", (d, d, 1), "w"))
+            spec.append((f"{p}.attn.proj.{j}.bias", (d,), "b"))
+        mlp(f"{p}.mlp", [2 * d, 2 * d, d])
+    spec.append(("final_proj.weight", (d, d, 1), "w"))
+    spec.append(("final_proj.bias", (d,), "b"))
+    return spec
+
+
+def make_state_dict(seed: int = 0, n_desc_layers: int = 1, gain: float = 1.0, **kw) -> "OrderedDict[str, np.ndarray]":
+    """Seeded weights as numpy arrays keyed like LineTransformer.state_dict().
+
+    Conv/Linear weights & biases ~ U(-g/sqrt(fan_in), g/sqrt(fan_in)) (torch's default init scale),
+    BN running_mean ~ N(0,0.1), running_var ~ U(0.5,1.5), affine gamma ~ U(0.5,1.5), beta ~ N(0,0.1)
+    so BN folding and LayerNorm affine are genuinely exercised; last-MLP biases are NOT zeroed
+    (a trained checkpoint would not have them at zero either)."""
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    for name, shape, kind in state_dict_spec(n_desc_layers, **kw):
+        if kind == "randn":
+            v = rs.standard_normal(shape)
+        elif kind == "w":
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+            b = gain / math.sqrt(fan_in)
+            v = rs.uniform(-b, b, shape)
+        elif kind in ("b", "b_last"):
+            v = rs.uniform(-0.1, 0.1, shape)
+        elif kind == "gamma":
+            v = rs.uniform(0.5, 1.5, shape)
+        elif kind == "beta":
+            v = rs.normal(0.0, 0.1, shape)
+        elif kind == "rmean":
+            v = rs.normal(0.0, 0.1, shape)
+        elif kind == "rvar":
+            v = rs.uniform(0.5, 1.5, shape)
+        elif kind == "nbt":
+            sd[name] = np.asarray(100, dtype=np.int64)
+            continue
+        else:
+            raise ValueError(kind)
+        sd[name] = np.ascontiguousarray(v, dtype=np.float32)
+    return sd
+
+
+def to_torch_state_dict(sd):
+    import torch
+    return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in sd.items())
+
+
+def calibrated_state_dict(n_desc_layers: int = 1) -> "OrderedDict[str, np.ndarray]":
+    """seed-0 weights with BatchNorm running stats overlaid from data/bn_calib_seed0.npz
+    (produced by tests/golden/make_calib.py).  With matched BN statistics the descriptors of
+    different lines are well separated (pairwise distances 0.06..1.5, argmin margins >> 1e-4), as a
+    trained checkpoint's would be, which makes index-exact match parity a meaningful test."""
+    import os
+    sd = make_state_dict(0, n_desc_layers)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "bn_calib_seed0.npz")
+    with np.load(path) as cal:
+        for k in cal.files:
+            assert k in sd and sd[k].shape == cal[k].shape, k
+            sd[k] = cal[k].astype(np.float32)
+    return sd

@@ -1,0 +1,47 @@
+"""Shared helpers for the test-suite (oracle side).  Test infrastructure only."""
+import os
+
+import numpy as np
+import torch
+
+from linetr_amd import synth
+from oracle import linetr_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BASE_CFG = dict(min_length=16, token_distance=8, max_tokens=21, remove_borders=8, max_keylines=-1,
+                nn_threshold=0.8)
+TOK_KEYS = ["klines", "length_klines", "angles", "sublines", "pnt_sublines", "mask_sublines",
+            "resp_sublines", "angle_sublines", "score_sublines", "mat_klines2sublines"]
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def golden_cfg(g, **extra):
+    cfg = dict(BASE_CFG)
+    for k in g.files:
+        if k.startswith("cfg_"):
+            v = g[k]
+            cfg[k[4:]] = v.item()
+    cfg.update(extra)
+    return cfg
+
+
+def weights_for(g):
+    seed = int(g["weight_seed"]) if "weight_seed" in g.files else 0
+    nl = int(g["n_desc_layers"]) if "n_desc_layers" in g.files else 1
+    return synth.calibrated_state_dict(nl) if seed == 0 else synth.make_state_dict(seed, nl)
+
+
+def tiny_maps(g):
+    hw = tuple(int(v) for v in g["hw"])
+    dd, ds = synth.synth_dense_maps_np(int(g["map_seed"]), *hw)
+    return torch.from_numpy(dd), torch.from_numpy(ds), hw
+
+
+def oracle_image(sd_t, rows, dd, ds, hw, cfg, valid_mask=None, align_corners=None, image_shape=None):
+    out = O.preprocess(synth.array_to_keylines(rows), (1, 1, hw[0], hw[1]), dd, ds, cfg, valid_mask, align_corners)
+    if len(out["klines"]) == 0:
+        return out
+    return O.forward(sd_t, out, image_shape or hw)

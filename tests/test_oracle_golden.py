@@ -1,0 +1,111 @@
+"""CPU: pin oracle/linetr_oracle.py against the fixtures frozen from the real reference
+(tests/golden/make_golden.py).  Tokeniser entries bit-exact, descriptors <= 2e-5, matches identical."""
+import numpy as np
+import pytest
+import torch
+
+from linetr_amd import synth
+from oracle import linetr_oracle as O
+from helpers import BASE_CFG, TOK_KEYS, golden_cfg, load, oracle_image, tiny_maps, weights_for
+
+torch.set_grad_enabled(False)
+DESC_TOL = 2e-5
+
+
+def test_cfg2_pair_tokenizer_forward_match():
+    g = load("cfg2_pair")
+    sd = synth.to_torch_state_dict(synth.calibrated_state_dict())
+    outs = []
+    for tag in "ab":
+        dd, ds = synth.synth_dense_maps(int(g[f"{tag}_seed"]), 480, 640)
+        out = oracle_image(sd, g[f"{tag}_lines"], dd, ds, (480, 640), BASE_CFG)
+        for k in TOK_KEYS:
+            assert np.array_equal(out[k].numpy(), g[f"{tag}_{k}"]), k
+        desc = out["desc_sublines"].numpy()[0]
+        ii, jj = g[f"{tag}_desc_sample_idx"].T
+        assert np.array_equal(desc[ii, jj], g[f"{tag}_desc_sample"])
+        assert np.abs(desc.astype(np.float64).sum(-1) - g[f"{tag}_desc_checksum"]).max() == 0
+        assert np.abs(out["line_desc"].numpy() - g[f"{tag}_line_desc"]).max() < DESC_TOL
+        assert out["line_desc"].shape == (1, 256, 199)          # the [:-1] drop (quirk 5)
+        outs.append(out)
+    M, Dk = O.match_lines(outs[0]["line_desc"], outs[1]["line_desc"], outs[0]["mat_klines2sublines"][0],
+                          outs[1]["mat_klines2sublines"][0], 0.8)
+    assert np.array_equal(M, g["pair_M"])
+    assert M.dtype == np.float64 and Dk.dtype == np.float32
+    assert np.abs(Dk - g["pair_Dk"]).max() < 1e-5
+
+
+def test_jitter_pair_recovers_permutation():
+    g = load("cfg2_jitter_pair")
+    sd = synth.to_torch_state_dict(synth.calibrated_state_dict())
+    dd, ds = synth.synth_dense_maps(int(g["map_seed"]), 480, 640)
+    o0 = oracle_image(sd, g["a_lines"], dd, ds, (480, 640), BASE_CFG)
+    o1 = oracle_image(sd, g["b_lines"], dd, ds, (480, 640), BASE_CFG)
+    M, _ = O.match_lines(o0["line_desc"], o1["line_desc"], o0["mat_klines2sublines"][0],
+                         o1["mat_klines2sublines"][0], 0.8)
+    assert np.array_equal(M, g["pair_M"])
+    # every matched pair is the same physical line (start points within the jitter)
+    i, j = np.nonzero(M[0])
+    assert len(i) >= 195
+    k0, k1 = o0["klines"][0].numpy(), o1["klines"][0].numpy()
+    err = np.minimum(np.abs(k0[i] - k1[j]).reshape(-1, 4).max(1),
+                     np.abs(k0[i] - k1[j][:, ::-1]).reshape(-1, 4).max(1))   # near-vertical lines may swap ends
+    assert (err < 2.0).sum() >= 195, err
+
+
+@pytest.mark.parametrize("name", ["tiny_default", "tiny_float_td", "tiny_align_true", "tiny_two_layers",
+                                  "tiny_max3", "tiny_noborder"])
+def test_tiny_cases(name):
+    g = load(name)
+    dd, ds, hw = tiny_maps(g)
+    sd = synth.to_torch_state_dict(weights_for(g))
+    cfg = golden_cfg(g)
+    out = oracle_image(sd, g["lines"].copy(), dd, ds, hw, cfg, align_corners=bool(g["align_corners"]))
+    for k in TOK_KEYS:
+        assert np.array_equal(out[k].numpy(), g[k]), k
+    assert np.abs(out["desc_sublines"].numpy() - g["desc_sublines"]).max() < 1e-6
+    assert np.abs(out["line_desc"].numpy() - g["line_desc"]).max() < DESC_TOL
+
+
+def test_tiny_validmask_and_single_line():
+    g = load("tiny_validmask")
+    dd, ds, hw = tiny_maps(g)
+    sd = synth.to_torch_state_dict(weights_for(g))
+    vm = np.ones(hw)
+    vm[:, :int(g["valid_mask_cols"])] = 0
+    out = oracle_image(sd, g["lines"].copy(), dd, ds, hw, BASE_CFG, valid_mask=vm)
+    for k in ("klines", "sublines", "mat_klines2sublines"):
+        assert np.array_equal(out[k].numpy(), g[k]), k
+    assert np.abs(out["line_desc"].numpy() - g["line_desc"]).max() < DESC_TOL
+    g = load("tiny_single_line")
+    out = O.preprocess(synth.array_to_keylines(g["lines"]), (1, 1, *hw), dd, ds, BASE_CFG)
+    assert len(out["klines"]) == int(g["n_klines"]) == 0
+    ret = O.forward(sd, out, hw)
+    for k, v in ret.items():
+        assert tuple(v.shape) == tuple(g[f"ret_{k}_shape"])
+
+
+def test_cfg5_small_long_tokens():
+    g = load("cfg5_small")
+    dd, ds, hw = tiny_maps(g)
+    sd = synth.to_torch_state_dict(weights_for(g))
+    cfg = dict(BASE_CFG, max_tokens=int(g["max_tokens"]))
+    out = oracle_image(sd, g["lines"], dd, ds, hw, cfg)
+    for k in ("klines", "sublines", "pnt_sublines", "mask_sublines", "resp_sublines", "angle_sublines",
+              "score_sublines"):
+        assert np.array_equal(out[k].numpy(), g[k]), k
+    assert out["pnt_sublines"].shape[2] == 41
+    desc = out["desc_sublines"].numpy()[0].astype(np.float64)
+    assert np.abs(desc.sum(-1) - g["desc_checksum"]).max() < 1e-5
+    assert np.abs(out["line_desc"].numpy() - g["line_desc"]).max() < DESC_TOL
+
+
+def test_matcher_known_answers():
+    g = load("matcher_cases")
+    for k in ("ties", "big", "empty0", "empty1"):
+        d = g[f"{k}_dist"]
+        assert np.array_equal(O.mutual_nn(d, 0.8, True), g[f"{k}_mutual"]), k
+        assert np.array_equal(O.mutual_nn(d, 0.8, False), g[f"{k}_oneway"]), k
+    M, D = O.point_nn(g["point_desc0"], g["point_desc1"], 0.7, True)
+    assert np.array_equal(M, g["point_M"])
+    assert np.abs(D - g["point_D"]).max() < 1e-6
