@@ -1,0 +1,197 @@
+/*
+ * linetr_hip.h -- C ABI of the MI355X-native (gfx950) Line-Transformer descriptor + matcher.
+ *
+ * This is the drop-in boundary for the hot path of yosungho/LineTR: every entry point names the
+ * reference interface it replaces (paths relative to the reference checkout).  Plain pointers and
+ * sizes only -- no torch/ATen types.  All `d_*` pointers are DEVICE pointers (HIP), `h_*` are HOST
+ * pointers.  `stream` is a hipStream_t passed as void* (NULL = default stream).  Every function
+ * returns 0 on success or a negative LINETR_E_* code; linetr_last_error() returns a message for the
+ * calling thread.  Nothing here ever falls back to a CPU implementation: if no HIP device is
+ * usable, linetr_create() fails.
+ *
+ * Call sequence for one batch of B images (one image = B=1):
+ *     linetr_prefilter / linetr_pack_lines   (host, O(K) per image)  -> line records
+ *     linetr_tokenize                         (device)                -> the tensors of `preprocess`
+ *     linetr_forward                          (device)                -> line_desc
+ *     linetr_match                            (device)                -> Dk, match indices
+ */
+#ifndef LINETR_HIP_H
+#define LINETR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LINETR_ABI_VERSION 1
+
+enum {
+  LINETR_OK = 0,
+  LINETR_E_ARG = -1,       /* bad argument / unsupported configuration            */
+  LINETR_E_HIP = -2,       /* a HIP runtime call failed                            */
+  LINETR_E_WEIGHTS = -3,   /* state_dict tensor missing / wrong size               */
+  LINETR_E_ASSERT = -4,    /* reference AssertionError: token beyond the line end  */
+  LINETR_E_WORKSPACE = -5, /* workspace too small                                  */
+  LINETR_E_CAPACITY = -6   /* caller-provided output capacity too small            */
+};
+
+typedef struct LinetrHandle LinetrHandle;
+
+/* Model hyper-parameters: LineTransformer.default_config, models/line_transformer.py:187-201. */
+typedef struct {
+  int32_t d_model;          /* descriptor_dim, must be 256                                  */
+  int32_t n_heads;          /* must be 4                                                    */
+  int32_t d_inner;          /* FFN width, multiple of 128 (default 1024)                    */
+  int32_t n_sig_layers;     /* line-signature layers (7)                                    */
+  int32_t n_desc_layers;    /* n_line_descriptive_layers; only the LAST one reaches the     */
+                            /* output (models/line_transformer.py:123-125)                  */
+  int32_t enc_channels[4];  /* keyline_encoder = {32,64,128,256}                            */
+  int32_t norm_height;      /* constructor-time image_shape used by normalize_keylines      */
+  int32_t norm_width;       /* (models/line_transformer.py:206,:238)                        */
+} LinetrModelConfig;
+
+/* One key-line after pre-filtering (float64 geometry exactly as the reference keeps it in NumPy). */
+typedef struct {
+  double sp[2];        /* start point (x,y), post remove_borders clip                           */
+  double ep[2];        /* end point                                                            */
+  double length;       /* lineLength * 2^octave (models/line_process.py:220) -- NOT geometric   */
+  double angle[2];     /* (cos 2theta, sin 2theta), models/line_process.py:28-41                */
+  int32_t first_sub;   /* index of this line's first sub-line inside the whole batch           */
+  int32_t n_tok;       /* ceil(length / token_distance), models/line_process.py:109            */
+  int32_t n_sub;       /* ceil(n_tok / max_tokens), models/line_process.py:121                 */
+  int32_t image;       /* image index inside the batch                                         */
+  int32_t line_local;  /* index of this key-line inside its image                              */
+  int32_t reserved;
+} LinetrLineRec;       /* 80 bytes */
+
+/* Device outputs of the tokeniser == the tensor entries LineTransformer.preprocess returns
+ * (models/line_process.py:182-193), leading batch-1 axis dropped, images concatenated.
+ * K = total key-lines, N = total sub-lines, T = max_tokens, S = T+1.  All float32. */
+typedef struct {
+  float* klines;      /* [K,2,2]                                                    */
+  float* length;      /* [K]                                                        */
+  float* angles;      /* [K,2]                                                      */
+  float* sublines;    /* [N,2,2]                                                    */
+  float* pnt;         /* [N,T,2]   pnt_sublines                                     */
+  float* mask;        /* [N,S]     mask_sublines (trailing 1-axis dropped)          */
+  float* resp;        /* [N]       resp_sublines                                    */
+  float* angle_sub;   /* [N,2]     angle_sublines                                   */
+  float* desc;        /* [N,T,256] desc_sublines                                    */
+  float* score;       /* [N,T]     score_sublines                                   */
+} LinetrTokens;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+
+int linetr_abi_version(void);
+const char* linetr_last_error(void);
+
+/* Replaces LineTransformer.__init__ + load_state_dict (models/line_transformer.py:203-223).
+ * `names[i]` are state_dict keys, `h_data[i]` host float32 arrays of
+ * `numel[i]` elements; integer buffers (num_batches_tracked) may be omitted or passed as NULL.
+ * BatchNorm folding, head permutation and the CLS-query constants are derived here in float64
+ * and uploaded once (weights stay resident in HBM/Infinity Cache). */
+int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, const char* const* names,
+                  const float* const* h_data, const int64_t* numel, int32_t device,
+                  LinetrHandle** out);
+void linetr_destroy(LinetrHandle* h);
+
+/* ---- host pre-filter ------------------------------------------------------------------------ */
+
+/* change_cv2_T_np + remove_borders + filter_by_length (models/line_process.py:203-231, :59-84,
+ * :6-21) on one image.  h_lines6 = [K,6] rows (startX,startY,endX,endY,lineLength,octave).
+ * h_valid_mask: NULL (== the reference's non-ndarray mask, i.e. ignored) or [height,width] float64.
+ * max_keylines follows the reference's slice semantics ([:max_keylines], so -1 drops the shortest).
+ * Ties in length are ordered by descending original index (== a stable ascending argsort, reversed).
+ * Writes up to `capacity` records (first_sub/n_tok/n_sub/image filled as by linetr_pack_lines;
+ * `sub_base` = number of sub-lines of the images that precede this one in the batch) and
+ * returns K' in *k_out, the number of sub-lines of this image in *n_out.  LINETR_E_ASSERT if a token distance
+ * exceeds the geometric line length (the reference's AssertionError, line_process.py:44-45). */
+int linetr_prefilter(const double* h_lines6, int32_t K, int32_t height, int32_t width, int32_t border,
+                     double min_length, int32_t max_keylines, const double* h_valid_mask,
+                     double token_distance, int32_t max_tokens, int32_t image_index, int32_t sub_base,
+                     LinetrLineRec* h_recs, int32_t capacity, int32_t* k_out, int32_t* n_out);
+
+/* Same record packing for lines that were already filtered/sorted by the caller (the Python shim
+ * keeps NumPy's own argsort so that tie order is the reference's on the same machine).
+ * h_klines [K,2,2], h_length [K], h_angles [K,2] float64. */
+int linetr_pack_lines(const double* h_klines, const double* h_length, const double* h_angles, int32_t K,
+                      double token_distance, int32_t max_tokens, int32_t image_index, int32_t sub_base,
+                      LinetrLineRec* h_recs, int32_t* n_out);
+
+/* ---- device: tokenise ----------------------------------------------------------------------- */
+
+/* Bytes of scratch linetr_tokenize needs (NHWC copy of the dense descriptor maps + index maps). */
+int64_t linetr_tokenize_workspace_bytes(int32_t n_images, int32_t height, int32_t width, int32_t N);
+
+/* line_tokenizer + sample_descriptors + score gather (models/line_process.py:100-196, :86-98).
+ * d_recs: [K] records of all images (image-major, per-image order preserved); h_recs the same
+ * array on the host (used only to size launches).  d_dense_desc [B,256,height/8,width/8] NCHW,
+ * d_dense_score [B,height,width].  The end-point clip of line_process.py:114-116 is applied, and
+ * the clipped end points are what `out.klines` holds (reference quirk: it mutates through a view).
+ * d_sub2line [N] int32 (key-line index of every sub-line INSIDE ITS IMAGE, non-decreasing per image)
+ * is written for linetr_match.  `out.desc` may be NULL to skip descriptor sampling. */
+int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N,
+                    double token_distance, int32_t max_tokens, const float* d_dense_desc,
+                    const float* d_dense_score, int32_t n_images, int32_t height, int32_t width,
+                    int32_t align_corners, LinetrTokens out, int32_t* d_sub2line, void* d_workspace,
+                    int64_t workspace_bytes, void* stream);
+
+/* ---- device: descriptor network ------------------------------------------------------------- */
+
+int64_t linetr_forward_workspace_bytes(const LinetrHandle* h, int32_t N, int32_t max_tokens);
+
+/* LineTransformer.forward (models/line_transformer.py:225-249) on a var-len batch.
+ * h_cu_sub [B+1]: host prefix sums of sub-lines per image (signature attention is per image).
+ * Inputs are the tokeniser tensors; mask is accepted for interface fidelity and ignored, because it
+ * masks query rows only and the CLS row is never masked (models/line_attention.py:16).
+ * d_line_desc [N,256] row-major (the shim exposes the reference's [1,256,N] as a transposed view). */
+int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const int32_t* h_cu_sub, int32_t n_images,
+                   int32_t max_tokens, float* d_line_desc, void* d_workspace, int64_t workspace_bytes,
+                   void* stream);
+
+/* ---- device: matcher ------------------------------------------------------------------------ */
+
+int64_t linetr_match_workspace_bytes(int32_t n_pairs, int64_t sum_n0n1, int64_t sum_k0k1, int64_t sum_k);
+
+/* get_dist_matrix + subline2keyline + nn_matcher_distmat (models/line_process.py:198-201,
+ * models/line_transformer.py:277-282, models/nn_matcher.py:3-31) for P pairs in one launch set.
+ * Pair p uses descriptors d_desc0[h_off_n0[p] .. +n0) (rows of 256) and key-line maps
+ * d_sub2line0 (LOCAL key-line index per sub-line, non-decreasing), same for side 1.
+ * h_dims [P,4] = (n0,k0,n1,k1); offsets are host int64 arrays [P].
+ * Outputs: d_dk at h_off_dk[p] holds Dk [k0,k1] float32; d_match01 at h_off_k0[p] holds, per
+ * key-line of image 0, the matched key-line of image 1 or -1 (the non-zero of the reference's 0/1
+ * matrix; first-index argmin, strict `<`, optional mutual check). */
+int linetr_match(LinetrHandle* h, int32_t n_pairs, const int32_t* h_dims, const float* d_desc0,
+                 const int64_t* h_off_n0, const int32_t* d_sub2line0, const float* d_desc1,
+                 const int64_t* h_off_n1, const int32_t* d_sub2line1, float nn_thresh, int32_t mutual,
+                 float* d_dk, const int64_t* h_off_dk, int32_t* d_match01, const int64_t* h_off_k0,
+                 void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* nn_matcher (models/nn_matcher.py:33-42): point-descriptor variant, desc given [256,n] column-major
+ * like SuperPoint's `descriptors` -- section 8(f) "next" row, same kernels. */
+int linetr_match_points(LinetrHandle* h, const float* d_desc0_cn, int32_t n0, const float* d_desc1_cn,
+                        int32_t n1, float nn_thresh, int32_t mutual, float* d_dist, int32_t* d_match01,
+                        void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- instrumentation ------------------------------------------------------------------------ */
+
+/* Per-kernel-class HIP-event timing.  linetr_set_profiling(h,1) clears the accumulators and makes
+ * every subsequent kernel launch of this handle be bracketed by hipEventRecord on its stream;
+ * linetr_get_profile synchronises the recorded events and returns, per kernel class, the number of
+ * launches, the summed duration and the ALGORITHMIC flops / bytes (SURVEY.md section 8d accounting)
+ * those launches performed.  bench.py derives its roofline object from this. */
+typedef struct {
+  const char* name;   /* static string, e.g. "gemm_f32_128x128" */
+  int32_t calls;
+  float ms;           /* summed over calls */
+  double flops;       /* summed algorithmic flops */
+  double bytes;       /* summed compulsory HBM bytes */
+} LinetrProfileEntry;
+int linetr_set_profiling(LinetrHandle* h, int32_t on);
+int linetr_get_profile(LinetrHandle* h, LinetrProfileEntry* out, int32_t max_entries, int32_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LINETR_HIP_H */

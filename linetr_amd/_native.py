@@ -1,0 +1,107 @@
+"""ctypes binding of liblinetr_hip.so (the C ABI of include/linetr_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblinetr_hip.so")
+
+E_ASSERT = -4
+
+
+class ModelConfig(C.Structure):
+    _fields_ = [("d_model", C.c_int32), ("n_heads", C.c_int32), ("d_inner", C.c_int32),
+                ("n_sig_layers", C.c_int32), ("n_desc_layers", C.c_int32), ("enc_channels", C.c_int32 * 4),
+                ("norm_height", C.c_int32), ("norm_width", C.c_int32)]
+
+
+class LineRec(C.Structure):
+    _fields_ = [("sp", C.c_double * 2), ("ep", C.c_double * 2), ("length", C.c_double),
+                ("angle", C.c_double * 2), ("first_sub", C.c_int32), ("n_tok", C.c_int32),
+                ("n_sub", C.c_int32), ("image", C.c_int32), ("line_local", C.c_int32), ("reserved", C.c_int32)]
+
+
+REC_DTYPE = np.dtype([("sp", "<f8", 2), ("ep", "<f8", 2), ("length", "<f8"), ("angle", "<f8", 2),
+                      ("first_sub", "<i4"), ("n_tok", "<i4"), ("n_sub", "<i4"), ("image", "<i4"),
+                      ("line_local", "<i4"), ("reserved", "<i4")])
+assert REC_DTYPE.itemsize == C.sizeof(LineRec) == 80
+
+
+class Tokens(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("klines", "length", "angles", "sublines", "pnt", "mask", "resp",
+                                          "angle_sub", "desc", "score")]
+
+
+class ProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("calls", C.c_int32), ("ms", C.c_float), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the in-tree shared library (built by ``python -m linetr_amd.build`` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built (run `python -m linetr_amd.build`). "
+            "linetr_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_float
+    L.linetr_abi_version.restype = i32
+    L.linetr_last_error.restype = C.c_char_p
+    L.linetr_create.argtypes = [C.POINTER(ModelConfig), i32, C.POINTER(C.c_char_p), C.POINTER(vp), C.POINTER(i64), i32,
+                                C.POINTER(vp)]
+    L.linetr_destroy.argtypes = [vp]
+    L.linetr_destroy.restype = None
+    L.linetr_prefilter.argtypes = [vp, i32, i32, i32, i32, f64, i32, vp, f64, i32, i32, i32, vp, i32, C.POINTER(i32),
+                                   C.POINTER(i32)]
+    L.linetr_pack_lines.argtypes = [vp, vp, vp, i32, f64, i32, i32, i32, vp, C.POINTER(i32)]
+    L.linetr_tokenize_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.linetr_tokenize_workspace_bytes.restype = i64
+    L.linetr_tokenize.argtypes = [vp, vp, i32, i32, f64, i32, vp, vp, i32, i32, i32, i32, Tokens, vp, vp, i64, vp]
+    L.linetr_forward_workspace_bytes.argtypes = [vp, i32, i32]
+    L.linetr_forward_workspace_bytes.restype = i64
+    L.linetr_forward.argtypes = [vp, C.POINTER(Tokens), vp, i32, i32, vp, vp, i64, vp]
+    L.linetr_match_workspace_bytes.argtypes = [i32, i64, i64, i64]
+    L.linetr_match_workspace_bytes.restype = i64
+    L.linetr_match.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, i64, vp]
+    L.linetr_match_points.argtypes = [vp, vp, i32, vp, i32, f32, i32, vp, vp, vp, i64, vp]
+    L.linetr_set_profiling.argtypes = [vp, i32]
+    L.linetr_get_profile.argtypes = [vp, C.POINTER(ProfileEntry), i32, C.POINTER(i32)]
+    if L.linetr_abi_version() != 1:
+        raise RuntimeError("liblinetr_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+EXPORTS = ["linetr_abi_version", "linetr_last_error", "linetr_create", "linetr_destroy", "linetr_prefilter",
+           "linetr_pack_lines", "linetr_tokenize_workspace_bytes", "linetr_tokenize", "linetr_forward_workspace_bytes",
+           "linetr_forward", "linetr_match_workspace_bytes", "linetr_match", "linetr_match_points",
+           "linetr_set_profiling", "linetr_get_profile"]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def check(code: int):
+    if code == 0:
+        return
+    msg = lib().linetr_last_error().decode("utf-8", "replace")
+    if code == E_ASSERT:
+        raise AssertionError(msg)     # same exception type the reference raises (line_process.py:44-45)
+    raise NativeError(f"liblinetr_hip error {code}: {msg}")
+
+
+def np_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)

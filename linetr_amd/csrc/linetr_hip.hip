@@ -1,0 +1,789 @@
+// liblinetr_hip.so -- host side of the C ABI declared in include/linetr_hip.h.
+// Weight preparation (float64 on the host), host pre-filter, launch sequencing, profiling.
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <numeric>
+
+#include "lt_common.h"
+#include "lt_gemm.h"
+#include "lt_match.h"
+#include "lt_model.h"
+#include "lt_token.h"
+
+using namespace lt;
+
+// =============================================================================================
+// handle
+// =============================================================================================
+
+struct SigLayer {
+  const float *Wqkv, *bqkv, *Wm, *bm, *W1, *b1, *W2, *b2;
+};
+
+struct ProfClass {
+  const char* name;
+  int calls = 0;
+  double flops = 0, bytes = 0;
+  float ms = 0;
+};
+
+struct LinetrHandle {
+  LinetrModelConfig cfg;
+  int device = 0;
+  float* arena = nullptr;  // all prepared weights, one allocation
+  // word / line positional encoders (BN folded)
+  const float *wW1, *wb1, *wW2, *wb2, *wW3, *wb3, *wW4, *wb4;
+  const float *lW1, *lb1, *lW2, *lb2, *lW3, *lb3, *lW4, *lb4, *lW5, *lb5;
+  // line-descriptive layer (CLS-row algebra)
+  ClsPoolConst pool;
+  const float *Watt, *batt, *Wfc, *bfc, *ln1g, *ln1b, *Wf1, *bf1, *Wf2, *bf2, *ln2g, *ln2b;
+  std::vector<SigLayer> sig;
+  const float *Wfin, *bfin;
+  // profiling
+  bool profiling = false;
+  std::vector<ProfClass> classes;
+  struct Pending { int cls; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int prof_class(LinetrHandle* h, const char* name) {
+  for (size_t i = 0; i < h->classes.size(); ++i)
+    if (h->classes[i].name == name || strcmp(h->classes[i].name, name) == 0) return (int)i;
+  ProfClass c;
+  c.name = name;
+  h->classes.push_back(c);
+  return (int)h->classes.size() - 1;
+}
+
+hipEvent_t prof_event(LinetrHandle* h) {
+  if (!h->event_pool.empty()) {
+    hipEvent_t e = h->event_pool.back();
+    h->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+// RAII bracket around one kernel launch
+struct ProfScope {
+  LinetrHandle* h;
+  hipStream_t st;
+  int cls = -1;
+  hipEvent_t a{}, b{};
+  ProfScope(LinetrHandle* h_, hipStream_t st_, const char* name, double flops, double bytes) : h(h_), st(st_) {
+    if (!h->profiling) return;
+    cls = prof_class(h, name);
+    h->classes[cls].calls++;
+    h->classes[cls].flops += flops;
+    h->classes[cls].bytes += bytes;
+    a = prof_event(h);
+    b = prof_event(h);
+    hipEventRecord(a, st);
+  }
+  ~ProfScope() {
+    if (cls < 0) return;
+    hipEventRecord(b, st);
+    h->pending.push_back({cls, a, b});
+  }
+};
+
+const char* gemm_class_name(const GemmArgs& g, int groups) {
+  if (g.N % 128 != 0) return "gemm_f32_128x64";
+  int64_t big = (int64_t)cdiv(g.M, 128) * (g.N / 128) * groups;
+  return big >= 384 ? "gemm_f32_128x128" : "gemm_f32_64x128";
+}
+
+int run_gemm(LinetrHandle* h, hipStream_t st, const float* A, int lda, const float* A2, int lda2, int K1,
+             const float* W, const float* bias, const float* R, int ldr, float* Y, int ldy, int M, int N,
+             int K, int act, int groups = 1, int64_t gA = 0, int64_t gW = 0, int64_t gBias = 0, int64_t gY = 0) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.K1 = K1;
+  g.W = W; g.ldw = K; g.bias = bias; g.R = R; g.ldr = ldr; g.Y = Y; g.ldy = ldy;
+  g.M = M; g.N = N; g.K = K; g.act = act;
+  g.gA = gA; g.gW = gW; g.gBias = gBias; g.gY = gY;
+  ProfScope ps(h, st, gemm_class_name(g, groups), 2.0 * M * (double)N * K * groups,
+               4.0 * groups * ((double)M * K + (double)N * K + (double)M * N));
+  return gemm_launch(g, groups, st);
+}
+
+// ---- float64 weight preparation ---------------------------------------------------------------
+
+struct TensorMap {
+  std::map<std::string, std::pair<const float*, int64_t>> t;
+  const float* get(const std::string& k, int64_t numel, int& err) const {
+    auto it = t.find(k);
+    if (it == t.end() || it->second.first == nullptr) {
+      err = fail(LINETR_E_WEIGHTS, "state_dict tensor '%s' missing", k.c_str());
+      return nullptr;
+    }
+    if (it->second.second != numel) {
+      err = fail(LINETR_E_WEIGHTS, "state_dict tensor '%s' has %lld elements, expected %lld", k.c_str(),
+                 (long long)it->second.second, (long long)numel);
+      return nullptr;
+    }
+    return it->second.first;
+  }
+};
+
+struct Arena {
+  std::vector<float> host;
+  size_t put(const std::vector<double>& v) {
+    size_t off = (host.size() + 63) / 64 * 64;
+    host.resize(off + v.size());
+    for (size_t i = 0; i < v.size(); ++i) host[off + i] = (float)v[i];
+    return off;
+  }
+};
+
+// Conv1d(k=1)+BatchNorm1d(eval) -> one affine map (models/line_transformer.py:9-20)
+void fold_bn(const float* W, const float* b, const float* g, const float* beta, const float* mean,
+             const float* var, int out, int in, std::vector<double>& Wf, std::vector<double>& bf) {
+  Wf.resize((size_t)out * in);
+  bf.resize(out);
+  for (int o = 0; o < out; ++o) {
+    const double s = (double)g[o] / std::sqrt((double)var[o] + 1e-5);
+    for (int i = 0; i < in; ++i) Wf[(size_t)o * in + i] = (double)W[(size_t)o * in + i] * s;
+    bf[o] = ((double)b[o] - (double)mean[o]) * s + (double)beta[o];
+  }
+}
+
+std::vector<double> to_d(const float* p, size_t n) { return std::vector<double>(p, p + n); }
+
+}  // namespace
+
+// =============================================================================================
+// lifetime
+// =============================================================================================
+
+extern "C" int linetr_abi_version(void) { return LINETR_ABI_VERSION; }
+extern "C" const char* linetr_last_error(void) { return g_err.c_str(); }
+
+extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, const char* const* names,
+                             const float* const* h_data, const int64_t* numel, int32_t device,
+                             LinetrHandle** out) {
+  if (!cfg || !out || !names || !h_data || !numel) return fail(LINETR_E_ARG, "null argument");
+  if (cfg->d_model != D || cfg->n_heads != HEADS)
+    return fail(LINETR_E_ARG, "only descriptor_dim=256 / n_heads=4 are supported");
+  if (cfg->d_inner % 128 != 0 || cfg->n_sig_layers < 0 || cfg->n_desc_layers < 1)
+    return fail(LINETR_E_ARG, "bad d_inner / layer counts");
+  const int e0 = cfg->enc_channels[0], e1 = cfg->enc_channels[1], e2 = cfg->enc_channels[2], e3 = cfg->enc_channels[3];
+  if (e0 != 32 || e1 % 64 || e2 % 64 || e3 % 64 || e3 != D)
+    return fail(LINETR_E_ARG, "keyline_encoder must be [32, 64k, 64k, 256] (got %d,%d,%d,%d)", e0, e1, e2, e3);
+  int ndev = 0;
+  LT_HIP(hipGetDeviceCount(&ndev));
+  if (ndev <= 0 || device >= ndev) return fail(LINETR_E_HIP, "no usable HIP device (count=%d)", ndev);
+  LT_HIP(hipSetDevice(device));
+
+  TensorMap tm;
+  for (int i = 0; i < n_tensors; ++i) tm.t[names[i]] = {h_data[i], numel[i]};
+  int err = 0;
+  Arena ar;
+  auto H = std::make_unique<LinetrHandle>();
+  H->cfg = *cfg;
+  H->device = device;
+  struct Fix { const float** dst; size_t off; };
+  std::vector<Fix> fix;
+  auto place = [&](const float** dst, const std::vector<double>& v) { fix.push_back({dst, ar.put(v)}); };
+
+  // ---- positional encoders: 4 x (conv + BN + ReLU) + linear ------------------------------------
+  const int ch_w[6] = {3, e0, e1, e2, e3, D}, ch_l[6] = {5, e0, e1, e2, e3, D};
+  std::vector<double> W5w, b5w;  // last (linear) layer of the word encoder, consumed algebraically
+  for (int enc = 0; enc < 2; ++enc) {
+    const std::string pre = enc == 0 ? "klenc.word_position_enc.encoder." : "klenc.line_position_enc.encoder.";
+    const int* ch = enc == 0 ? ch_w : ch_l;
+    const float** Wdst[4] = {enc == 0 ? &H->wW1 : &H->lW1, enc == 0 ? &H->wW2 : &H->lW2,
+                             enc == 0 ? &H->wW3 : &H->lW3, enc == 0 ? &H->wW4 : &H->lW4};
+    const float** bdst[4] = {enc == 0 ? &H->wb1 : &H->lb1, enc == 0 ? &H->wb2 : &H->lb2,
+                             enc == 0 ? &H->wb3 : &H->lb3, enc == 0 ? &H->wb4 : &H->lb4};
+    for (int i = 0; i < 4; ++i) {
+      const std::string c = pre + std::to_string(3 * i), bn = pre + std::to_string(3 * i + 1);
+      const float* W = tm.get(c + ".weight", (int64_t)ch[i + 1] * ch[i], err);
+      const float* b = tm.get(c + ".bias", ch[i + 1], err);
+      const float* g = tm.get(bn + ".weight", ch[i + 1], err);
+      const float* be = tm.get(bn + ".bias", ch[i + 1], err);
+      const float* mu = tm.get(bn + ".running_mean", ch[i + 1], err);
+      const float* va = tm.get(bn + ".running_var", ch[i + 1], err);
+      if (err) return err;
+      std::vector<double> Wf, bf;
+      fold_bn(W, b, g, be, mu, va, ch[i + 1], ch[i], Wf, bf);
+      place(Wdst[i], Wf);
+      place(bdst[i], bf);
+    }
+    const float* W = tm.get(pre + "12.weight", (int64_t)D * e3, err);
+    const float* b = tm.get(pre + "12.bias", D, err);
+    if (err) return err;
+    if (enc == 0) { W5w = to_d(W, (size_t)D * D); b5w = to_d(b, D); }
+    else { place(&H->lW5, to_d(W, (size_t)D * D)); place(&H->lb5, to_d(b, D)); }
+  }
+
+  // ---- line-descriptive layer: only the last one matters (line_transformer.py:123-125) ----------
+  {
+    const std::string p = "klenc.desc_layers." + std::to_string(cfg->n_desc_layers - 1) + ".";
+    const float* cls = tm.get("klenc.cls_token", D, err);
+    const float* Wq = tm.get(p + "slf_attn.w_qs.weight", D * D, err);
+    const float* bq = tm.get(p + "slf_attn.w_qs.bias", D, err);
+    const float* Wk = tm.get(p + "slf_attn.w_ks.weight", D * D, err);
+    const float* bk = tm.get(p + "slf_attn.w_ks.bias", D, err);
+    const float* Wv = tm.get(p + "slf_attn.w_vs.weight", D * D, err);
+    const float* bv = tm.get(p + "slf_attn.w_vs.bias", D, err);
+    const float* Wfc = tm.get(p + "slf_attn.fc.weight", D * D, err);
+    const float* bfc = tm.get(p + "slf_attn.fc.bias", D, err);
+    const float* g1 = tm.get(p + "slf_attn.layer_norm.weight", D, err);
+    const float* b1 = tm.get(p + "slf_attn.layer_norm.bias", D, err);
+    const int DI = cfg->d_inner;
+    const float* W1 = tm.get(p + "pos_ffn.w_1.weight", (int64_t)DI * D, err);
+    const float* bb1 = tm.get(p + "pos_ffn.w_1.bias", DI, err);
+    const float* W2 = tm.get(p + "pos_ffn.w_2.weight", (int64_t)D * DI, err);
+    const float* bb2 = tm.get(p + "pos_ffn.w_2.bias", D, err);
+    const float* g2 = tm.get(p + "pos_ffn.layer_norm.weight", D, err);
+    const float* b2 = tm.get(p + "pos_ffn.layer_norm.bias", D, err);
+    if (err) return err;
+    // CLS query, pre-scaled by 1/sqrt(64) (line_attention.py:14)
+    std::vector<double> q(D);
+    for (int o = 0; o < D; ++o) {
+      double s = bq[o];
+      for (int i = 0; i < D; ++i) s += (double)Wq[o * D + i] * cls[i];
+      q[o] = s / 8.0;
+    }
+    std::vector<double> U(HEADS * D, 0.0), U2(HEADS * D, 0.0);
+    for (int h = 0; h < HEADS; ++h) {
+      double c = 0.0;
+      for (int d = 0; d < DH; ++d) {
+        const int o = h * DH + d;  // descriptive heads are head-major (line_attention.py:55-57)
+        c += q[o] * bk[o];
+        for (int i = 0; i < D; ++i) U[h * D + i] += q[o] * Wk[o * D + i];
+      }
+      for (int i = 0; i < D; ++i) {  // U2 = W5^T u_h
+        double s = 0.0;
+        for (int o = 0; o < D; ++o) s += W5w[(size_t)o * D + i] * U[h * D + o];
+        U2[h * D + i] = s;
+      }
+      double ub5 = 0.0, ucls = 0.0;
+      for (int i = 0; i < D; ++i) { ub5 += U[h * D + i] * b5w[i]; ucls += U[h * D + i] * cls[i]; }
+      H->pool.c_tok[h] = (float)(ub5 + c);
+      H->pool.s_cls[h] = (float)(ucls + c);
+    }
+    place(&H->pool.U, U);
+    place(&H->pool.U2, U2);
+    // value path after pooling: att_h = Wv_h dbar + (Wv_h W5) abar + p0 * Wv_h (cls - b5) + (Wv_h b5 + bv_h)
+    std::vector<double> Watt((size_t)HEADS * DH * POOLW, 0.0), batt(HEADS * DH);
+    for (int h = 0; h < HEADS; ++h)
+      for (int d = 0; d < DH; ++d) {
+        const int o = h * DH + d;
+        double* row = &Watt[((size_t)h * DH + d) * POOLW];
+        double r = 0.0, bb = bv[o];
+        for (int i = 0; i < D; ++i) {
+          row[i] = Wv[o * D + i];
+          r += (double)Wv[o * D + i] * ((double)cls[i] - b5w[i]);
+          bb += (double)Wv[o * D + i] * b5w[i];
+        }
+        for (int i = 0; i < D; ++i) {
+          double s = 0.0;
+          for (int m = 0; m < D; ++m) s += (double)Wv[o * D + m] * W5w[(size_t)m * D + i];
+          row[D + i] = s;
+        }
+        row[2 * D] = r;
+        batt[o] = bb;
+      }
+    place(&H->Watt, Watt);
+    place(&H->batt, batt);
+    place(&H->Wfc, to_d(Wfc, D * D));
+    std::vector<double> bfc2(D);
+    for (int i = 0; i < D; ++i) bfc2[i] = (double)bfc[i] + cls[i];  // residual of the CLS row is the constant token
+    place(&H->bfc, bfc2);
+    place(&H->ln1g, to_d(g1, D)); place(&H->ln1b, to_d(b1, D));
+    place(&H->Wf1, to_d(W1, (size_t)DI * D)); place(&H->bf1, to_d(bb1, DI));
+    place(&H->Wf2, to_d(W2, (size_t)D * DI)); place(&H->bf2, to_d(bb2, D));
+    place(&H->ln2g, to_d(g2, D)); place(&H->ln2b, to_d(b2, D));
+  }
+
+  // ---- signature layers --------------------------------------------------------------------------
+  H->sig.resize(cfg->n_sig_layers);
+  for (int l = 0; l < cfg->n_sig_layers; ++l) {
+    const std::string p = "selfattn.layers." + std::to_string(l) + ".";
+    const float* Wp[3];
+    const float* bp[3];
+    for (int j = 0; j < 3; ++j) {
+      Wp[j] = tm.get(p + "attn.proj." + std::to_string(j) + ".weight", D * D, err);
+      bp[j] = tm.get(p + "attn.proj." + std::to_string(j) + ".bias", D, err);
+    }
+    const float* Wm = tm.get(p + "attn.merge.weight", D * D, err);
+    const float* bm = tm.get(p + "attn.merge.bias", D, err);
+    const float* W1 = tm.get(p + "mlp.0.weight", 4 * D * D, err);
+    const float* b1 = tm.get(p + "mlp.0.bias", 2 * D, err);
+    const float* g = tm.get(p + "mlp.1.weight", 2 * D, err);
+    const float* be = tm.get(p + "mlp.1.bias", 2 * D, err);
+    const float* mu = tm.get(p + "mlp.1.running_mean", 2 * D, err);
+    const float* va = tm.get(p + "mlp.1.running_var", 2 * D, err);
+    const float* W2 = tm.get(p + "mlp.3.weight", 2 * D * D, err);
+    const float* b2 = tm.get(p + "mlp.3.bias", D, err);
+    if (err) return err;
+    // reference channel c = d*4 + h (line_transformer.py:151)  ->  head-major c' = h*64 + d;
+    // q additionally scaled by 1/sqrt(64) (:134), an exact power of two.
+    std::vector<double> Wqkv((size_t)3 * D * D), bqkv(3 * D);
+    for (int j = 0; j < 3; ++j)
+      for (int h = 0; h < HEADS; ++h)
+        for (int d = 0; d < DH; ++d) {
+          const int src = d * HEADS + h, dst = j * D + h * DH + d;
+          const double sc = j == 0 ? 0.125 : 1.0;
+          for (int i = 0; i < D; ++i) Wqkv[(size_t)dst * D + i] = (double)Wp[j][src * D + i] * sc;
+          bqkv[dst] = (double)bp[j][src] * sc;
+        }
+    std::vector<double> Wm2((size_t)D * D);
+    for (int o = 0; o < D; ++o)
+      for (int h = 0; h < HEADS; ++h)
+        for (int d = 0; d < DH; ++d) Wm2[(size_t)o * D + h * DH + d] = Wm[o * D + d * HEADS + h];
+    std::vector<double> W1f, b1f;
+    fold_bn(W1, b1, g, be, mu, va, 2 * D, 2 * D, W1f, b1f);
+    SigLayer& S = H->sig[l];
+    place(&S.Wqkv, Wqkv); place(&S.bqkv, bqkv);
+    place(&S.Wm, Wm2); place(&S.bm, to_d(bm, D));
+    place(&S.W1, W1f); place(&S.b1, b1f);
+    place(&S.W2, to_d(W2, (size_t)2 * D * D)); place(&S.b2, to_d(b2, D));
+  }
+  {
+    const float* W = tm.get("final_proj.weight", D * D, err);
+    const float* b = tm.get("final_proj.bias", D, err);
+    if (err) return err;
+    place(&H->Wfin, to_d(W, D * D));
+    place(&H->bfin, to_d(b, D));
+  }
+
+  LT_HIP(hipMalloc((void**)&H->arena, ar.host.size() * sizeof(float)));
+  LT_HIP(hipMemcpy(H->arena, ar.host.data(), ar.host.size() * sizeof(float), hipMemcpyHostToDevice));
+  for (auto& f : fix) *f.dst = H->arena + f.off;
+  *out = H.release();
+  return LINETR_OK;
+}
+
+extern "C" void linetr_destroy(LinetrHandle* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  for (auto& p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto e : h->event_pool) hipEventDestroy(e);
+  if (h->arena) hipFree(h->arena);
+  delete h;
+}
+
+// =============================================================================================
+// host pre-filter
+// =============================================================================================
+
+static int pack_one(LinetrLineRec& r, double td, int T, int image, int line_local, int& sub_cursor) {
+  if (!(td > 0) || T < 1) return fail(LINETR_E_ARG, "token_distance must be > 0 and max_tokens >= 1");
+  const double nt = std::ceil(r.length / td);          // line_process.py:109
+  if (!(nt >= 1) || nt > 1e7) return fail(LINETR_E_ARG, "key-line %d has a non-positive / absurd token count", line_local);
+  r.n_tok = (int)nt;
+  r.n_sub = (r.n_tok + T - 1) / T;                      // :121
+  r.first_sub = sub_cursor;
+  r.image = image;
+  r.line_local = line_local;
+  r.reserved = 0;
+  sub_cursor += r.n_sub;
+  // the reference asserts every walked distance <= geometric length (:44-45)
+  if (r.n_tok >= 2) {
+    const double dx = r.ep[0] - r.sp[0], dy = r.ep[1] - r.sp[1];
+    const double geo = std::sqrt(dx * dx + dy * dy);
+    if (!(geo >= (double)(r.n_tok - 2) * td))
+      return fail(LINETR_E_ASSERT, "distance should be smaller than line length! (key-line %d)", line_local);
+  }
+  return 0;
+}
+
+static void angle_of(LinetrLineRec& r) {  // line_process.py:28-41
+  double th = std::atan2(r.ep[0] - r.sp[0], r.ep[1] - r.sp[1]);
+  if (th < 0) th += M_PI;
+  r.angle[0] = std::cos(2 * th);
+  r.angle[1] = std::sin(2 * th);
+}
+
+extern "C" int linetr_pack_lines(const double* h_klines, const double* h_length, const double* h_angles, int32_t K,
+                                 double td, int32_t T, int32_t image_index, int32_t sub_base,
+                                 LinetrLineRec* h_recs, int32_t* n_out) {
+  if (K < 0 || (K > 0 && (!h_klines || !h_length || !h_angles || !h_recs))) return fail(LINETR_E_ARG, "null argument");
+  int cur = sub_base;
+  for (int k = 0; k < K; ++k) {
+    LinetrLineRec& r = h_recs[k];
+    r.sp[0] = h_klines[k * 4 + 0]; r.sp[1] = h_klines[k * 4 + 1];
+    r.ep[0] = h_klines[k * 4 + 2]; r.ep[1] = h_klines[k * 4 + 3];
+    r.length = h_length[k];
+    r.angle[0] = h_angles[k * 2]; r.angle[1] = h_angles[k * 2 + 1];
+    if (int e = pack_one(r, td, T, image_index, k, cur)) return e;
+  }
+  if (n_out) *n_out = cur - sub_base;
+  return LINETR_OK;
+}
+
+extern "C" int linetr_prefilter(const double* L, int32_t K, int32_t height, int32_t width, int32_t border,
+                                double min_length, int32_t max_keylines, const double* vm, double td, int32_t T,
+                                int32_t image_index, int32_t sub_base, LinetrLineRec* h_recs, int32_t capacity,
+                                int32_t* k_out, int32_t* n_out) {
+  if (K < 0 || (K > 0 && !L) || !k_out || !n_out) return fail(LINETR_E_ARG, "null argument");
+  std::vector<LinetrLineRec> keep;
+  keep.reserve(K);
+  const double xmax = ((double)width - 0.001) - (double)border;   // width-eps-border, line_process.py:72-74
+  const double ymax = ((double)height - 0.001) - (double)border;
+  for (int k = 0; k < K; ++k) {
+    const double* l = L + (size_t)k * 6;
+    LinetrLineRec r{};
+    if (l[0] < l[2]) { r.sp[0] = l[0]; r.sp[1] = l[1]; r.ep[0] = l[2]; r.ep[1] = l[3]; }   // :212-217
+    else { r.sp[0] = l[2]; r.sp[1] = l[3]; r.ep[0] = l[0]; r.ep[1] = l[1]; }
+    r.length = l[4] * std::pow(2.0, l[5]);                                                   // :220
+    const bool inside = r.sp[0] >= border && r.sp[0] < width - border && r.sp[1] >= border && r.sp[1] < height - border &&
+                        r.ep[0] >= border && r.ep[0] < width - border && r.ep[1] >= border && r.ep[1] < height - border;
+    if (!inside) continue;                                                                   // :62-70
+    r.sp[0] = std::min(r.sp[0], xmax); r.ep[0] = std::min(r.ep[0], xmax);
+    r.sp[1] = std::min(r.sp[1], ymax); r.ep[1] = std::min(r.ep[1], ymax);
+    if (vm) {                                                                                // :76-80
+      const int64_t sx = (int64_t)std::floor(r.sp[0]), sy = (int64_t)std::floor(r.sp[1]);
+      const int64_t ex = (int64_t)std::floor(r.ep[0]), ey = (int64_t)std::floor(r.ep[1]);
+      auto at = [&](int64_t y, int64_t x) {  // numpy-style wrap of negative indices
+        if (y < 0) y += height;
+        if (x < 0) x += width;
+        return vm[y * width + x];
+      };
+      if (at(sy, sx) + at(ey, ex) == 0.0) continue;
+    }
+    if (!(r.length > min_length)) continue;                                                  // :8
+    keep.push_back(r);
+  }
+  std::vector<int> idx(keep.size());
+  std::iota(idx.begin(), idx.end(), 0);
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return keep[a].length < keep[b].length; });
+  std::reverse(idx.begin(), idx.end());                                                      // :15-16
+  int64_t n_keep = (int64_t)idx.size();
+  if (max_keylines < 0) n_keep = std::max<int64_t>(0, n_keep + max_keylines);                // python slice [:m]
+  else n_keep = std::min<int64_t>(n_keep, max_keylines);
+  if (n_keep > capacity) return fail(LINETR_E_CAPACITY, "prefilter: %lld lines exceed capacity %d", (long long)n_keep, capacity);
+  int cur = sub_base;
+  for (int64_t i = 0; i < n_keep; ++i) {
+    LinetrLineRec r = keep[idx[i]];
+    angle_of(r);                                                                             // :20
+    if (int e = pack_one(r, td, T, image_index, (int)i, cur)) return e;
+    h_recs[i] = r;
+  }
+  *k_out = (int)n_keep;
+  *n_out = cur - sub_base;
+  return LINETR_OK;
+}
+
+// =============================================================================================
+// tokenise
+// =============================================================================================
+
+extern "C" int64_t linetr_tokenize_workspace_bytes(int32_t n_images, int32_t height, int32_t width, int32_t N) {
+  const int64_t P = (int64_t)(height / 8) * (width / 8);
+  return align_up(n_images * P * D * 4, 256) + align_up((int64_t)std::max(N, 1) * 4, 256) + 256;
+}
+
+extern "C" int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N, double td,
+                               int32_t T, const float* d_dense_desc, const float* d_dense_score, int32_t n_images,
+                               int32_t height, int32_t width, int32_t align_corners, LinetrTokens out,
+                               int32_t* d_sub2line, void* d_ws, int64_t ws_bytes, void* stream) {
+  if (!h) return fail(LINETR_E_ARG, "null handle");
+  if (K <= 0 || N <= 0) return LINETR_OK;
+  if (!d_recs || !d_dense_score || !out.sublines || !out.pnt || !out.mask || !out.resp || !out.angle_sub ||
+      !out.score || (out.desc && !d_dense_desc))
+    return fail(LINETR_E_ARG, "tokenize: null pointer");
+  if (T < 1 || T > 4096 || height % 8 || width % 8) return fail(LINETR_E_ARG, "tokenize: bad max_tokens / image size");
+  if (ws_bytes < linetr_tokenize_workspace_bytes(n_images, height, width, N))
+    return fail(LINETR_E_WORKSPACE, "tokenize: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  LT_HIP(hipSetDevice(h->device));
+  const int Hc = height / 8, Wc = width / 8, P = Hc * Wc;
+  float* nhwc = (float*)d_ws;
+  int* s2l_g = (int*)((char*)d_ws + align_up((int64_t)n_images * P * D * 4, 256));
+  {
+    ProfScope ps(h, st, "line_fill", 0, (double)K * 80 + (double)N * 8);
+    hipLaunchKernelGGL(line_fill_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, d_recs, K, (double)width - 0.6,
+                       (double)height - 0.6, out.klines, out.length, out.angles, s2l_g, d_sub2line);
+    LT_LAUNCH_CHECK();
+  }
+  {
+    ProfScope ps(h, st, "tokenize", 0, (double)N * T * 16);
+    hipLaunchKernelGGL(tokenize_kernel, dim3(N), dim3(64), 0, st, d_recs, s2l_g, N, td, T, height, width,
+                       d_dense_score, out.sublines, out.pnt, out.mask, out.resp, out.angle_sub, out.score);
+    LT_LAUNCH_CHECK();
+  }
+  if (out.desc) {
+    {
+      ProfScope ps(h, st, "nchw_to_nhwc", 0, 2.0 * n_images * P * D * 4);
+      hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(P, 32), D / 32, n_images), dim3(32, 8), 0, st, d_dense_desc,
+                         nhwc, D, P);
+      LT_LAUNCH_CHECK();
+    }
+    const int64_t ntok = (int64_t)N * T;
+    ProfScope ps(h, st, "sample_desc", 0, (double)ntok * D * 4 * 2);
+    hipLaunchKernelGGL(sample_desc_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, st, out.pnt, s2l_g, d_recs,
+                       ntok, T, nhwc, Hc, Wc, align_corners, out.desc);
+    LT_LAUNCH_CHECK();
+  }
+  return LINETR_OK;
+}
+
+// =============================================================================================
+// forward
+// =============================================================================================
+
+namespace {
+struct FwdWs {
+  float *a1, *a2, *a3, *a4, *pooled, *att, *fc, *o, *f1, *f2, *l1, *l2, *l3, *l4, *lpos, *zA, *zB, *qkv, *msgp, *msg, *hid;
+  int* cu;
+  int64_t total;
+};
+FwdWs fwd_layout(const LinetrModelConfig& c, int N, int T, int n_images, char* base) {
+  FwdWs w;
+  int64_t off = 0;
+  auto take = [&](int64_t floats) { float* p = (float*)(base + off); off += align_up(floats * 4, 256); return p; };
+  const int64_t rows = (int64_t)N * T;
+  w.a1 = take(rows * c.enc_channels[0]); w.a2 = take(rows * c.enc_channels[1]);
+  w.a3 = take(rows * c.enc_channels[2]); w.a4 = take(rows * c.enc_channels[3]);
+  w.pooled = take((int64_t)N * HEADS * POOLW);
+  w.att = take((int64_t)N * D); w.fc = take((int64_t)N * D); w.o = take((int64_t)N * D);
+  w.f1 = take((int64_t)N * c.d_inner); w.f2 = take((int64_t)N * D);
+  w.l1 = take((int64_t)N * c.enc_channels[0]); w.l2 = take((int64_t)N * c.enc_channels[1]);
+  w.l3 = take((int64_t)N * c.enc_channels[2]); w.l4 = take((int64_t)N * c.enc_channels[3]);
+  w.lpos = take((int64_t)N * D);
+  w.zA = take((int64_t)N * D); w.zB = take((int64_t)N * D);
+  w.qkv = take((int64_t)N * 3 * D); w.msgp = take((int64_t)N * D); w.msg = take((int64_t)N * D);
+  w.hid = take((int64_t)N * 2 * D);
+  w.cu = (int*)take(n_images + 1);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" int64_t linetr_forward_workspace_bytes(const LinetrHandle* h, int32_t N, int32_t T) {
+  if (!h) return -1;
+  // the image count only sizes a tiny prefix-sum array; reserve for the worst case (every sub-line its own image)
+  return fwd_layout(h->cfg, std::max(N, 1), T, std::max(N, 1), nullptr).total;
+}
+
+extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const int32_t* h_cu, int32_t n_images,
+                              int32_t T, float* d_line_desc, void* d_ws, int64_t ws_bytes, void* stream) {
+  if (!h || !tok || !h_cu || n_images < 1) return fail(LINETR_E_ARG, "forward: null argument");
+  const int N = h_cu[n_images];
+  if (N <= 0) return LINETR_OK;
+  if (!tok->sublines || !tok->pnt || !tok->resp || !tok->angle_sub || !tok->desc || !tok->score || !d_line_desc)
+    return fail(LINETR_E_ARG, "forward: null tensor");
+  int max_n = 0;
+  for (int i = 0; i < n_images; ++i) {
+    if (h_cu[i + 1] < h_cu[i]) return fail(LINETR_E_ARG, "forward: cu_sub not monotone");
+    max_n = std::max(max_n, h_cu[i + 1] - h_cu[i]);
+  }
+  if (h_cu[0] != 0) return fail(LINETR_E_ARG, "forward: cu_sub[0] != 0");
+  if (ws_bytes < linetr_forward_workspace_bytes(h, N, T)) return fail(LINETR_E_WORKSPACE, "forward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  LT_HIP(hipSetDevice(h->device));
+  const LinetrModelConfig& c = h->cfg;
+  FwdWs w = fwd_layout(c, N, T, std::max(N, 1), (char*)d_ws);
+  LT_HIP(hipMemcpyAsync(w.cu, h_cu, (n_images + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+  const int64_t rows = (int64_t)N * T;
+  if (rows > INT32_MAX / 2) return fail(LINETR_E_ARG, "forward: batch too large");
+  const int e0 = c.enc_channels[0], e1 = c.enc_channels[1], e2 = c.enc_channels[2], e3 = c.enc_channels[3];
+  const float cx = c.norm_width / 2.f, cy = c.norm_height / 2.f;           // line_transformer.py:30-32
+  const float scale = (float)std::max(c.norm_width, c.norm_height) * 0.7f;
+  int e;
+  // ---- word positional encoder up to the last ReLU (a4); its final linear layer is applied after pooling
+  {
+    ProfScope ps(h, st, "mlp_first", 2.0 * rows * 3 * e0, (double)rows * (12 + 4 * e0));
+    hipLaunchKernelGGL(word_mlp1_kernel, dim3((unsigned)cdiv((int)(rows * 8), 256)), dim3(256), 0, st, tok->pnt,
+                       tok->score, rows, cx, cy, scale, h->wW1, h->wb1, w.a1);
+    LT_LAUNCH_CHECK();
+  }
+  if ((e = run_gemm(h, st, w.a1, e0, nullptr, 0, 0, h->wW2, h->wb2, nullptr, 0, w.a2, e1, (int)rows, e1, e0, ACT_RELU))) return e;
+  if ((e = run_gemm(h, st, w.a2, e1, nullptr, 0, 0, h->wW3, h->wb3, nullptr, 0, w.a3, e2, (int)rows, e2, e1, ACT_RELU))) return e;
+  if ((e = run_gemm(h, st, w.a3, e2, nullptr, 0, 0, h->wW4, h->wb4, nullptr, 0, w.a4, e3, (int)rows, e3, e2, ACT_RELU))) return e;
+  // ---- CLS-row attention pooling + value/last-MLP projection
+  {
+    ProfScope ps(h, st, "cls_pool", 2.0 * rows * (2.0 * HEADS * D * 2), (double)rows * D * 8);
+    hipLaunchKernelGGL(cls_pool_kernel, dim3(N), dim3(256), HEADS * (T + 1) * sizeof(float), st, tok->desc, w.a4, T,
+                       h->pool, w.pooled);
+    LT_LAUNCH_CHECK();
+  }
+  if ((e = run_gemm(h, st, w.pooled, HEADS * POOLW, nullptr, 0, 0, h->Watt, h->batt, nullptr, 0, w.att, D, N, DH, POOLW,
+                    ACT_NONE, HEADS, POOLW, (int64_t)DH * POOLW, DH, DH))) return e;
+  if ((e = run_gemm(h, st, w.att, D, nullptr, 0, 0, h->Wfc, h->bfc, nullptr, 0, w.fc, D, N, D, D, ACT_NONE))) return e;
+  {
+    ProfScope ps(h, st, "row_norm", 0, (double)N * D * 8);
+    hipLaunchKernelGGL(row_norm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, w.fc, N, 0, h->ln1g, h->ln1b,
+                       (const float*)nullptr, 1e-6f, w.o);
+    LT_LAUNCH_CHECK();
+  }
+  if ((e = run_gemm(h, st, w.o, D, nullptr, 0, 0, h->Wf1, h->bf1, nullptr, 0, w.f1, c.d_inner, N, c.d_inner, D, ACT_GELU))) return e;
+  if ((e = run_gemm(h, st, w.f1, c.d_inner, nullptr, 0, 0, h->Wf2, h->bf2, w.o, D, w.f2, D, N, D, c.d_inner, ACT_NONE))) return e;
+  // ---- line positional encoder
+  {
+    ProfScope ps(h, st, "mlp_first", 2.0 * N * 5 * e0, (double)N * (28 + 4 * e0));
+    hipLaunchKernelGGL(line_mlp1_kernel, dim3(cdiv(N * 8, 256)), dim3(256), 0, st, tok->sublines, tok->resp,
+                       tok->angle_sub, N, cx, cy, scale, h->lW1, h->lb1, w.l1);
+    LT_LAUNCH_CHECK();
+  }
+  if ((e = run_gemm(h, st, w.l1, e0, nullptr, 0, 0, h->lW2, h->lb2, nullptr, 0, w.l2, e1, N, e1, e0, ACT_RELU))) return e;
+  if ((e = run_gemm(h, st, w.l2, e1, nullptr, 0, 0, h->lW3, h->lb3, nullptr, 0, w.l3, e2, N, e2, e1, ACT_RELU))) return e;
+  if ((e = run_gemm(h, st, w.l3, e2, nullptr, 0, 0, h->lW4, h->lb4, nullptr, 0, w.l4, e3, N, e3, e2, ACT_RELU))) return e;
+  if ((e = run_gemm(h, st, w.l4, e3, nullptr, 0, 0, h->lW5, h->lb5, nullptr, 0, w.lpos, D, N, D, e3, ACT_NONE))) return e;
+  {  // sentence = line_pos + LN(ffn) (line_transformer.py:128)
+    ProfScope ps(h, st, "row_norm", 0, (double)N * D * 12);
+    hipLaunchKernelGGL(row_norm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, w.f2, N, 0, h->ln2g, h->ln2b, w.lpos, 1e-6f, w.zA);
+    LT_LAUNCH_CHECK();
+  }
+  // ---- line signature network
+  float *z = w.zA, *zn = w.zB;
+  const int qtiles = cdiv(max_n, ATT_QT);
+  for (size_t l = 0; l < h->sig.size(); ++l) {
+    const SigLayer& S = h->sig[l];
+    if ((e = run_gemm(h, st, z, D, nullptr, 0, 0, S.Wqkv, S.bqkv, nullptr, 0, w.qkv, 3 * D, N, 3 * D, D, ACT_NONE))) return e;
+    {
+      double fl = 0;
+      for (int i = 0; i < n_images; ++i) { double n = h_cu[i + 1] - h_cu[i]; fl += 2.0 * 2.0 * n * n * D; }
+      ProfScope ps(h, st, "sig_attn", fl, (double)N * D * 16);
+      hipLaunchKernelGGL(sig_attn_kernel, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, w.cu, w.msgp);
+      LT_LAUNCH_CHECK();
+    }
+    if ((e = run_gemm(h, st, w.msgp, D, nullptr, 0, 0, S.Wm, S.bm, nullptr, 0, w.msg, D, N, D, D, ACT_NONE))) return e;
+    if ((e = run_gemm(h, st, z, D, w.msg, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ACT_RELU))) return e;
+    if ((e = run_gemm(h, st, w.hid, 2 * D, nullptr, 0, 0, S.W2, S.b2, z, D, zn, D, N, D, 2 * D, ACT_NONE))) return e;
+    std::swap(z, zn);
+  }
+  if ((e = run_gemm(h, st, z, D, nullptr, 0, 0, h->Wfin, h->bfin, nullptr, 0, zn, D, N, D, D, ACT_NONE))) return e;
+  {
+    ProfScope ps(h, st, "row_norm", 0, (double)N * D * 8);
+    hipLaunchKernelGGL(row_norm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, zn, N, 1, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, 0.f, d_line_desc);
+    LT_LAUNCH_CHECK();
+  }
+  return LINETR_OK;
+}
+
+// =============================================================================================
+// matcher
+// =============================================================================================
+
+extern "C" int64_t linetr_match_workspace_bytes(int32_t n_pairs, int64_t sum_n0n1, int64_t sum_k0k1, int64_t sum_k) {
+  (void)sum_k0k1;
+  return align_up((int64_t)n_pairs * sizeof(PairDesc), 256) + align_up(sum_n0n1 * 4, 256) +
+         align_up((3 * sum_k + 4 * (int64_t)n_pairs) * 4, 256) + 256;
+}
+
+extern "C" int linetr_match(LinetrHandle* h, int32_t P, const int32_t* dims, const float* d_desc0, const int64_t* off_n0,
+                            const int32_t* d_s2l0, const float* d_desc1, const int64_t* off_n1, const int32_t* d_s2l1,
+                            float thr, int32_t mutual, float* d_dk, const int64_t* off_dk, int32_t* d_match01,
+                            const int64_t* off_k0, void* d_ws, int64_t ws_bytes, void* stream) {
+  if (!h || P < 0) return fail(LINETR_E_ARG, "match: bad argument");
+  if (P == 0) return LINETR_OK;
+  if (!dims || !off_n0 || !off_n1 || !off_dk || !off_k0 || !d_ws) return fail(LINETR_E_ARG, "match: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  LT_HIP(hipSetDevice(h->device));
+  std::vector<PairDesc> pd(P);
+  int64_t od = 0, os = 0, sum_k = 0;
+  int max_n0 = 0, max_n1 = 0;
+  double flops = 0;
+  for (int p = 0; p < P; ++p) {
+    PairDesc& d = pd[p];
+    d.n0 = dims[p * 4 + 0]; d.k0 = dims[p * 4 + 1]; d.n1 = dims[p * 4 + 2]; d.k1 = dims[p * 4 + 3];
+    if (d.n0 < 0 || d.n1 < 0 || d.k0 < 0 || d.k1 < 0 || d.k0 > d.n0 || d.k1 > d.n1)
+      return fail(LINETR_E_ARG, "match: bad dims for pair %d", p);
+    d.off_n0 = off_n0[p]; d.off_n1 = off_n1[p]; d.off_dk = off_dk[p]; d.off_k0 = off_k0[p];
+    d.off_d = od; od += (int64_t)d.n0 * d.n1;
+    d.off_seg = os; os += 3 * (int64_t)(d.k0 + d.k1) / 1 + 4;  // seg0,seg1,row_arg,col_arg,row_min (<= 3*(k0+k1)+2)
+    sum_k += d.k0 + d.k1;
+    max_n0 = std::max(max_n0, d.n0); max_n1 = std::max(max_n1, d.n1);
+    flops += 2.0 * d.n0 * d.n1 * D;
+  }
+  if (ws_bytes < linetr_match_workspace_bytes(P, od, 0, sum_k)) return fail(LINETR_E_WORKSPACE, "match: workspace too small");
+  char* base = (char*)d_ws;
+  PairDesc* d_pd = (PairDesc*)base;
+  float* d_dist = (float*)(base + align_up((int64_t)P * sizeof(PairDesc), 256));
+  int* d_scr = (int*)((char*)d_dist + align_up(od * 4, 256));
+  LT_HIP(hipMemcpyAsync(d_pd, pd.data(), P * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+  if (max_n0 > 0 && max_n1 > 0) {
+    if (!d_desc0 || !d_desc1 || !d_s2l0 || !d_s2l1 || !d_dk) return fail(LINETR_E_ARG, "match: null tensor");
+    ProfScope ps(h, st, "pair_dist", flops, 0);
+    hipLaunchKernelGGL(pair_dist_kernel, dim3(cdiv(max_n1, 64), cdiv(max_n0, 64), P), dim3(256), 0, st, d_pd, d_desc0,
+                       d_desc1, d_dist);
+    LT_LAUNCH_CHECK();
+  }
+  {
+    ProfScope ps(h, st, "pair_match", 0, 0);
+    hipLaunchKernelGGL(pair_match_kernel, dim3(P), dim3(256), 0, st, d_pd, d_s2l0, d_s2l1, d_dist, thr, mutual, d_dk,
+                       d_match01, d_scr);
+    LT_LAUNCH_CHECK();
+  }
+  // the PairDesc table was copied from a stack-owned vector: make sure the copy has been consumed
+  LT_HIP(hipStreamSynchronize(st));
+  return LINETR_OK;
+}
+
+extern "C" int linetr_match_points(LinetrHandle* h, const float* d0_cn, int32_t n0, const float* d1_cn, int32_t n1,
+                                   float thr, int32_t mutual, float* d_dist, int32_t* d_match01, void* d_ws,
+                                   int64_t ws_bytes, void* stream) {
+  if (!h || n0 < 0 || n1 < 0) return fail(LINETR_E_ARG, "match_points: bad argument");
+  if (n0 == 0) return LINETR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  LT_HIP(hipSetDevice(h->device));
+  // scratch: row-major copies + identity sub2line maps + the generic matcher's workspace
+  const int64_t need_t = align_up((int64_t)n0 * D * 4, 256) + align_up((int64_t)std::max(n1, 1) * D * 4, 256) +
+                         align_up((int64_t)n0 * 4, 256) + align_up((int64_t)std::max(n1, 1) * 4, 256);
+  const int64_t need_m = linetr_match_workspace_bytes(1, (int64_t)n0 * n1, 0, n0 + n1);
+  if (ws_bytes < need_t + need_m) return fail(LINETR_E_WORKSPACE, "match_points: workspace too small (need %lld)", (long long)(need_t + need_m));
+  char* base = (char*)d_ws;
+  float* r0 = (float*)base; base += align_up((int64_t)n0 * D * 4, 256);
+  float* r1 = (float*)base; base += align_up((int64_t)std::max(n1, 1) * D * 4, 256);
+  int* id0 = (int*)base; base += align_up((int64_t)n0 * 4, 256);
+  int* id1 = (int*)base; base += align_up((int64_t)std::max(n1, 1) * 4, 256);
+  std::vector<int> iota(std::max(n0, n1));
+  std::iota(iota.begin(), iota.end(), 0);
+  LT_HIP(hipMemcpyAsync(id0, iota.data(), n0 * 4, hipMemcpyHostToDevice, st));
+  if (n1 > 0) LT_HIP(hipMemcpyAsync(id1, iota.data(), n1 * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(transpose_cn_kernel, dim3(cdiv(n0, 32), D / 32), dim3(32, 8), 0, st, d0_cn, r0, D, n0);
+  if (n1 > 0) hipLaunchKernelGGL(transpose_cn_kernel, dim3(cdiv(n1, 32), D / 32), dim3(32, 8), 0, st, d1_cn, r1, D, n1);
+  LT_LAUNCH_CHECK();
+  const int32_t dims[4] = {n0, n0, n1, n1};
+  const int64_t zero = 0;
+  return linetr_match(h, 1, dims, r0, &zero, id0, r1, &zero, id1, thr, mutual, d_dist, &zero, d_match01, &zero, base,
+                      ws_bytes - need_t, stream);
+}
+
+// =============================================================================================
+// profiling
+// =============================================================================================
+
+extern "C" int linetr_set_profiling(LinetrHandle* h, int32_t on) {
+  if (!h) return fail(LINETR_E_ARG, "null handle");
+  for (auto& p : h->pending) { h->event_pool.push_back(p.a); h->event_pool.push_back(p.b); }
+  h->pending.clear();
+  h->classes.clear();
+  h->profiling = on != 0;
+  return LINETR_OK;
+}
+
+extern "C" int linetr_get_profile(LinetrHandle* h, LinetrProfileEntry* out, int32_t max_entries, int32_t* n_out) {
+  if (!h || !n_out) return fail(LINETR_E_ARG, "null argument");
+  LT_HIP(hipSetDevice(h->device));
+  for (auto& p : h->pending) {
+    LT_HIP(hipEventSynchronize(p.b));
+    float ms = 0.f;
+    LT_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+    h->classes[p.cls].ms += ms;
+    h->event_pool.push_back(p.a);
+    h->event_pool.push_back(p.b);
+  }
+  h->pending.clear();
+  const int n = std::min<int>((int)h->classes.size(), max_entries);
+  for (int i = 0; i < n; ++i) {
+    out[i].name = h->classes[i].name;
+    out[i].calls = h->classes[i].calls;
+    out[i].ms = h->classes[i].ms;
+    out[i].flops = h->classes[i].flops;
+    out[i].bytes = h->classes[i].bytes;
+  }
+  *n_out = (int)h->classes.size();
+  return LINETR_OK;
+}

@@ -1,0 +1,159 @@
+// Descriptor-distance matcher on the device: get_dist_matrix (models/line_process.py:198-201),
+// subline2keyline (models/line_transformer.py:277-282) and nn_matcher_distmat
+// (models/nn_matcher.py:3-31).
+#pragma once
+#include "lt_common.h"
+
+namespace lt {
+
+struct PairDesc {          // one image pair (device copy lives in the workspace)
+  int n0, k0, n1, k1;
+  int64_t off_n0, off_n1;  // row offsets into desc0 / desc1 / sub2line0 / sub2line1
+  int64_t off_d;           // offset of D [n0,n1] in the workspace
+  int64_t off_dk;          // offset of Dk [k0,k1] in the output
+  int64_t off_k0;          // offset of match01 [k0]
+  int64_t off_seg;         // offset of the segment tables / argmin scratch (ints) in the workspace
+};
+
+// D[a][b] = max(2 - 2 * <d0[a], d1[b]>, 0), fp32 MFMA, 64x64 tile per block, K = 256.
+// grid (tiles_b, tiles_a, pair)
+__global__ __launch_bounds__(256) void pair_dist_kernel(const PairDesc* __restrict__ pairs,
+                                                        const float* __restrict__ desc0,
+                                                        const float* __restrict__ desc1, float* __restrict__ dist) {
+  constexpr int LS = 36;
+  __shared__ __attribute__((aligned(16))) float As[64 * LS];
+  __shared__ __attribute__((aligned(16))) float Bs[64 * LS];
+  const PairDesc pd = pairs[blockIdx.z];
+  const int a0 = blockIdx.y * 64, b0 = blockIdx.x * 64;
+  if (a0 >= pd.n0 || b0 >= pd.n1) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wa = wave >> 1, wb = wave & 1;
+  const float* A = desc0 + pd.off_n0 * D;
+  const float* B = desc1 + pd.off_n1 * D;
+  const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < D; k0 += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int ra = a0 + lrow + i * 32; ra = ra < pd.n0 ? ra : pd.n0 - 1;
+      int rb = b0 + lrow + i * 32; rb = rb < pd.n1 ? rb : pd.n1 - 1;
+      *reinterpret_cast<f32x4*>(&As[(lrow + i * 32) * LS + lc4]) =
+          *reinterpret_cast<const f32x4*>(A + (int64_t)ra * D + k0 + lc4);
+      *reinterpret_cast<f32x4*>(&Bs[(lrow + i * 32) * LS + lc4]) =
+          *reinterpret_cast<const f32x4*>(B + (int64_t)rb * D + k0 + lc4);
+    }
+    __syncthreads();
+    const float* ap = &As[(wa * 32 + (lane & 31)) * LS + (lane >> 5) * 4];
+    const float* bp = &Bs[(wb * 32 + (lane & 31)) * LS + (lane >> 5) * 4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk * 8);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bp + kk * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    }
+  }
+  float* Dp = dist + pd.off_d;
+  const int col = b0 + wb * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = a0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < pd.n0 && col < pd.n1) Dp[(int64_t)row * pd.n1 + col] = fmaxf(2.f - 2.f * acc[r], 0.f);
+  }
+}
+
+// One block per pair: key-line pooling (mean of sub-line distances), row/column first-index argmin,
+// strict threshold and mutual check.  Deterministic (fixed summation order, no atomics).
+// Scratch ints at off_seg: seg0[k0+1], seg1[k1+1], row_arg[k0], col_arg[k1]; row_min floats alias.
+__global__ __launch_bounds__(256) void pair_match_kernel(const PairDesc* __restrict__ pairs,
+                                                         const int* __restrict__ s2l0, const int* __restrict__ s2l1,
+                                                         const float* __restrict__ dist, float thr, int mutual,
+                                                         float* __restrict__ dk_out, int* __restrict__ match01,
+                                                         int* __restrict__ scratch) {
+  const PairDesc pd = pairs[blockIdx.x];
+  const int tid = threadIdx.x;
+  int* seg0 = scratch + pd.off_seg;
+  int* seg1 = seg0 + pd.k0 + 1;
+  int* row_arg = seg1 + pd.k1 + 1;
+  int* col_arg = row_arg + pd.k0;
+  float* row_min = reinterpret_cast<float*>(col_arg + pd.k1);
+  const int* m0 = s2l0 + pd.off_n0;
+  const int* m1 = s2l1 + pd.off_n1;
+  // segment starts: sub-lines of a key-line are contiguous and key-line ids non-decreasing
+  for (int n = tid; n < pd.n0; n += 256)
+    if (n == 0 || m0[n] != m0[n - 1]) seg0[m0[n]] = n;
+  for (int n = tid; n < pd.n1; n += 256)
+    if (n == 0 || m1[n] != m1[n - 1]) seg1[m1[n]] = n;
+  if (tid == 0) { seg0[pd.k0] = pd.n0; seg1[pd.k1] = pd.n1; }
+  __syncthreads();
+  const float* Dp = dist + pd.off_d;
+  float* Dk = dk_out + pd.off_dk;
+  const int total = pd.k0 * pd.k1;
+  for (int e = tid; e < total; e += 256) {
+    const int i = e / pd.k1, j = e % pd.k1;
+    const int a0 = seg0[i], a1 = seg0[i + 1], b0 = seg1[j], b1 = seg1[j + 1];
+    float v;
+    if (a1 - a0 == 1 && b1 - b0 == 1) {
+      v = Dp[(int64_t)a0 * pd.n1 + b0];
+    } else {  // (A0 @ D) @ A1^T with A rows = 1/num_sublines
+      const float w0 = 1.f / (float)(a1 - a0), w1 = 1.f / (float)(b1 - b0);
+      v = 0.f;
+      for (int b = b0; b < b1; ++b) {
+        float t = 0.f;
+        for (int a = a0; a < a1; ++a) t += w0 * Dp[(int64_t)a * pd.n1 + b];
+        v += t * w1;
+      }
+    }
+    Dk[e] = v;
+  }
+  __syncthreads();
+  // argmin over clip(min=0) values; np.argmin returns the first minimum
+  for (int i = tid; i < pd.k0; i += 256) {
+    float best = INFINITY; int arg = 0;
+    for (int j = 0; j < pd.k1; ++j) {
+      const float v = fmaxf(Dk[(int64_t)i * pd.k1 + j], 0.f);
+      if (v < best) { best = v; arg = j; }
+    }
+    row_arg[i] = arg; row_min[i] = best;
+  }
+  for (int j = tid; j < pd.k1; j += 256) {
+    float best = INFINITY; int arg = 0;
+    for (int i = 0; i < pd.k0; ++i) {
+      const float v = fmaxf(Dk[(int64_t)i * pd.k1 + j], 0.f);
+      if (v < best) { best = v; arg = i; }
+    }
+    col_arg[j] = arg;
+  }
+  __syncthreads();
+  int* mo = match01 + pd.off_k0;
+  for (int i = tid; i < pd.k0; i += 256) {
+    int j = -1;
+    if (pd.k1 > 0) {
+      const int a = row_arg[i];
+      bool keep = row_min[i] < thr;
+      if (mutual) keep = keep && (col_arg[a] == i);
+      if (keep) j = a;
+    }
+    mo[i] = j;
+  }
+}
+
+// [256][n] (SuperPoint 'descriptors' layout) -> [n][256]
+__global__ void transpose_cn_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int n) {
+  __shared__ float tile[32][33];
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    int p = p0 + threadIdx.x;
+    tile[i][threadIdx.x] = p < n ? in[(int64_t)(c0 + i) * n + p] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    int p = p0 + i;
+    if (p < n) out[(int64_t)p * C + c0 + threadIdx.x] = tile[threadIdx.x][i];
+  }
+}
+
+}  // namespace lt

@@ -1,0 +1,298 @@
+// Non-GEMM device stages of LineTransformer.forward (models/line_transformer.py:225-249).
+#pragma once
+#include "lt_common.h"
+
+namespace lt {
+
+// ---------------------------------------------------------------------------------------------
+// First MLP layer of the two positional encoders on the VALU (3 -> 32 and 5 -> 32, BN folded, ReLU),
+// fused with normalize_keylines (models/line_transformer.py:22-38, :40-73).
+// 8 threads per row, 4 output channels each.
+// ---------------------------------------------------------------------------------------------
+__global__ void word_mlp1_kernel(const float* __restrict__ pnt, const float* __restrict__ score, int64_t rows,
+                                 float cx, float cy, float scale, const float* __restrict__ W /*[32][3]*/,
+                                 const float* __restrict__ b, float* __restrict__ out /*[rows][32]*/) {
+#pragma clang fp contract(off)
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = gid >> 3;
+  if (row >= rows) return;
+  const int c0 = (int)(gid & 7) * 4;
+  const float x = (pnt[row * 2 + 0] - cx) / scale;
+  const float y = (pnt[row * 2 + 1] - cy) / scale;
+  const float s = score[row];
+  f32x4 o;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float* w = W + (c0 + c) * 3;
+    float v = b[c0 + c] + w[0] * x + w[1] * y + w[2] * s;
+    o[c] = fmaxf(v, 0.f);
+  }
+  *reinterpret_cast<f32x4*>(out + row * 32 + c0) = o;
+}
+
+__global__ void line_mlp1_kernel(const float* __restrict__ sublines /*[N][2][2]*/, const float* __restrict__ resp,
+                                 const float* __restrict__ angle, int N, float cx, float cy, float scale,
+                                 const float* __restrict__ W /*[32][5]*/, const float* __restrict__ b,
+                                 float* __restrict__ out /*[N][32]*/) {
+#pragma clang fp contract(off)
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = gid >> 3;
+  if (row >= N) return;
+  const int c0 = (gid & 7) * 4;
+  const float* sl = sublines + (int64_t)row * 4;
+  const float sx = (sl[0] - cx) / scale, sy = (sl[1] - cy) / scale;
+  const float ex = (sl[2] - cx) / scale, ey = (sl[3] - cy) / scale;
+  const float in[5] = {(sx + ex) / 2.f, (sy + ey) / 2.f, resp[row], angle[row * 2], angle[row * 2 + 1]};
+  f32x4 o;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float* w = W + (c0 + c) * 5;
+    float v = b[c0 + c];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) v += w[i] * in[i];
+    o[c] = fmaxf(v, 0.f);
+  }
+  *reinterpret_cast<f32x4*>(out + (int64_t)row * 32 + c0) = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CLS-row attention pooling of the line-descriptive layer (models/line_attention.py:6-75 restricted
+// to query row 0, the only row that reaches the output: models/line_transformer.py:128).
+//
+// For head h the CLS query q_h is a model constant, so
+//     score_hj = q_h . (Wk_h x_j + bk_h) = u_h . x_j + c_h ,   x_j = desc_j + W5 a4_j + b5
+//              = u_h . desc_j + (W5^T u_h) . a4_j + const_h
+// and the attention output only needs the attention-weighted means of desc_j and a4_j (the value and
+// last-MLP projections are linear, they are applied after pooling by a [N x 544] x [544 x 64] GEMM).
+// One 256-thread block per sub-line.
+//   pooled[n][h] = [ sum_j p_hj desc_j (256) | sum_j p_hj a4_j (256) | p_h0 | 0 x31 ]
+// ---------------------------------------------------------------------------------------------
+struct ClsPoolConst {
+  const float* U;     // [4][256]  u_h
+  const float* U2;    // [4][256]  W5^T u_h
+  float c_tok[4];     // u_h.b5 + c_h   (additive constant of token rows)
+  float s_cls[4];     // u_h.cls + c_h  (score of the CLS key, row 0)
+};
+
+__global__ __launch_bounds__(256) void cls_pool_kernel(const float* __restrict__ desc /*[N][T][256]*/,
+                                                       const float* __restrict__ a4 /*[N*T][256]*/, int T,
+                                                       ClsPoolConst cc, float* __restrict__ pooled /*[N][4][544]*/) {
+  extern __shared__ float sm[];  // [4][T+1]
+  const int S = T + 1;
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* dn = desc + (int64_t)n * T * D;
+  const float* an = a4 + (int64_t)n * T * D;
+  f32x4 u[4], u2[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    u[h] = *reinterpret_cast<const f32x4*>(cc.U + h * D + lane * 4);
+    u2[h] = *reinterpret_cast<const f32x4*>(cc.U2 + h * D + lane * 4);
+  }
+  for (int j = wave; j < T; j += 4) {
+    const f32x4 dv = *reinterpret_cast<const f32x4*>(dn + j * D + lane * 4);
+    const f32x4 av = *reinterpret_cast<const f32x4*>(an + j * D + lane * 4);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      float p = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) p += dv[c] * u[h][c] + av[c] * u2[h][c];
+      p = wave_sum(p);
+      if (lane == 0) sm[h * S + 1 + j] = p + cc.c_tok[h];
+    }
+  }
+  if (tid < 4) sm[tid * S] = cc.s_cls[tid];
+  __syncthreads();
+  if (tid < 4) {  // softmax over the S keys of head `tid` (F.softmax, line_attention.py:18)
+    float* s = sm + tid * S;
+    float mx = s[0];
+    for (int j = 1; j < S; ++j) mx = fmaxf(mx, s[j]);
+    float sum = 0.f;
+    for (int j = 0; j < S; ++j) { s[j] = expf(s[j] - mx); sum += s[j]; }
+    for (int j = 0; j < S; ++j) s[j] = s[j] / sum;
+  }
+  __syncthreads();
+  float db[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < T; ++j) {
+    const float dv = dn[j * D + tid], av = an[j * D + tid];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const float p = sm[h * S + 1 + j];
+      db[h] += p * dv;
+      ab[h] += p * av;
+    }
+  }
+  float* out = pooled + (int64_t)n * 4 * POOLW;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    out[h * POOLW + tid] = db[h];
+    out[h * POOLW + 256 + tid] = ab[h];
+  }
+  if (tid < 4 * 32) {
+    const int h = tid >> 5, i = tid & 31;
+    out[h * POOLW + 512 + i] = i == 0 ? sm[h * S] : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row kernels over [rows][256]; one wave64 per row, lane = 4 channels.
+//   mode 0: y = LayerNorm(x) * gamma + beta (+ add)      eps = 1e-6 (models/line_attention.py:40,83)
+//   mode 1: y = x / max(||x||_2, 1e-12)                  F.normalize (models/line_transformer.py:246)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__ x, int rows, int mode,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ add, float eps, float* __restrict__ y) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)row * D + lane * 4);
+  f32x4 o;
+  if (mode == 0) {
+    float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { float d = v[c] - mean; q += d * d; }
+    const float rstd = 1.f / sqrtf(wave_sum(q) * (1.f / D) + eps);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + lane * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + lane * 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = (v[c] - mean) * rstd * g[c] + b[c];
+    if (add) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(add + (int64_t)row * D + lane * 4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c] += a[c];
+    }
+  } else {
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q += v[c] * v[c];
+    const float nrm = fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = v[c] / nrm;
+  }
+  *reinterpret_cast<f32x4*>(y + (int64_t)row * D + lane * 4) = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Neighbour-line ("signature") multi-head attention, one image = one softmax domain
+// (models/line_transformer.py:132-154).  Flash-style, fp32 MFMA, no N x N matrix in memory.
+//
+// grid (image, head, q-tile of 128), block 256 = 4 wave64, wave w owns 32 query rows.
+// qkv [N,768] = [q | k | v], each head-major (c = h*64+d; the reference's interleaved c = d*4+h is
+// undone by permuting weight rows at load time) and q pre-scaled by 1/8 (exact, power of two).
+//
+// Per 32-row kv chunk and wave:
+//   S^T[kv][q] = K_h[kv,:] . Q_h[q,:]      (A = K tile from LDS, B = Q fragment held in VGPRs)
+//   in the 32x32 C/D layout a lane owns ONE query column (q = lane&31) and 16 kv rows, so the online
+//   softmax max/sum are in-lane + one exchange with lane^32;
+//   the exponentiated S^T registers ARE the B operand of  O^T[d][q] += V^T[d][kv] . P^T[kv][q]
+//   under the k-permutation k = 8kk + 4*(lane>>5) + s  <->  register 4kk+s, so P never leaves VGPRs.
+// ---------------------------------------------------------------------------------------------
+constexpr int ATT_QT = 128;   // query rows per block
+constexpr int ATT_KT = 64;    // kv rows staged per iteration
+constexpr int ATT_KS = DH + 4;
+
+__global__ __launch_bounds__(256) void sig_attn_kernel(const float* __restrict__ qkv, const int* __restrict__ cu_sub,
+                                                       float* __restrict__ out /*[N][256] head-major*/) {
+  __shared__ __attribute__((aligned(16))) float Ks[ATT_KT * ATT_KS];
+  __shared__ __attribute__((aligned(16))) float Vs[ATT_KT * DH];
+  const int img = blockIdx.x, head = blockIdx.y;
+  const int n0 = cu_sub[img], Ni = cu_sub[img + 1] - n0;
+  const int q0 = blockIdx.z * ATT_QT;
+  if (q0 >= Ni) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h2 = lane >> 5, lq = lane & 31;
+  const int q = q0 + wave * 32 + lq;
+  const bool wave_active = q0 + wave * 32 < Ni;  // wave-uniform
+  const float* base = qkv + (int64_t)n0 * 768;
+
+  f32x4 qf[8];
+  {
+    const int qr = q < Ni ? q : Ni - 1;
+    const float* qp = base + (int64_t)qr * 768 + head * DH + h2 * 4;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const f32x4*>(qp + kk * 8);
+  }
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+
+  const int srow = tid >> 4, sc4 = (tid & 15) * 4;  // staging: 16 rows x 16 float4 per pass
+  for (int t0 = 0; t0 < Ni; t0 += ATT_KT) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = srow + i * 16;
+      const int kv = t0 + r;
+      f32x4 kx = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+      if (kv < Ni) {
+        const float* p = base + (int64_t)kv * 768 + head * DH + sc4;
+        kx = *reinterpret_cast<const f32x4*>(p + 256);
+        vx = *reinterpret_cast<const f32x4*>(p + 512);
+      }
+      *reinterpret_cast<f32x4*>(&Ks[r * ATT_KS + sc4]) = kx;
+      *reinterpret_cast<f32x4*>(&Vs[r * DH + sc4]) = vx;
+    }
+    __syncthreads();
+    if (!wave_active) continue;
+#pragma unroll
+    for (int c = 0; c < ATT_KT / 32; ++c) {
+      const int kv0 = t0 + c * 32;
+      if (kv0 >= Ni) break;
+      f32x16 st;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+      const float* kp = &Ks[(c * 32 + lq) * ATT_KS + h2 * 4];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(kp + kk * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], qf[kk][s], st, 0, 0, 0);
+      }
+      // online softmax over this lane's 16 kv rows (+ the other half-wave's 16)
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+        if (kv >= Ni) st[r] = -INFINITY;
+        mx = fmaxf(mx, st[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m, mx);
+      const float alpha = expf(m - m_new);  // m = -inf on the first chunk -> 0
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = expf(st[r] - m_new); ps += st[r]; }
+      ps += __shfl_xor(ps, 32, 64);
+      l = l * alpha + ps;
+      m = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      // O^T += V^T . P^T
+      const float* vp = &Vs[(c * 32 + h2 * 4) * DH + lq];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float v0 = vp[(kk * 8 + s) * DH];
+          const float v1 = vp[(kk * 8 + s) * DH + 32];
+          o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, st[kk * 4 + s], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, st[kk * 4 + s], o1, 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (wave_active && q < Ni) {
+    const float inv = 1.f / l;
+    float* op = out + (int64_t)(n0 + q) * D + head * DH;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = (r & 3) + 8 * (r >> 2) + 4 * h2;
+      op[d] = o0[r] * inv;
+      op[d + 32] = o1[r] * inv;
+    }
+  }
+}
+
+}  // namespace lt

@@ -1,0 +1,191 @@
+// Key-line -> sub-line tokenisation, descriptor sampling and score gather on the device.
+// Replaces the Python double loop of models/line_process.py:100-196 (line_tokenizer),
+// :86-98 (sample_descriptors) and :174-179 (score gather).
+#pragma once
+#include "lt_common.h"
+
+namespace lt {
+
+// ---------------------------------------------------------------------------------------------
+// NCHW -> NHWC copy of the dense descriptor map so that each bilinear tap is one coalesced 1 KiB
+// row (SuperPoint emits [1,256,H/8,W/8], models/superpoint.py:193).  32x32 LDS-tiled transpose.
+// grid (P/32 ceil, C/32, B), block (32, 8)
+// ---------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int P) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const float* src = in + (int64_t)b * C * P;
+  float* dst = out + (int64_t)b * C * P;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    int p = p0 + threadIdx.x;
+    tile[i][threadIdx.x] = p < P ? src[(int64_t)(c0 + i) * P + p] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    int p = p0 + i;
+    if (p < P) dst[(int64_t)p * C + c0 + threadIdx.x] = tile[threadIdx.x][i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per key-line: float32 copies of klines/length/angles (models/line_process.py:182-184, with the
+// end-point clip of :114-116 already applied) and the sub-line -> key-line maps.
+// ---------------------------------------------------------------------------------------------
+__global__ void line_fill_kernel(const LinetrLineRec* __restrict__ recs, int K, double wclip, double hclip,
+                                 float* __restrict__ klines, float* __restrict__ length,
+                                 float* __restrict__ angles, int* __restrict__ sub2line_g,
+                                 int* __restrict__ sub2line_l) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const LinetrLineRec r = recs[k];
+  if (klines) {
+    klines[k * 4 + 0] = (float)r.sp[0];
+    klines[k * 4 + 1] = (float)r.sp[1];
+    klines[k * 4 + 2] = (float)fmin(r.ep[0], wclip);
+    klines[k * 4 + 3] = (float)fmin(r.ep[1], hclip);
+    length[k] = (float)r.length;
+    angles[k * 2 + 0] = (float)r.angle[0];
+    angles[k * 2 + 1] = (float)r.angle[1];
+  }
+  for (int s = 0; s < r.n_sub; ++s) {
+    sub2line_g[r.first_sub + s] = k;
+    if (sub2line_l) sub2line_l[r.first_sub + s] = r.line_local;
+  }
+}
+
+// point at arclength `d` from sp along sp->ep in the reference's slope form, float64, no FMA
+// contraction (models/line_process.py:43-57).
+__device__ __forceinline__ void walk_along(const double sp[2], const double ep[2], double d, double& x, double& y) {
+#pragma clang fp contract(off)
+  const double vx = ep[0] - sp[0], vy = ep[1] - sp[1];
+  double dx, dy;
+  if (vx != 0.0) {
+    const double m = vy / vx;
+    dx = sqrt(d * d / (1.0 + m * m));
+    dy = m * dx;
+  } else {
+    dx = 0.0;
+    dy = vy > 0.0 ? d : -d;
+  }
+  x = dx + sp[0];
+  y = dy + sp[1];
+}
+
+// ---------------------------------------------------------------------------------------------
+// One 64-thread block per sub-line; thread t < T produces token t.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void tokenize_kernel(
+    const LinetrLineRec* __restrict__ recs, const int* __restrict__ sub2line_g, int N, double td, int T,
+    int height, int width, const float* __restrict__ dense_score, float* __restrict__ sublines,
+    float* __restrict__ pnt, float* __restrict__ mask, float* __restrict__ resp,
+    float* __restrict__ angle_sub, float* __restrict__ score) {
+#pragma clang fp contract(off)
+  const int n = blockIdx.x;
+  if (n >= N) return;
+  const LinetrLineRec r = recs[sub2line_g[n]];
+  const int j = n - r.first_sub;  // sub-line index inside its key-line
+  const double epc[2] = {fmin(r.ep[0], (double)width - 0.6), fmin(r.ep[1], (double)height - 0.6)};
+  for (int t = threadIdx.x; t < T; t += 64) {
+    const int ti = j * T + t;
+    double x = 0.0, y = 0.0;
+    float mk = 0.f;
+    if (ti < r.n_tok - 1) {
+      walk_along(r.sp, r.ep, (double)ti * td, x, y);  // :110-113
+      mk = 1.f;
+    } else if (ti == r.n_tok - 1) {
+      x = epc[0];                                      // :114-117
+      y = epc[1];
+      mk = 1.f;
+    }
+    const float fx = (float)x, fy = (float)y;          // :157 .float()
+    const int64_t o = (int64_t)n * T + t;
+    pnt[o * 2 + 0] = fx;
+    pnt[o * 2 + 1] = fy;
+    mask[(int64_t)n * (T + 1) + 1 + t] = mk;
+    // score gather :174-179 -- torch.round (half to even), clip to the map, index [y][x]
+    int ix = (int)rintf(fx), iy = (int)rintf(fy);
+    ix = ix < width - 1 ? ix : width - 1;
+    iy = iy < height - 1 ? iy : height - 1;
+    ix = ix < 0 ? 0 : ix;   // negative coordinates cannot occur after remove_borders; guard the load anyway
+    iy = iy < 0 ? 0 : iy;
+    score[o] = dense_score[(int64_t)r.image * height * width + (int64_t)iy * width + ix];
+  }
+  if (threadIdx.x == 0) {
+    mask[(int64_t)n * (T + 1)] = 1.f;  // CLS slot :135
+    double s[2], e[2];
+    if (j == 0) { s[0] = r.sp[0]; s[1] = r.sp[1]; }
+    else walk_along(r.sp, r.ep, (double)(j * T - 1) * td, s[0], s[1]);        // :125-128
+    if (j == r.n_sub - 1) { e[0] = epc[0]; e[1] = epc[1]; }
+    else walk_along(r.sp, r.ep, (double)((j + 1) * T - 1) * td, e[0], e[1]);
+    sublines[(int64_t)n * 4 + 0] = (float)s[0];
+    sublines[(int64_t)n * 4 + 1] = (float)s[1];
+    sublines[(int64_t)n * 4 + 2] = (float)e[0];
+    sublines[(int64_t)n * 4 + 3] = (float)e[1];
+    const double dx = e[0] - s[0], dy = e[1] - s[1];
+    const double geo = sqrt(dx * dx + dy * dy);                               // :148-149
+    resp[n] = (float)(geo / (td * (double)T));
+    angle_sub[(int64_t)n * 2 + 0] = (float)r.angle[0];                        // :151
+    angle_sub[(int64_t)n * 2 + 1] = (float)r.angle[1];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sample_descriptors (models/line_process.py:86-98): bilinear grid_sample (zero padding) of the NHWC
+// descriptor map + L2 normalisation.  One wave64 per token, lane = 4 channels (dwordx4, coalesced
+// 1 KiB per tap).  fp32 arithmetic in the order PyTorch's CPU grid_sampler uses.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_desc_kernel(
+    const float* __restrict__ pnt, const int* __restrict__ sub2line_g, const LinetrLineRec* __restrict__ recs,
+    int64_t n_tokens, int T, const float* __restrict__ nhwc, int Hc, int Wc, int align_corners,
+    float* __restrict__ desc) {
+#pragma clang fp contract(off)
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= n_tokens) return;
+  const int lane = threadIdx.x & 63;
+  const int n = (int)(tok / T);
+  const int img = recs[sub2line_g[n]].image;
+  const float px = pnt[tok * 2 + 0], py = pnt[tok * 2 + 1];
+  const float s = 8.f;
+  // keypoints - s/2 + 0.5 ; /= (w*s - s/2 - 0.5) ; *2 - 1          (:88-92)
+  float gx = ((px - s / 2) + 0.5f) / ((float)Wc * s - s / 2 - 0.5f);
+  float gy = ((py - s / 2) + 0.5f) / ((float)Hc * s - s / 2 - 0.5f);
+  gx = gx * 2.f - 1.f;
+  gy = gy * 2.f - 1.f;
+  float ix, iy;  // grid_sampler_unnormalize
+  if (align_corners) {
+    ix = ((gx + 1.f) / 2.f) * (float)(Wc - 1);
+    iy = ((gy + 1.f) / 2.f) * (float)(Hc - 1);
+  } else {
+    ix = ((gx + 1.f) * (float)Wc - 1.f) / 2.f;
+    iy = ((gy + 1.f) * (float)Hc - 1.f) / 2.f;
+  }
+  const float x_w = floorf(ix), y_n = floorf(iy);
+  const float w = ix - x_w, e = 1.f - w, nn = iy - y_n, ss = 1.f - nn;
+  const float nw = ss * e, ne = ss * w, sw = nn * e, se = nn * w;
+  const int x0 = (int)x_w, y0 = (int)y_n, x1 = x0 + 1, y1 = y0 + 1;
+  const float* base = nhwc + (int64_t)img * Hc * Wc * D + lane * 4;
+  auto tap = [&](int yy, int xx) -> f32x4 {
+    if (xx < 0 || xx >= Wc || yy < 0 || yy >= Hc) return f32x4{0.f, 0.f, 0.f, 0.f};
+    return *reinterpret_cast<const f32x4*>(base + ((int64_t)yy * Wc + xx) * D);
+  };
+  const f32x4 v_nw = tap(y0, x0), v_ne = tap(y0, x1), v_sw = tap(y1, x0), v_se = tap(y1, x1);
+  f32x4 o;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float v = v_nw[c] * nw;
+    v = v + v_ne[c] * ne;
+    v = v + v_sw[c] * sw;
+    v = v + v_se[c] * se;
+    o[c] = v;
+    sq += v * v;
+  }
+  sq = wave_sum(sq);
+  const float nrm = fmaxf(sqrtf(sq), 1e-12f);  // F.normalize eps
+#pragma unroll
+  for (int c = 0; c < 4; ++c) o[c] = o[c] / nrm;
+  *reinterpret_cast<f32x4*>(desc + tok * D + lane * 4) = o;
+}
+
+}  // namespace lt

@@ -1,0 +1,278 @@
+"""Host-side driver of the native library: owns the handle, device workspaces and the var-len batch
+plumbing.  PyTorch is used for device memory, streams and H2D/D2H copies only; every arithmetic step
+of the hot path is a HIP kernel behind the C ABI (include/linetr_hip.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+D = 256
+
+DEFAULT_MODEL = dict(descriptor_dim=256, keyline_encoder=[32, 64, 128, 256], n_heads=4,
+                     n_line_descriptive_layers=1, d_inner=1024, n_sig_layers=7, image_shape=[480, 640])
+
+
+def _as_numpy_f32(v):
+    if torch.is_tensor(v):
+        v = v.detach().cpu().numpy()
+    return np.ascontiguousarray(v, dtype=np.float32)
+
+
+@dataclass
+class TokenBatch:
+    """Device tensors produced by the tokeniser for a batch of images (images concatenated)."""
+    n_images: int
+    max_tokens: int
+    cu_k: np.ndarray          # [B+1] host prefix sums of key-lines
+    cu_n: np.ndarray          # [B+1] host prefix sums of sub-lines
+    recs: np.ndarray          # host LineRec array [K]
+    klines: torch.Tensor      # [K,2,2]
+    length: torch.Tensor      # [K]
+    angles: torch.Tensor      # [K,2]
+    sublines: torch.Tensor    # [N,2,2]
+    pnt: torch.Tensor         # [N,T,2]
+    mask: torch.Tensor        # [N,T+1]
+    resp: torch.Tensor        # [N]
+    angle_sub: torch.Tensor   # [N,2]
+    desc: torch.Tensor        # [N,T,256]
+    score: torch.Tensor       # [N,T]
+    sub2line: torch.Tensor    # [N] int32, key-line index inside the image
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def K(self):
+        return int(self.cu_k[-1])
+
+    @property
+    def N(self):
+        return int(self.cu_n[-1])
+
+    def c_tokens(self) -> nat.Tokens:
+        t = nat.Tokens()
+        for k in ("klines", "length", "angles", "sublines", "pnt", "mask", "resp", "angle_sub", "desc", "score"):
+            setattr(t, k, getattr(self, k).data_ptr())
+        return t
+
+
+class Engine:
+    """One native model instance on one GPU."""
+
+    def __init__(self, state_dict, device="cuda:0", **model_cfg):
+        cfg = {**DEFAULT_MODEL, **model_cfg}
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("linetr_amd.Engine needs a HIP device (torch device 'cuda:N'); there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.cfg = cfg
+        L = nat.lib()
+        mc = nat.ModelConfig()
+        mc.d_model, mc.n_heads, mc.d_inner = cfg["descriptor_dim"], cfg["n_heads"], cfg["d_inner"]
+        mc.n_sig_layers, mc.n_desc_layers = cfg["n_sig_layers"], cfg["n_line_descriptive_layers"]
+        for i, c in enumerate(cfg["keyline_encoder"]):
+            mc.enc_channels[i] = c
+        shape = cfg["image_shape"]
+        mc.norm_height, mc.norm_width = int(shape[-2]), int(shape[-1])
+        names, arrs = [], []
+        for k, v in state_dict.items():
+            if k.endswith("num_batches_tracked"):
+                continue
+            names.append(k.encode())
+            arrs.append(_as_numpy_f32(v))
+        n = len(names)
+        c_names = (C.c_char_p * n)(*names)
+        c_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        c_numel = (C.c_int64 * n)(*[a.size for a in arrs])
+        h = C.c_void_p()
+        nat.check(L.linetr_create(C.byref(mc), n, c_names, c_ptrs, c_numel, self.device.index, C.byref(h)))
+        self._h = h
+        self._L = L
+        self._ws = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.linetr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, tag: str, nbytes: int) -> torch.Tensor:
+        ws = self._ws.get(tag)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=self.device)
+            self._ws[tag] = ws
+        return ws
+
+    def _f32(self, t: torch.Tensor) -> torch.Tensor:
+        if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        return t
+
+    # ------------------------------------------------------------------ host pre-filter
+    def prefilter(self, lines6_list, height, width, *, remove_borders, min_length, max_keylines, token_distance,
+                  max_tokens, valid_masks=None):
+        """a1-a3 for a list of images (each [K,6] float64).  Returns (recs, cu_k, cu_n)."""
+        L = self._L
+        B = len(lines6_list)
+        cap = sum(len(l) for l in lines6_list)
+        recs = np.zeros(max(cap, 1), dtype=nat.REC_DTYPE)
+        cu_k = np.zeros(B + 1, dtype=np.int32)
+        cu_n = np.zeros(B + 1, dtype=np.int32)
+        k_out, n_out = C.c_int32(), C.c_int32()
+        for i, l6 in enumerate(lines6_list):
+            l6 = np.ascontiguousarray(l6, dtype=np.float64).reshape(-1, 6)
+            vm = None
+            if valid_masks is not None and valid_masks[i] is not None:
+                vm = np.ascontiguousarray(valid_masks[i], dtype=np.float64)
+            base = int(cu_k[i])
+            nat.check(L.linetr_prefilter(nat.np_ptr(l6), len(l6), height, width, int(remove_borders), float(min_length),
+                                         int(max_keylines), nat.np_ptr(vm) if vm is not None else None,
+                                         float(token_distance), int(max_tokens), i, int(cu_n[i]),
+                                         C.c_void_p(recs.ctypes.data + base * nat.REC_DTYPE.itemsize), cap - base,
+                                         C.byref(k_out), C.byref(n_out)))
+            cu_k[i + 1] = base + k_out.value
+            cu_n[i + 1] = cu_n[i] + n_out.value
+        return recs[:cu_k[-1]], cu_k, cu_n
+
+    def pack(self, klines, length, angles, token_distance, max_tokens, image=0, sub_base=0):
+        """records for already-filtered lines (float64 arrays, reference layout)."""
+        K = len(klines)
+        recs = np.zeros(max(K, 1), dtype=nat.REC_DTYPE)
+        n_out = C.c_int32()
+        kl = np.ascontiguousarray(klines, dtype=np.float64)
+        ln = np.ascontiguousarray(length, dtype=np.float64)
+        an = np.ascontiguousarray(angles, dtype=np.float64)
+        nat.check(self._L.linetr_pack_lines(nat.np_ptr(kl), nat.np_ptr(ln), nat.np_ptr(an), K, float(token_distance),
+                                            int(max_tokens), int(image), int(sub_base), nat.np_ptr(recs), C.byref(n_out)))
+        return recs[:K], n_out.value
+
+    # ------------------------------------------------------------------ device stages
+    def tokenize(self, recs, cu_k, cu_n, dense_desc, dense_score, *, token_distance, max_tokens, align_corners=False,
+                 sample_desc=True) -> TokenBatch:
+        """line_tokenizer on the device.  dense_desc [B,256,H/8,W/8], dense_score [B,H,W]."""
+        B = len(cu_k) - 1
+        K, N, T = int(cu_k[-1]), int(cu_n[-1]), int(max_tokens)
+        dense_desc = self._f32(dense_desc)
+        dense_score = self._f32(dense_score)
+        if dense_score.dim() == 2:
+            dense_score = dense_score[None]
+        if dense_desc.dim() == 3:
+            dense_desc = dense_desc[None]
+        if dense_desc.shape[0] != B or dense_score.shape[0] != B:
+            raise ValueError("dense maps must have one entry per image")
+        H, W = int(dense_score.shape[-2]), int(dense_score.shape[-1])
+        if dense_desc.shape[1] != D or dense_desc.shape[2] * 8 != H or dense_desc.shape[3] * 8 != W:
+            raise ValueError(f"dense_descriptor shape {tuple(dense_desc.shape)} does not match dense_score {H}x{W}")
+        dev = self.device
+        f = dict(dtype=torch.float32, device=dev)
+        tb = TokenBatch(
+            n_images=B, max_tokens=T, cu_k=np.asarray(cu_k, np.int32), cu_n=np.asarray(cu_n, np.int32), recs=recs,
+            klines=torch.empty((K, 2, 2), **f), length=torch.empty((K,), **f), angles=torch.empty((K, 2), **f),
+            sublines=torch.empty((N, 2, 2), **f), pnt=torch.empty((N, T, 2), **f), mask=torch.empty((N, T + 1), **f),
+            resp=torch.empty((N,), **f), angle_sub=torch.empty((N, 2), **f),
+            desc=torch.empty((N, T, D), **f) if sample_desc else torch.empty((0,), **f),
+            score=torch.empty((N, T), **f), sub2line=torch.empty((N,), dtype=torch.int32, device=dev))
+        if K == 0 or N == 0:
+            return tb
+        d_recs = torch.from_numpy(recs.view(np.uint8).reshape(-1)).to(dev)
+        nbytes = self._L.linetr_tokenize_workspace_bytes(B, H, W, N)
+        ws = self._workspace("tok", nbytes)
+        ct = tb.c_tokens()
+        if not sample_desc:
+            ct.desc = None
+        nat.check(self._L.linetr_tokenize(self._h, d_recs.data_ptr(), K, N, float(token_distance), T,
+                                          dense_desc.data_ptr(), dense_score.data_ptr(), B, H, W, int(bool(align_corners)),
+                                          ct, tb.sub2line.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+        tb.extra["d_recs"] = d_recs  # keep alive until the stream has consumed it
+        return tb
+
+    def forward_tensors(self, sublines, pnt, resp, angle_sub, desc, score, cu_n, out=None) -> torch.Tensor:
+        """LineTransformer.forward on flat tensors; returns line_desc [N,256] (row-major)."""
+        N, T = int(pnt.shape[0]), int(pnt.shape[1])
+        t = nat.Tokens()
+        keep = [self._f32(x) for x in (sublines, pnt, resp, angle_sub, desc, score)]
+        t.sublines, t.pnt, t.resp, t.angle_sub, t.desc, t.score = [x.data_ptr() for x in keep]
+        cu = np.ascontiguousarray(cu_n, dtype=np.int32)
+        if int(cu[-1]) != N:
+            raise ValueError("cu_n does not match the number of sub-lines")
+        if out is None:
+            out = torch.empty((N, D), dtype=torch.float32, device=self.device)
+        if N == 0:
+            return out
+        nbytes = self._L.linetr_forward_workspace_bytes(self._h, N, T)
+        ws = self._workspace("fwd", nbytes)
+        nat.check(self._L.linetr_forward(self._h, C.byref(t), nat.np_ptr(cu), len(cu) - 1, T, out.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), self._stream()))
+        return out
+
+    def forward(self, tb: TokenBatch, out=None) -> torch.Tensor:
+        return self.forward_tensors(tb.sublines, tb.pnt, tb.resp, tb.angle_sub, tb.desc, tb.score, tb.cu_n, out)
+
+    def match(self, desc0, cu_n0, sub2line0, cu_k0, desc1, cu_n1, sub2line1, cu_k1, thr, mutual=True):
+        """Match image i of side 0 with image i of side 1 for all i.  desc* are [N,256] row-major.
+        Returns (Dk_flat float32 device, off_dk host int64 [P+1], match01 int32 device [K0_total])."""
+        P = len(cu_n0) - 1
+        assert len(cu_n1) - 1 == P
+        dims = np.zeros((P, 4), dtype=np.int32)
+        dims[:, 0] = np.diff(cu_n0); dims[:, 1] = np.diff(cu_k0)
+        dims[:, 2] = np.diff(cu_n1); dims[:, 3] = np.diff(cu_k1)
+        off_n0 = np.ascontiguousarray(cu_n0[:-1], dtype=np.int64)
+        off_n1 = np.ascontiguousarray(cu_n1[:-1], dtype=np.int64)
+        off_k0 = np.ascontiguousarray(cu_k0[:-1], dtype=np.int64)
+        kk = dims[:, 1].astype(np.int64) * dims[:, 3].astype(np.int64)
+        off_dk = np.zeros(P + 1, dtype=np.int64)
+        np.cumsum(kk, out=off_dk[1:])
+        sum_nn = int((dims[:, 0].astype(np.int64) * dims[:, 2].astype(np.int64)).sum())
+        sum_k = int(dims[:, 1].sum() + dims[:, 3].sum())
+        dk = torch.empty((max(int(off_dk[-1]), 1),), dtype=torch.float32, device=self.device)
+        m01 = torch.empty((max(int(cu_k0[-1]), 1),), dtype=torch.int32, device=self.device)
+        if P == 0:
+            return dk[:0], off_dk, m01[:0]
+        nbytes = self._L.linetr_match_workspace_bytes(P, sum_nn, 0, sum_k)
+        ws = self._workspace("match", nbytes)
+        d0, d1 = self._f32(desc0), self._f32(desc1)
+        nat.check(self._L.linetr_match(self._h, P, nat.np_ptr(dims), d0.data_ptr(), nat.np_ptr(off_n0),
+                                       sub2line0.data_ptr(), d1.data_ptr(), nat.np_ptr(off_n1), sub2line1.data_ptr(),
+                                       float(thr), int(bool(mutual)), dk.data_ptr(), nat.np_ptr(off_dk[:-1].copy()),
+                                       m01.data_ptr(), nat.np_ptr(off_k0), ws.data_ptr(), ws.numel(), self._stream()))
+        return dk[:int(off_dk[-1])], off_dk, m01[:int(cu_k0[-1])]
+
+    def match_points(self, desc0_cn: torch.Tensor, desc1_cn: torch.Tensor, thr, mutual=True):
+        """nn_matcher on [256,n] descriptors; returns (dist [n0,n1] device, match01 [n0] device)."""
+        d0, d1 = self._f32(desc0_cn), self._f32(desc1_cn)
+        n0, n1 = int(d0.shape[1]), int(d1.shape[1])
+        dist = torch.empty((n0, n1), dtype=torch.float32, device=self.device)
+        m01 = torch.full((n0,), -1, dtype=torch.int32, device=self.device)
+        if n0 == 0 or n1 == 0:
+            return dist, m01
+        need = 4 * (n0 + n1) * (D + 1) + 2048 + self._L.linetr_match_workspace_bytes(1, n0 * n1, 0, n0 + n1)
+        ws = self._workspace("match", need)
+        nat.check(self._L.linetr_match_points(self._h, d0.data_ptr(), n0, d1.data_ptr(), n1, float(thr),
+                                              int(bool(mutual)), dist.data_ptr(), m01.data_ptr(), ws.data_ptr(),
+                                              ws.numel(), self._stream()))
+        return dist, m01
+
+    # ------------------------------------------------------------------ profiling
+    def set_profiling(self, on: bool):
+        nat.check(self._L.linetr_set_profiling(self._h, int(on)))
+
+    def get_profile(self):
+        arr = (nat.ProfileEntry * 64)()
+        n = C.c_int32()
+        nat.check(self._L.linetr_get_profile(self._h, arr, 64, C.byref(n)))
+        return [dict(name=arr[i].name.decode(), calls=arr[i].calls, ms=arr[i].ms, flops=arr[i].flops,
+                     bytes=arr[i].bytes) for i in range(min(n.value, 64))]
