@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native LineTR hot path.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json / SURVEY.md section 8d): line-descriptors/sec = sub-line descriptors written to
+`line_desc` / wall time of tokenise + forward (host pre-filter, H2D of the line records, tokeniser,
+descriptor network; for N>1 also the single RCCL all-gather of the descriptors).  SuperPoint dense
+maps are already resident in HBM, detected lines are resident on the host.  A "step" is one pass of
+that path over one batch of P synthetic image pairs per GPU (weak scaling: every rank gets its own P
+pairs).  Default workload = cfg3 of BASELINE.json (64 pairs of 640x480, 200 lines -> 199 sub-lines x
+21 tokens per image), the configuration the roofline is defined on; --workload cfg2 / cfg5 select the
+single-pair and the long-line configurations.  pair-match ms and the single-pair latency are reported
+in the same JSON line.  One JSON line is printed by rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from linetr_amd import parallel, synth  # noqa: E402
+from linetr_amd.engine import Engine  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (H, W, lines/image, len_lo, len_hi, max_tokens, default pairs per GPU)
+    "cfg2": (480, 640, 200, 17.0, 167.0, 21, 1),
+    "cfg3": (480, 640, 200, 17.0, 167.0, 21, 64),
+    "cfg5": (960, 1280, 600, 40.0, 327.0, 41, 8),
+}
+LINE_CFG = dict(min_length=16, token_distance=8, remove_borders=8, max_keylines=-1, nn_threshold=0.8)
+
+
+def algorithmic_flops_per_image(N, T, K=None):
+    """F_img = 2*[N*T*108640 + N*108704 + N*(2*S*65536 + 2*65536 + 2*S*256 + 524288)
+    + 7*(N*655360 + 512*N^2) + N*65536]."""
+    S = T + 1
+    return 2.0 * (N * T * 108640 + N * 108704 + N * (2 * S * 65536 + 2 * 65536 + 2 * S * 256 + 524288)
+                  + 7 * (N * 655360 + 512 * N * N) + N * 65536)
+
+
+def make_inputs(workload, pairs, rank, device):
+    H, W, n_lines, lo, hi, T, _ = WORKLOADS[workload]
+    lines, dds, dss = [], [], []
+    for p in range(pairs):
+        gp = rank * pairs + p
+        for side in (0, 1):
+            seed = 1000 + 2 * gp + side if workload != "cfg2" else 11 + side + 2 * gp
+            lines.append(synth.synth_lines(seed, n_lines, H, W, lo, hi))
+            dd, ds = synth.synth_dense_maps(seed, H, W)
+            dds.append(dd)
+            dss.append(ds)
+    dd = torch.cat(dds).to(device)
+    ds = torch.cat(dss).to(device)
+    return lines, dd, ds, (H, W), T
+
+
+class Pipeline:
+    def __init__(self, eng, lines, dd, ds, hw, T, world, pairs):
+        self.eng, self.lines, self.dd, self.ds, self.hw, self.T = eng, lines, dd, ds, hw, T
+        self.world, self.pairs = world, pairs
+        self.n_img_cap = 2 * pairs
+        self.rows_cap = sum(len(l) for l in lines)
+        self.packed = None
+
+    def describe(self):
+        e, c = self.eng, LINE_CFG
+        recs, cu_k, cu_n = e.prefilter(self.lines, self.hw[0], self.hw[1], remove_borders=c["remove_borders"],
+                                       min_length=c["min_length"], max_keylines=c["max_keylines"],
+                                       token_distance=c["token_distance"], max_tokens=self.T)
+        tb = e.tokenize(recs, cu_k, cu_n, self.dd, self.ds, token_distance=c["token_distance"], max_tokens=self.T)
+        ld = e.forward(tb)
+        return tb, ld
+
+    def step(self):
+        tb, ld = self.describe()
+        gathered = None
+        if self.world > 1:
+            self.packed = parallel.pack_descriptors(ld, tb.cu_n, self.n_img_cap, self.rows_cap, self.packed)
+            gathered = parallel.allgather_descriptors(self.packed)
+        return tb, ld, gathered
+
+    def match(self, tb, ld):
+        """image 2p vs image 2p+1 for every local pair."""
+        cu_n, cu_k = tb.cu_n, tb.cu_k
+        # de-interleave the two sides: side 0 = even images, side 1 = odd images (row ranges are contiguous per image)
+        ev, od = slice(0, None, 2), slice(1, None, 2)
+        n = np.diff(cu_n); k = np.diff(cu_k)
+        idx0 = torch.cat([torch.arange(cu_n[i], cu_n[i + 1]) for i in range(0, len(n), 2)]).to(ld.device)
+        idx1 = torch.cat([torch.arange(cu_n[i], cu_n[i + 1]) for i in range(1, len(n), 2)]).to(ld.device)
+        d0, d1 = ld[idx0], ld[idx1]
+        s0, s1 = tb.sub2line[idx0], tb.sub2line[idx1]
+        c = lambda v: np.concatenate([[0], np.cumsum(v)]).astype(np.int32)
+        args = (d0, c(n[ev]), s0, c(k[ev]), d1, c(n[od]), s1, c(k[od]))
+        return args
+
+
+def cpu_baseline(workload, budget_s=12.0, max_pairs=16):
+    """The CPU oracle (a faithful port of the reference's as-executed PyTorch-CPU/NumPy path, incl. the
+    per-line Python tokeniser loop and the full 22-token descriptive layer) timed on this box."""
+    from oracle import linetr_oracle as O
+    H, W, n_lines, lo, hi, T, _ = WORKLOADS[workload]
+    sd = synth.to_torch_state_dict(synth.calibrated_state_dict())
+    cfg = dict(LINE_CFG, max_tokens=T)
+    n_desc, t_tok, t_fwd, t_match, pairs = 0, 0.0, 0.0, 0.0, 0
+    t_start = time.perf_counter()
+    with torch.no_grad():
+        while pairs < max_pairs and (pairs < 2 or time.perf_counter() - t_start < budget_s):
+            outs = []
+            for side in (0, 1):
+                seed = 5000 + 2 * pairs + side
+                rows = synth.synth_lines(seed, n_lines, H, W, lo, hi)
+                dd, ds = synth.synth_dense_maps(seed, H, W)
+                kl = synth.array_to_keylines(rows)
+                t0 = time.perf_counter()
+                out = O.preprocess(kl, (1, 1, H, W), dd, ds, cfg)
+                t1 = time.perf_counter()
+                out = O.forward(sd, out, (H, W))
+                t2 = time.perf_counter()
+                t_tok += t1 - t0
+                t_fwd += t2 - t1
+                n_desc += out["line_desc"].shape[2]
+                outs.append(out)
+            t0 = time.perf_counter()
+            O.match_lines(outs[0]["line_desc"], outs[1]["line_desc"], outs[0]["mat_klines2sublines"][0],
+                          outs[1]["mat_klines2sublines"][0], 0.8)
+            t_match += time.perf_counter() - t0
+            pairs += 1
+    return {
+        "value": n_desc / (t_tok + t_fwd), "unit": "line-descriptors/s", "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{pairs} {workload}-shaped pairs ({n_desc} descriptors), oracle tokenise {t_tok / pairs * 1e3:.1f} ms + "
+                  f"forward {t_fwd / pairs * 1e3:.1f} ms + match {t_match / pairs * 1e3:.2f} ms per pair, "
+                  f"torch {torch.__version__} CPU, {os.cpu_count()} logical cpus",
+        "pair_match_ms": t_match / pairs * 1e3,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--pairs", type=int, default=0, help="image pairs per GPU per step (default: workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the LineTR hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if args.gpus != world and rank == 0:
+        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    H, W, n_lines, lo, hi, T, def_pairs = WORKLOADS[args.workload]
+    pairs = args.pairs or def_pairs
+    eng = Engine(synth.calibrated_state_dict(), device, image_shape=[H, W])
+    lines, dd, ds, hw, T = make_inputs(args.workload, pairs, rank, device)
+    pipe = Pipeline(eng, lines, dd, ds, hw, T, world, pairs)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tb, ld, _g = pipe.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tb, ld, _g = pipe.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([float(tb.N)], dtype=torch.float64, device=device)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        n_desc_step = float(cnt.item())
+    else:
+        n_desc_step = float(tb.N)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_desc_step * args.steps / elapsed
+
+    # ---- pair-match ms (a19-a21) on the descriptors just produced --------------------------------------------
+    margs = pipe.match(tb, ld)
+    for _ in range(2):
+        eng.match(*margs, LINE_CFG["nn_threshold"], True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        dk, off_dk, m01 = eng.match(*margs, LINE_CFG["nn_threshold"], True)
+    torch.cuda.synchronize()
+    pair_match_ms = (time.perf_counter() - t0) / reps / pairs * 1e3
+    n_matches = int((m01 >= 0).sum().item())
+
+    # ---- single-pair latency (cfg2 shape, tokenise + forward + match) -----------------------------------------
+    one = Pipeline(eng, lines[:2], dd[:2], ds[:2], hw, T, 1, 1)
+    for _ in range(3):
+        tb1, ld1 = one.describe()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        tb1, ld1 = one.describe()
+    torch.cuda.synchronize()
+    pair_latency_ms = (time.perf_counter() - t0) / 10 * 1e3
+
+    # ---- per-kernel HIP-event profile of the same step (roofline of the dominant kernel) ----------------------
+    prof_steps = 3
+    eng.set_profiling(True)
+    for _ in range(prof_steps):
+        pipe.describe()
+    torch.cuda.synchronize()
+    prof = eng.get_profile()
+    eng.set_profiling(False)
+    prof.sort(key=lambda e: -e["ms"])
+    dom = prof[0]
+    tot_ms = sum(e["ms"] for e in prof)
+    if dom["flops"] > 0:
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(dom["ms"] / dom["calls"] * 1e3, 2), "launches_per_step": dom["calls"] // prof_steps,
+                    "share_of_gpu_time": round(dom["ms"] / tot_ms, 3)}
+    else:
+        ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        roofline = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_us": round(dom["ms"] / dom["calls"] * 1e3, 2), "launches_per_step": dom["calls"] // prof_steps,
+                    "share_of_gpu_time": round(dom["ms"] / tot_ms, 3)}
+    n_img = 2 * pairs
+    alg_flops_step = sum(algorithmic_flops_per_image(int(n), T) for n in np.diff(tb.cu_n))
+    breakdown = {e["name"]: {"calls": e["calls"] // prof_steps, "ms": round(e["ms"] / prof_steps, 4),
+                             "tflops": round(e["flops"] / max(e["ms"], 1e-9) / 1e9, 1) if e["flops"] else None}
+                 for e in prof}
+
+    out = {
+        "metric": "line_descriptors_per_sec", "value": round(value, 1), "unit": "line-descriptors/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {pairs} pairs/GPU of {W}x{H}, {n_lines} lines/image -> "
+                               f"{int(tb.N / n_img)} sub-lines x {T} tokens, d_model=256, seeded weights",
+                   "pairs_per_gpu": pairs, "descriptors_per_step": int(n_desc_step),
+                   "collective": "all_gather(line_desc)" if world > 1 else "none"},
+        "pair_match_ms": round(pair_match_ms, 4), "pair_latency_ms": round(pair_latency_ms, 3),
+        "matches_per_step": n_matches,
+        "whole_step_algorithmic_tflops": round(alg_flops_step / (ms_per_step * 1e-3) / 1e12 * (world if world > 1 else 1) / max(world, 1), 2),
+        "gpu_ms_per_step_profiled": round(tot_ms / prof_steps, 3),
+        "roofline": roofline, "kernels": breakdown,
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        cb = cpu_baseline(args.workload, args.cpu_budget)
+        out["cpu_baseline"] = {k: (round(v, 1) if isinstance(v, float) else v) for k, v in cb.items()}
+        out["speedup_vs_cpu"] = round(value / cb["value"], 1)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
