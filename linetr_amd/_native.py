@@ -51,6 +51,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; importing it first makes liblinetr_hip.so bind to the SAME HIP runtime
+    # (one context, shared streams and device pointers) instead of a second copy from /opt/rocm.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension has not been built (run `python -m linetr_amd.build`). "
