@@ -168,6 +168,13 @@ int linetr_match(LinetrHandle* h, int32_t n_pairs, const int32_t* h_dims, const 
                  float* d_dk, const int64_t* h_off_dk, int32_t* d_match01, const int64_t* h_off_k0,
                  void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* nn_matcher_distmat (models/nn_matcher.py:3-31) on a distance matrix that already lives on the device:
+ * d_dist [n0,n1] float32 -> d_match01 [n0] (index into side 1 or -1).  `h` may be NULL for the three
+ * matcher entry points (they need no weights); the current HIP device is used then. */
+int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_t n0, int32_t n1, float nn_thresh,
+                         int32_t mutual, int32_t* d_match01, void* d_workspace, int64_t workspace_bytes,
+                         void* stream);
+
 /* nn_matcher (models/nn_matcher.py:33-42): point-descriptor variant, desc given [256,n] column-major
  * like SuperPoint's `descriptors` -- section 8(f) "next" row, same kernels. */
 int linetr_match_points(LinetrHandle* h, const float* d_desc0_cn, int32_t n0, const float* d_desc1_cn,

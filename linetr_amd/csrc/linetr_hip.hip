@@ -77,7 +77,7 @@ struct ProfScope {
   int cls = -1;
   hipEvent_t a{}, b{};
   ProfScope(LinetrHandle* h_, hipStream_t st_, const char* name, double flops, double bytes) : h(h_), st(st_) {
-    if (!h->profiling) return;
+    if (!h || !h->profiling) return;
     cls = prof_class(h, name);
     h->classes[cls].calls++;
     h->classes[cls].flops += flops;
@@ -676,11 +676,11 @@ extern "C" int linetr_match(LinetrHandle* h, int32_t P, const int32_t* dims, con
                             const int32_t* d_s2l0, const float* d_desc1, const int64_t* off_n1, const int32_t* d_s2l1,
                             float thr, int32_t mutual, float* d_dk, const int64_t* off_dk, int32_t* d_match01,
                             const int64_t* off_k0, void* d_ws, int64_t ws_bytes, void* stream) {
-  if (!h || P < 0) return fail(LINETR_E_ARG, "match: bad argument");
+  if (P < 0) return fail(LINETR_E_ARG, "match: bad argument");
   if (P == 0) return LINETR_OK;
   if (!dims || !off_n0 || !off_n1 || !off_dk || !off_k0 || !d_ws) return fail(LINETR_E_ARG, "match: null argument");
   hipStream_t st = (hipStream_t)stream;
-  LT_HIP(hipSetDevice(h->device));
+  if (h) LT_HIP(hipSetDevice(h->device));
   std::vector<PairDesc> pd(P);
   int64_t od = 0, os = 0, sum_k = 0;
   int max_n0 = 0, max_n1 = 0;
@@ -724,10 +724,10 @@ extern "C" int linetr_match(LinetrHandle* h, int32_t P, const int32_t* dims, con
 extern "C" int linetr_match_points(LinetrHandle* h, const float* d0_cn, int32_t n0, const float* d1_cn, int32_t n1,
                                    float thr, int32_t mutual, float* d_dist, int32_t* d_match01, void* d_ws,
                                    int64_t ws_bytes, void* stream) {
-  if (!h || n0 < 0 || n1 < 0) return fail(LINETR_E_ARG, "match_points: bad argument");
+  if (n0 < 0 || n1 < 0) return fail(LINETR_E_ARG, "match_points: bad argument");
   if (n0 == 0) return LINETR_OK;
   hipStream_t st = (hipStream_t)stream;
-  LT_HIP(hipSetDevice(h->device));
+  if (h) LT_HIP(hipSetDevice(h->device));
   // scratch: row-major copies + identity sub2line maps + the generic matcher's workspace
   const int64_t need_t = align_up((int64_t)n0 * D * 4, 256) + align_up((int64_t)std::max(n1, 1) * D * 4, 256) +
                          align_up((int64_t)n0 * 4, 256) + align_up((int64_t)std::max(n1, 1) * 4, 256);
@@ -749,6 +749,33 @@ extern "C" int linetr_match_points(LinetrHandle* h, const float* d0_cn, int32_t 
   const int64_t zero = 0;
   return linetr_match(h, 1, dims, r0, &zero, id0, r1, &zero, id1, thr, mutual, d_dist, &zero, d_match01, &zero, base,
                       ws_bytes - need_t, stream);
+}
+
+extern "C" int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_t n0, int32_t n1, float thr,
+                                    int32_t mutual, int32_t* d_match01, void* d_ws, int64_t ws_bytes, void* stream) {
+  if (n0 < 0 || n1 < 0) return fail(LINETR_E_ARG, "match_distmat: bad argument");
+  if (n0 == 0) return LINETR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (h) LT_HIP(hipSetDevice(h->device));
+  // scratch: PairDesc | identity maps | Dk copy | segment/argmin ints
+  const int64_t o_id0 = 256, o_id1 = o_id0 + align_up((int64_t)n0 * 4, 256);
+  const int64_t o_dk = o_id1 + align_up((int64_t)std::max(n1, 1) * 4, 256);
+  const int64_t o_scr = o_dk + align_up((int64_t)n0 * std::max(n1, 1) * 4, 256);
+  const int64_t need = o_scr + align_up((3 * (int64_t)(n0 + n1) + 4) * 4, 256);
+  if (!d_ws || ws_bytes < need) return fail(LINETR_E_WORKSPACE, "match_distmat: workspace too small (need %lld)", (long long)need);
+  char* base = (char*)d_ws;
+  PairDesc pd{};
+  pd.n0 = pd.k0 = n0; pd.n1 = pd.k1 = n1;
+  std::vector<int> iota(std::max(n0, n1));
+  std::iota(iota.begin(), iota.end(), 0);
+  LT_HIP(hipMemcpyAsync(base, &pd, sizeof pd, hipMemcpyHostToDevice, st));
+  LT_HIP(hipMemcpyAsync(base + o_id0, iota.data(), n0 * 4, hipMemcpyHostToDevice, st));
+  if (n1 > 0) LT_HIP(hipMemcpyAsync(base + o_id1, iota.data(), n1 * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(pair_match_kernel, dim3(1), dim3(256), 0, st, (const PairDesc*)base, (const int*)(base + o_id0),
+                     (const int*)(base + o_id1), d_dist, thr, mutual, (float*)(base + o_dk), d_match01, (int*)(base + o_scr));
+  LT_LAUNCH_CHECK();
+  LT_HIP(hipStreamSynchronize(st));
+  return LINETR_OK;
 }
 
 // =============================================================================================

@@ -1,0 +1,254 @@
+"""Drop-in for the reference's ``models.line_transformer`` module.
+
+``LineTransformer`` keeps the reference's constructor/config/``preprocess``/``forward``/
+``subline2keyline``/``default_ret`` surface and its ``state_dict`` key layout (so the authors'
+``LineTR_weight.pth`` loads strictly), but owns no arithmetic: its nn.Module tree only HOLDS the
+parameters; tokenisation, the descriptor network and the matcher run in liblinetr_hip.so through
+``linetr_amd.engine.Engine``.  There is no CPU execution path -- calling it without a HIP device raises.
+
+Reference behaviour mirrored here (file:line in the reference checkout):
+  * config dict merged over default_config and mutated by callers (models/line_transformer.py:187-206)
+  * mode == 'test' loads <pkg>/weights/LineTR_weight.pth strictly and prints a message (:220-223)
+  * preprocess(): cv2 KeyLines -> arrays -> remove_borders -> filter_by_length -> tokeniser (:251-275);
+    writes config['image_shape'] = image_shape (:258); ndarray valid masks honoured, tensors ignored
+  * forward(): same dict object returned with 'line_desc' [1,256,N] added (:225-249)
+"""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+import torch
+from torch import nn
+
+from .engine import Engine
+
+__all__ = ["LineTransformer", "get_dist_matrix", "change_cv2_T_np", "remove_borders", "filter_by_length",
+           "get_angles"]
+
+
+# ------------------------------------------------------------------------------------------------
+# O(K) host glue that must reproduce NumPy's own ordering (np.argsort tie order) -- kept in NumPy on
+# purpose; the per-token work happens on the device.
+# ------------------------------------------------------------------------------------------------
+
+def get_angles(lines):
+    """(cos 2theta, sin 2theta) with theta = arctan2(dx, dy) folded into [0, pi)."""
+    if len(lines) == 0:
+        return []
+    theta = np.arctan2(lines[:, 1, 0] - lines[:, 0, 0], lines[:, 1, 1] - lines[:, 0, 1])
+    theta = np.where(theta < 0, theta + np.pi, theta)
+    return np.stack([np.cos(2 * theta), np.sin(2 * theta)], axis=1)
+
+
+def change_cv2_T_np(klines_cv):
+    """KeyLine objects -> {'klines' [K,2,2], 'length_klines' [K], 'angles' [K,2]} (float64)."""
+    if len(klines_cv) == 0:
+        return {"klines": np.zeros((0, 2, 2)), "length_klines": np.zeros((0,)), "angles": []}
+    raw = np.array([(l.startPointX, l.startPointY, l.endPointX, l.endPointY, l.lineLength, l.octave)
+                    for l in klines_cv], dtype=np.float64)
+    keep_order = raw[:, 0] < raw[:, 2]
+    sp = np.where(keep_order[:, None], raw[:, 0:2], raw[:, 2:4])
+    ep = np.where(keep_order[:, None], raw[:, 2:4], raw[:, 0:2])
+    klines = np.stack([sp, ep], axis=1)
+    return {"klines": klines, "length_klines": raw[:, 4] * np.exp2(raw[:, 5]), "angles": get_angles(klines)}
+
+
+def remove_borders(lines, border, height, width, valid_mask_given=None):
+    kl = lines["klines"]
+    if len(kl) == 0:
+        return lines
+    xs, ys = kl[:, :, 0], kl[:, :, 1]
+    ok = ((xs >= border) & (xs < width - border) & (ys >= border) & (ys < height - border)).all(axis=1)
+    np.minimum(xs, width - 0.001 - border, out=xs)     # in place, like the reference
+    np.minimum(ys, height - 0.001 - border, out=ys)
+    if isinstance(valid_mask_given, np.ndarray):
+        idx = np.floor(kl).astype(int)
+        either = valid_mask_given[idx[:, 0, 1], idx[:, 0, 0]] + valid_mask_given[idx[:, 1, 1], idx[:, 1, 0]]
+        ok &= either.astype(bool)
+    return {k: v[ok] for k, v in lines.items()}
+
+
+def filter_by_length(lines, min_length, max_sublines):
+    sel = lines["length_klines"] > min_length
+    kl, ln = lines["klines"][sel], lines["length_klines"][sel]
+    order = np.argsort(ln)[::-1][:max_sublines]
+    kl = kl[order]
+    return {"klines": kl, "length_klines": ln[order], "angles": get_angles(kl)}
+
+
+def get_dist_matrix(desc0, desc1):
+    """[b,256,N0],[b,256,N1] NumPy -> clip(2 - 2 d0^T d1, 0) [b,N0,N1] float32, on the HIP matcher kernel."""
+    from .nn_matcher import nn_matcher
+    desc0, desc1 = np.asarray(desc0), np.asarray(desc1)
+    return np.concatenate([nn_matcher(desc0[b], desc1[b], np.inf, False)[1] for b in range(desc0.shape[0])], 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers with the reference's state_dict keys
+# ------------------------------------------------------------------------------------------------
+
+def _pointwise_stack(widths):
+    mods = []
+    for i, (a, b) in enumerate(zip(widths[:-1], widths[1:])):
+        mods.append(nn.Conv1d(a, b, kernel_size=1))
+        if i < len(widths) - 2:
+            mods += [nn.BatchNorm1d(b), nn.ReLU()]
+    nn.init.zeros_(mods[-1].bias)
+    return nn.Sequential(*mods)
+
+
+class _Holder(nn.Module):
+    """A module that only groups parameters (no forward of its own)."""
+
+    def __init__(self, **children):
+        super().__init__()
+        for k, v in children.items():
+            setattr(self, k, v)
+
+
+def _param_tree(d, enc, heads, n_desc, d_inner, n_sig):
+    def desc_layer():
+        att = _Holder(w_qs=nn.Linear(d, d), w_ks=nn.Linear(d, d), w_vs=nn.Linear(d, d), fc=nn.Linear(d, d),
+                      layer_norm=nn.LayerNorm(d, eps=1e-6))
+        ffn = _Holder(w_1=nn.Linear(d, d_inner), w_2=nn.Linear(d_inner, d), layer_norm=nn.LayerNorm(d, eps=1e-6))
+        return _Holder(slf_attn=att, pos_ffn=ffn)
+
+    def sig_layer():
+        merge = nn.Conv1d(d, d, kernel_size=1)
+        proj = nn.ModuleList([nn.Conv1d(d, d, kernel_size=1) for _ in range(3)])
+        for p in proj:
+            p.load_state_dict(merge.state_dict())
+        return _Holder(attn=_Holder(merge=merge, proj=proj), mlp=_pointwise_stack([2 * d, 2 * d, d]))
+
+    klenc = _Holder(line_position_enc=_Holder(encoder=_pointwise_stack([5, *enc, d])),
+                    word_position_enc=_Holder(encoder=_pointwise_stack([3, *enc, d])),
+                    desc_layers=nn.ModuleList([desc_layer() for _ in range(n_desc)]))
+    klenc.cls_token = nn.Parameter(torch.randn(1, 1, 1, d))
+    selfattn = _Holder(layers=nn.ModuleList([sig_layer() for _ in range(n_sig)]))
+    return klenc, selfattn, nn.Conv1d(d, d, kernel_size=1)
+
+
+class LineTransformer(nn.Module):
+    """Line-Transformer descriptor network behind the reference's call surface."""
+
+    default_config = {
+        "mode": "test",
+        "image_shape": [480, 640],
+        "min_length": 16,
+        "token_distance": 8,
+        "max_tokens": 21,
+        "remove_borders": 8,
+        "max_keylines": -1,
+        "descriptor_dim": 256,
+        "keyline_encoder": [32, 64, 128, 256],
+        "n_heads": 4,
+        "n_line_descriptive_layers": 1,
+        "d_inner": 1024,
+    }
+    N_SIGNATURE_LAYERS = 7
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = {**self.default_config, **config}
+        self.image_shape = self.config["image_shape"]
+        c = self.config
+        self.klenc, self.selfattn, self.final_proj = _param_tree(
+            c["descriptor_dim"], c["keyline_encoder"], c["n_heads"], c["n_line_descriptive_layers"], c["d_inner"],
+            self.N_SIGNATURE_LAYERS)
+        self._engine = None
+        self._engine_key = None
+        if c["mode"] == "test":
+            path = Path(__file__).parent / "weights/LineTR_weight.pth"
+            self.load_state_dict(torch.load(path))
+            print("Loaded Line-Transformer model")
+
+    # -- native engine management ---------------------------------------------------------------
+    def _device(self):
+        return self.final_proj.weight.device
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def engine(self, device=None) -> Engine:
+        dev = torch.device(device) if device is not None else self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("LineTransformer (linetr_amd) runs on a HIP device only: move the module with "
+                               ".to('cuda'); there is no CPU fallback")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        key = (dev, tuple(self.image_shape[-2:]))
+        if self._engine is None or self._engine_key != key:
+            c = self.config
+            self._engine = Engine(self.state_dict(), dev, descriptor_dim=c["descriptor_dim"],
+                                  keyline_encoder=list(c["keyline_encoder"]), n_heads=c["n_heads"],
+                                  n_line_descriptive_layers=c["n_line_descriptive_layers"], d_inner=c["d_inner"],
+                                  n_sig_layers=self.N_SIGNATURE_LAYERS, image_shape=list(self.image_shape[-2:]))
+            self._engine_key = key
+        return self._engine
+
+    # -- reference surface ------------------------------------------------------------------------
+    def preprocess(self, klines_cv, image_shape, pred_superpoint, valid_mask=None):
+        """Line tokenisation.  Returns the reference's dict (11 tensor entries, leading batch axis 1)."""
+        klines = change_cv2_T_np(klines_cv)
+        _, _, height, width = self.config["image_shape"] = image_shape
+        if valid_mask is None:
+            valid_mask = np.ones((height, width))
+        klines = remove_borders(klines, self.config["remove_borders"], height, width, valid_mask)
+        klines = filter_by_length(klines, self.config["min_length"], self.config["max_keylines"])
+        K = len(klines["klines"])
+        if K == 0:
+            return klines
+        dd, ds = pred_superpoint["dense_descriptor"], pred_superpoint["dense_score"]
+        eng = self.engine(dd.device)
+        td, T = self.config["token_distance"], self.config["max_tokens"]
+        recs, N = eng.pack(klines["klines"], klines["length_klines"], klines["angles"], td, T)
+        align = int(torch.__version__[2]) > 2   # the reference's own version switch (line_process.py:93)
+        tb = eng.tokenize(recs, np.array([0, K], np.int32), np.array([0, N], np.int32), dd, ds, token_distance=td,
+                          max_tokens=T, align_corners=align)
+        n_sub = torch.from_numpy(recs["n_sub"].astype(np.int64)).to(tb.sub2line.device)
+        s2l = tb.sub2line.long()
+        A = torch.zeros((K, N), device=tb.sub2line.device)
+        A[s2l, torch.arange(N, device=s2l.device)] = (1 / n_sub.to(torch.float64))[s2l].float()
+        # the reference clips the end points through a view, so the exported key-lines carry the clip
+        klines["klines"] = tb.klines[None]
+        klines["length_klines"] = tb.length[None]
+        klines["angles"] = tb.angles[None]
+        klines["sublines"] = tb.sublines[None]
+        klines["pnt_sublines"] = tb.pnt[None]
+        klines["mask_sublines"] = tb.mask[None, :, :, None]
+        klines["resp_sublines"] = tb.resp[None, :, None]
+        klines["angle_sublines"] = tb.angle_sub[None]
+        klines["desc_sublines"] = tb.desc[None]
+        klines["score_sublines"] = tb.score[None, :, :, None]
+        klines["mat_klines2sublines"] = A[None]
+        return klines
+
+    def forward(self, data):
+        if len(data["klines"]) == 0:
+            return self.default_ret()
+        sub = data["sublines"]
+        B, N = int(sub.shape[0]), int(sub.shape[1])
+        T = int(data["pnt_sublines"].shape[2])
+        eng = self.engine(sub.device if sub.is_cuda else None)
+        flat = lambda t, *tail: t.reshape(B * N, *tail)
+        out = eng.forward_tensors(flat(sub, 2, 2), flat(data["pnt_sublines"], T, 2), flat(data["resp_sublines"]),
+                                  flat(data["angle_sublines"], 2), flat(data["desc_sublines"], T, 256),
+                                  flat(data["score_sublines"], T), np.arange(B + 1, dtype=np.int32) * N)
+        data.update({"line_desc": out.view(B, N, 256).transpose(1, 2)})
+        return data
+
+    def subline2keyline(self, distance_sublines, mat_klines2sublines0, mat_klines2sublines1):
+        """Mean sub-line distance per key-line pair: (A0 @ D @ A1^T)[None], NumPy in / NumPy out."""
+        a0, a1 = mat_klines2sublines0.float(), mat_klines2sublines1.float()
+        d = torch.as_tensor(np.asarray(distance_sublines), dtype=torch.float32, device=a0.device)
+        return (a0 @ d @ a1.t())[None].cpu().numpy()
+
+    def default_ret(self):
+        return {"klines": torch.empty((1, 0, 2, 2)), "sublines": torch.empty((1, 0, 2, 2)),
+                "line_desc": torch.empty((1, 256, 0)), "mat_klines2sublines": torch.empty((1, 0, 0))}

@@ -58,6 +58,7 @@ def unpack_descriptors(buf: torch.Tensor, n_images_cap: int):
 def allgather_descriptors(packed: torch.Tensor, group=None) -> torch.Tensor:
     """ONE collective: every rank contributes its packed slab, receives [world, rows, 256]."""
     world = dist.get_world_size(group)
-    out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(out, packed.contiguous(), group=group)
-    return out
+    rows = packed.shape[0]
+    out = torch.empty((world * rows,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, packed.contiguous(), group=group)   # dim-0 concatenation of the slabs
+    return out.view((world, rows) + tuple(packed.shape[1:]))
