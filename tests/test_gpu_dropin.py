@@ -70,7 +70,7 @@ def test_linetransformer_quirks_and_empty():
     for k, v in ret.items():
         assert tuple(v.shape) == tuple(g1[f"ret_{k}_shape"])
     assert len(m.preprocess([], (1, 1, *hw), sp)["klines"]) == 0                          # zero detections: no crash
-    bad = [synth.KeyLine(100, 100, 150, 100, length=200.0)]                                # detector length > geometry
+    bad = [synth.KeyLine(100, 100, 150, 100, length=400.0), synth.KeyLine(100, 200, 300, 200)]   # detector length > geometry
     with pytest.raises(AssertionError):
         m.preprocess(bad, (1, 1, *hw), sp)
 
