@@ -181,6 +181,15 @@ int linetr_match_points(LinetrHandle* h, const float* d_desc0_cn, int32_t n0, co
                         int32_t n1, float nn_thresh, int32_t mutual, float* d_dist, int32_t* d_match01,
                         void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- diagnostics ---------------------------------------------------------------------------- */
+
+/* Runs the library's fp32-MFMA GEMM  Y[M,N] = act(A[M,K] W[N,K]^T + bias) (+ R)  on device buffers; used
+ * by the unit tests (vs a plain PyTorch fp32 reference) and by the kernel micro-benchmarks.  act: 0 none,
+ * 1 ReLU, 2 erf-GELU, 3 max(2-2x,0).  d_bias / d_residual may be NULL.  N % 64 == 0, K % 32 == 0. */
+int linetr_debug_gemm(LinetrHandle* h, const float* d_A, const float* d_W, const float* d_bias,
+                      const float* d_residual, float* d_Y, int32_t M, int32_t N, int32_t K, int32_t act,
+                      void* stream);
+
 /* ---- instrumentation ------------------------------------------------------------------------ */
 
 /* Per-kernel-class HIP-event timing.  linetr_set_profiling(h,1) clears the accumulators and makes

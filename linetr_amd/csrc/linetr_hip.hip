@@ -94,9 +94,20 @@ struct ProfScope {
 };
 
 const char* gemm_class_name(const GemmArgs& g, int groups) {
-  if (g.N % 128 != 0) return "gemm_f32_128x64";
-  int64_t big = (int64_t)cdiv(g.M, 128) * (g.N / 128) * groups;
-  return big >= 384 ? "gemm_f32_128x128" : "gemm_f32_64x128";
+  const char* base;
+  if (g.N % 128 != 0) base = "gemm_f32_128x64";
+  else {
+    int64_t big = (int64_t)cdiv(g.M, 128) * (g.N / 128) * groups;
+    base = big >= 384 ? "gemm_f32_128x128" : "gemm_f32_64x128";
+  }
+  // LINETR_PROFILE_SHAPES=1: one profile class per GEMM shape (tuning aid)
+  static const bool by_shape = getenv("LINETR_PROFILE_SHAPES") != nullptr;
+  if (!by_shape) return base;
+  static std::map<std::string, std::string> names;
+  char buf[128];
+  snprintf(buf, sizeof buf, "%s[M=%d,N=%d,K=%d,g=%d]", base, g.M, g.N, g.K, groups);
+  auto it = names.emplace(buf, buf).first;
+  return it->second.c_str();
 }
 
 int run_gemm(LinetrHandle* h, hipStream_t st, const float* A, int lda, const float* A2, int lda2, int K1,
@@ -776,6 +787,13 @@ extern "C" int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_
   LT_LAUNCH_CHECK();
   LT_HIP(hipStreamSynchronize(st));
   return LINETR_OK;
+}
+
+extern "C" int linetr_debug_gemm(LinetrHandle* h, const float* A, const float* W, const float* bias, const float* R,
+                                 float* Y, int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
+  if (!h || !A || !W || !Y) return fail(LINETR_E_ARG, "debug_gemm: null argument");
+  LT_HIP(hipSetDevice(h->device));
+  return run_gemm(h, (hipStream_t)stream, A, K, nullptr, 0, 0, W, bias, R, N, Y, N, M, N, K, act);
 }
 
 // =============================================================================================

@@ -266,6 +266,19 @@ class Engine:
                                               ws.numel(), self._stream()))
         return dist, m01
 
+    def debug_gemm(self, A, W, bias=None, residual=None, act=0):
+        """Y = act(A @ W.T + bias) (+ residual) on the library's MFMA GEMM (diagnostics / unit tests)."""
+        A, W = self._f32(A), self._f32(W)
+        M, K = A.shape
+        N = W.shape[0]
+        Y = torch.empty((M, N), dtype=torch.float32, device=self.device)
+        b = self._f32(bias) if bias is not None else None
+        r = self._f32(residual) if residual is not None else None
+        nat.check(self._L.linetr_debug_gemm(self._h, A.data_ptr(), W.data_ptr(), b.data_ptr() if b is not None else None,
+                                            r.data_ptr() if r is not None else None, Y.data_ptr(), M, N, K, int(act),
+                                            self._stream()))
+        return Y
+
     # ------------------------------------------------------------------ profiling
     def set_profiling(self, on: bool):
         nat.check(self._L.linetr_set_profiling(self._h, int(on)))
