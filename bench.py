@@ -75,12 +75,16 @@ class Pipeline:
         self.n_img_cap = 2 * pairs
         self.rows_cap = sum(len(l) for l in lines)
         self.packed = None
+        # the detector output of the batch as one host array + row offsets (input format of the batched API)
+        self.offsets = np.zeros(len(lines) + 1, dtype=np.int32)
+        np.cumsum([len(l) for l in lines], out=self.offsets[1:])
+        self.cat = np.ascontiguousarray(np.concatenate(lines), dtype=np.float64)
 
     def describe(self):
         e, c = self.eng, LINE_CFG
-        recs, cu_k, cu_n = e.prefilter(self.lines, self.hw[0], self.hw[1], remove_borders=c["remove_borders"],
+        recs, cu_k, cu_n = e.prefilter(self.cat, self.hw[0], self.hw[1], remove_borders=c["remove_borders"],
                                        min_length=c["min_length"], max_keylines=c["max_keylines"],
-                                       token_distance=c["token_distance"], max_tokens=self.T)
+                                       token_distance=c["token_distance"], max_tokens=self.T, offsets=self.offsets)
         tb = e.tokenize(recs, cu_k, cu_n, self.dd, self.ds, token_distance=c["token_distance"], max_tokens=self.T)
         ld = e.forward(tb)
         return tb, ld

@@ -112,6 +112,17 @@ int linetr_prefilter(const double* h_lines6, int32_t K, int32_t height, int32_t 
                      double token_distance, int32_t max_tokens, int32_t image_index, int32_t sub_base,
                      LinetrLineRec* h_recs, int32_t capacity, int32_t* k_out, int32_t* n_out);
 
+/* linetr_prefilter for a whole batch in one call (images processed by up to `n_threads` host threads,
+ * 0 = library default).  h_lines6 holds the [K_i,6] blocks of all images back to back, h_line_off [B+1]
+ * their row offsets; h_valid_masks is NULL or an array of B (nullable) [height,width] float64 pointers.
+ * Writes the records image-major into h_recs (may be pinned memory) and the prefix sums of surviving
+ * key-lines / sub-lines into h_cu_k / h_cu_n [B+1]. */
+int linetr_prefilter_batch(const double* h_lines6, const int32_t* h_line_off, int32_t n_images, int32_t height,
+                           int32_t width, int32_t border, double min_length, int32_t max_keylines,
+                           const double* const* h_valid_masks, double token_distance, int32_t max_tokens,
+                           int32_t n_threads, LinetrLineRec* h_recs, int32_t capacity, int32_t* h_cu_k,
+                           int32_t* h_cu_n);
+
 /* Same record packing for lines that were already filtered/sorted by the caller (the Python shim
  * keeps NumPy's own argsort so that tie order is the reference's on the same machine).
  * h_klines [K,2,2], h_length [K], h_angles [K,2] float64. */
@@ -145,10 +156,11 @@ int64_t linetr_forward_workspace_bytes(const LinetrHandle* h, int32_t N, int32_t
  * h_cu_sub [B+1]: host prefix sums of sub-lines per image (signature attention is per image).
  * Inputs are the tokeniser tensors; mask is accepted for interface fidelity and ignored, because it
  * masks query rows only and the CLS row is never masked (models/line_attention.py:16).
+ * d_cu_sub: the same array already on the device, or NULL (the library then copies h_cu_sub itself).
  * d_line_desc [N,256] row-major (the shim exposes the reference's [1,256,N] as a transposed view). */
-int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const int32_t* h_cu_sub, int32_t n_images,
-                   int32_t max_tokens, float* d_line_desc, void* d_workspace, int64_t workspace_bytes,
-                   void* stream);
+int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const int32_t* h_cu_sub, const int32_t* d_cu_sub,
+                   int32_t n_images, int32_t max_tokens, float* d_line_desc, void* d_workspace,
+                   int64_t workspace_bytes, void* stream);
 
 /* ---- device: matcher ------------------------------------------------------------------------ */
 

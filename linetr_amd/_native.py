@@ -68,13 +68,14 @@ def lib():
     L.linetr_destroy.restype = None
     L.linetr_prefilter.argtypes = [vp, i32, i32, i32, i32, f64, i32, vp, f64, i32, i32, i32, vp, i32, C.POINTER(i32),
                                    C.POINTER(i32)]
+    L.linetr_prefilter_batch.argtypes = [vp, vp, i32, i32, i32, i32, f64, i32, vp, f64, i32, i32, vp, i32, vp, vp]
     L.linetr_pack_lines.argtypes = [vp, vp, vp, i32, f64, i32, i32, i32, vp, C.POINTER(i32)]
     L.linetr_tokenize_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.linetr_tokenize_workspace_bytes.restype = i64
     L.linetr_tokenize.argtypes = [vp, vp, i32, i32, f64, i32, vp, vp, i32, i32, i32, i32, Tokens, vp, vp, i64, vp]
     L.linetr_forward_workspace_bytes.argtypes = [vp, i32, i32]
     L.linetr_forward_workspace_bytes.restype = i64
-    L.linetr_forward.argtypes = [vp, C.POINTER(Tokens), vp, i32, i32, vp, vp, i64, vp]
+    L.linetr_forward.argtypes = [vp, C.POINTER(Tokens), vp, vp, i32, i32, vp, vp, i64, vp]
     L.linetr_match_workspace_bytes.argtypes = [i32, i64, i64, i64]
     L.linetr_match_workspace_bytes.restype = i64
     L.linetr_match.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, i64, vp]
@@ -90,7 +91,7 @@ def lib():
 
 
 EXPORTS = ["linetr_abi_version", "linetr_last_error", "linetr_create", "linetr_destroy", "linetr_prefilter",
-           "linetr_pack_lines", "linetr_tokenize_workspace_bytes", "linetr_tokenize", "linetr_forward_workspace_bytes",
+           "linetr_prefilter_batch", "linetr_pack_lines", "linetr_tokenize_workspace_bytes", "linetr_tokenize", "linetr_forward_workspace_bytes",
            "linetr_forward", "linetr_match_workspace_bytes", "linetr_match", "linetr_match_points",
            "linetr_match_distmat", "linetr_debug_gemm", "linetr_set_profiling", "linetr_get_profile"]
 

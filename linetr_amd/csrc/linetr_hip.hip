@@ -4,6 +4,7 @@
 #include <map>
 #include <memory>
 #include <numeric>
+#include <thread>
 
 #include "lt_common.h"
 #include "lt_gemm.h"
@@ -431,11 +432,9 @@ extern "C" int linetr_pack_lines(const double* h_klines, const double* h_length,
   return LINETR_OK;
 }
 
-extern "C" int linetr_prefilter(const double* L, int32_t K, int32_t height, int32_t width, int32_t border,
-                                double min_length, int32_t max_keylines, const double* vm, double td, int32_t T,
-                                int32_t image_index, int32_t sub_base, LinetrLineRec* h_recs, int32_t capacity,
-                                int32_t* k_out, int32_t* n_out) {
-  if (K < 0 || (K > 0 && !L) || !k_out || !n_out) return fail(LINETR_E_ARG, "null argument");
+// filter + sort of one image into `out` (records carry geometry/length/angle only)
+static void prefilter_core(const double* L, int32_t K, int32_t height, int32_t width, int32_t border,
+                           double min_length, int32_t max_keylines, const double* vm, std::vector<LinetrLineRec>& out) {
   std::vector<LinetrLineRec> keep;
   keep.reserve(K);
   const double xmax = ((double)width - 0.001) - (double)border;   // width-eps-border, line_process.py:72-74
@@ -471,16 +470,65 @@ extern "C" int linetr_prefilter(const double* L, int32_t K, int32_t height, int3
   int64_t n_keep = (int64_t)idx.size();
   if (max_keylines < 0) n_keep = std::max<int64_t>(0, n_keep + max_keylines);                // python slice [:m]
   else n_keep = std::min<int64_t>(n_keep, max_keylines);
-  if (n_keep > capacity) return fail(LINETR_E_CAPACITY, "prefilter: %lld lines exceed capacity %d", (long long)n_keep, capacity);
-  int cur = sub_base;
+  out.resize(n_keep);
   for (int64_t i = 0; i < n_keep; ++i) {
-    LinetrLineRec r = keep[idx[i]];
-    angle_of(r);                                                                             // :20
-    if (int e = pack_one(r, td, T, image_index, (int)i, cur)) return e;
-    h_recs[i] = r;
+    out[i] = keep[idx[i]];
+    angle_of(out[i]);                                                                        // :20
   }
-  *k_out = (int)n_keep;
+}
+
+extern "C" int linetr_prefilter(const double* L, int32_t K, int32_t height, int32_t width, int32_t border,
+                                double min_length, int32_t max_keylines, const double* vm, double td, int32_t T,
+                                int32_t image_index, int32_t sub_base, LinetrLineRec* h_recs, int32_t capacity,
+                                int32_t* k_out, int32_t* n_out) {
+  if (K < 0 || (K > 0 && !L) || !k_out || !n_out) return fail(LINETR_E_ARG, "null argument");
+  std::vector<LinetrLineRec> sel;
+  prefilter_core(L, K, height, width, border, min_length, max_keylines, vm, sel);
+  if ((int64_t)sel.size() > capacity)
+    return fail(LINETR_E_CAPACITY, "prefilter: %lld lines exceed capacity %d", (long long)sel.size(), capacity);
+  int cur = sub_base;
+  for (size_t i = 0; i < sel.size(); ++i) {
+    if (int e = pack_one(sel[i], td, T, image_index, (int)i, cur)) return e;
+    h_recs[i] = sel[i];
+  }
+  *k_out = (int)sel.size();
   *n_out = cur - sub_base;
+  return LINETR_OK;
+}
+
+extern "C" int linetr_prefilter_batch(const double* L, const int32_t* off, int32_t B, int32_t height, int32_t width,
+                                      int32_t border, double min_length, int32_t max_keylines,
+                                      const double* const* vms, double td, int32_t T, int32_t n_threads,
+                                      LinetrLineRec* h_recs, int32_t capacity, int32_t* cu_k, int32_t* cu_n) {
+  if (B < 0 || !off || !cu_k || !cu_n || (B > 0 && off[B] > 0 && !L)) return fail(LINETR_E_ARG, "null argument");
+  std::vector<std::vector<LinetrLineRec>> sel(B);
+  int nt = n_threads > 0 ? n_threads : std::min<int>(8, std::max(1u, std::thread::hardware_concurrency()));
+  nt = std::max(1, std::min(nt, B / 8));  // not worth a thread for fewer than 8 images each
+  auto work = [&](int t) {
+    for (int i = t; i < B; i += nt)
+      prefilter_core(L + (size_t)off[i] * 6, off[i + 1] - off[i], height, width, border, min_length, max_keylines,
+                     vms ? vms[i] : nullptr, sel[i]);
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+  }
+  cu_k[0] = cu_n[0] = 0;
+  int cur = 0;
+  int64_t k = 0;
+  for (int i = 0; i < B; ++i) {
+    if (k + (int64_t)sel[i].size() > capacity)
+      return fail(LINETR_E_CAPACITY, "prefilter_batch: more than %d surviving lines", capacity);
+    for (size_t j = 0; j < sel[i].size(); ++j) {
+      if (int e = pack_one(sel[i][j], td, T, i, (int)j, cur)) return e;
+      h_recs[k++] = sel[i][j];
+    }
+    cu_k[i + 1] = (int)k;
+    cu_n[i + 1] = cur;
+  }
   return LINETR_OK;
 }
 
@@ -576,8 +624,9 @@ extern "C" int64_t linetr_forward_workspace_bytes(const LinetrHandle* h, int32_t
   return fwd_layout(h->cfg, std::max(N, 1), T, std::max(N, 1), nullptr).total;
 }
 
-extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const int32_t* h_cu, int32_t n_images,
-                              int32_t T, float* d_line_desc, void* d_ws, int64_t ws_bytes, void* stream) {
+extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const int32_t* h_cu, const int32_t* d_cu,
+                              int32_t n_images, int32_t T, float* d_line_desc, void* d_ws, int64_t ws_bytes,
+                              void* stream) {
   if (!h || !tok || !h_cu || n_images < 1) return fail(LINETR_E_ARG, "forward: null argument");
   const int N = h_cu[n_images];
   if (N <= 0) return LINETR_OK;
@@ -594,7 +643,11 @@ extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const in
   LT_HIP(hipSetDevice(h->device));
   const LinetrModelConfig& c = h->cfg;
   FwdWs w = fwd_layout(c, N, T, std::max(N, 1), (char*)d_ws);
-  LT_HIP(hipMemcpyAsync(w.cu, h_cu, (n_images + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+  const int* cu_dev = d_cu;
+  if (!cu_dev) {
+    LT_HIP(hipMemcpyAsync(w.cu, h_cu, (n_images + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    cu_dev = w.cu;
+  }
   const int64_t rows = (int64_t)N * T;
   if (rows > INT32_MAX / 2) return fail(LINETR_E_ARG, "forward: batch too large");
   const int e0 = c.enc_channels[0], e1 = c.enc_channels[1], e2 = c.enc_channels[2], e3 = c.enc_channels[3];
@@ -655,7 +708,7 @@ extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const in
       double fl = 0;
       for (int i = 0; i < n_images; ++i) { double n = h_cu[i + 1] - h_cu[i]; fl += 2.0 * 2.0 * n * n * D; }
       ProfScope ps(h, st, "sig_attn", fl, (double)N * D * 16);
-      hipLaunchKernelGGL(sig_attn_kernel, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, w.cu, w.msgp);
+      hipLaunchKernelGGL(sig_attn_kernel, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
       LT_LAUNCH_CHECK();
     }
     if ((e = run_gemm(h, st, w.msgp, D, nullptr, 0, 0, S.Wm, S.bm, nullptr, 0, w.msg, D, N, D, D, ACT_NONE))) return e;

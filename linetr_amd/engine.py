@@ -123,30 +123,59 @@ class Engine:
         return t
 
     # ------------------------------------------------------------------ host pre-filter
-    def prefilter(self, lines6_list, height, width, *, remove_borders, min_length, max_keylines, token_distance,
-                  max_tokens, valid_masks=None):
-        """a1-a3 for a list of images (each [K,6] float64).  Returns (recs, cu_k, cu_n)."""
-        L = self._L
-        B = len(lines6_list)
-        cap = sum(len(l) for l in lines6_list)
-        recs = np.zeros(max(cap, 1), dtype=nat.REC_DTYPE)
-        cu_k = np.zeros(B + 1, dtype=np.int32)
-        cu_n = np.zeros(B + 1, dtype=np.int32)
-        k_out, n_out = C.c_int32(), C.c_int32()
-        for i, l6 in enumerate(lines6_list):
-            l6 = np.ascontiguousarray(l6, dtype=np.float64).reshape(-1, 6)
-            vm = None
-            if valid_masks is not None and valid_masks[i] is not None:
-                vm = np.ascontiguousarray(valid_masks[i], dtype=np.float64)
-            base = int(cu_k[i])
-            nat.check(L.linetr_prefilter(nat.np_ptr(l6), len(l6), height, width, int(remove_borders), float(min_length),
-                                         int(max_keylines), nat.np_ptr(vm) if vm is not None else None,
-                                         float(token_distance), int(max_tokens), i, int(cu_n[i]),
-                                         C.c_void_p(recs.ctypes.data + base * nat.REC_DTYPE.itemsize), cap - base,
-                                         C.byref(k_out), C.byref(n_out)))
-            cu_k[i + 1] = base + k_out.value
-            cu_n[i + 1] = cu_n[i] + n_out.value
-        return recs[:cu_k[-1]], cu_k, cu_n
+    def _pinned_slot(self, nbytes):
+        """ring of pinned staging buffers; a slot is reused only after its last H2D copy has completed."""
+        ring = self.__dict__.setdefault("_ring", {"i": 0, "slots": [None] * 3})
+        ring["i"] = (ring["i"] + 1) % len(ring["slots"])
+        slot = ring["slots"][ring["i"]]
+        if slot is None or slot["buf"].numel() < nbytes:
+            slot = {"buf": torch.empty(int(nbytes * 1.5) + 4096, dtype=torch.uint8, pin_memory=True), "event": None}
+            ring["slots"][ring["i"]] = slot
+        if slot["event"] is not None:
+            slot["event"].synchronize()
+            slot["event"] = None
+        return slot
+
+    def prefilter(self, lines6, height, width, *, remove_borders, min_length, max_keylines, token_distance,
+                  max_tokens, valid_masks=None, offsets=None, n_threads=0):
+        """a1-a3 for a batch.  `lines6` is a list of [K_i,6] float64 arrays, or one concatenated [sum K,6] array
+        with `offsets` [B+1].  Returns (recs, cu_k, cu_n); recs lives in pinned memory ready for an async H2D."""
+        if offsets is None:
+            lens = [len(l) for l in lines6]
+            offsets = np.zeros(len(lens) + 1, dtype=np.int32)
+            np.cumsum(lens, out=offsets[1:])
+            cat = (np.concatenate([np.asarray(l, dtype=np.float64).reshape(-1, 6) for l in lines6])
+                   if len(lens) else np.zeros((0, 6)))
+        else:
+            cat = lines6
+            offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        cat = np.ascontiguousarray(cat, dtype=np.float64)
+        B = len(offsets) - 1
+        cap = int(offsets[-1])
+        rec_bytes = max(cap, 1) * nat.REC_DTYPE.itemsize
+        slot = self._pinned_slot(rec_bytes + 8 * (B + 1) + 64)
+        host = slot["buf"].numpy()
+        recs = host[:rec_bytes].view(nat.REC_DTYPE)
+        cu_k = host[rec_bytes:rec_bytes + 4 * (B + 1)].view(np.int32)
+        cu_n = host[rec_bytes + 4 * (B + 1):rec_bytes + 8 * (B + 1)].view(np.int32)
+        vm_ptrs = None
+        keep = []
+        if valid_masks is not None:
+            arr = (C.c_void_p * B)()
+            for i, vm in enumerate(valid_masks):
+                if vm is not None:
+                    vm = np.ascontiguousarray(vm, dtype=np.float64)
+                    keep.append(vm)
+                    arr[i] = vm.ctypes.data
+            vm_ptrs = arr
+        nat.check(self._L.linetr_prefilter_batch(nat.np_ptr(cat), nat.np_ptr(offsets), B, int(height), int(width),
+                                                 int(remove_borders), float(min_length), int(max_keylines), vm_ptrs,
+                                                 float(token_distance), int(max_tokens), int(n_threads),
+                                                 nat.np_ptr(recs), cap, nat.np_ptr(cu_k), nat.np_ptr(cu_n)))
+        K = int(cu_k[-1])
+        out = recs[:K]
+        self._last_host = {"slot": slot, "recs_ptr": recs.ctypes.data, "rec_bytes": rec_bytes, "B": B}
+        return out, cu_k.copy(), cu_n.copy()
 
     def pack(self, klines, length, angles, token_distance, max_tokens, image=0, sub_base=0):
         """records for already-filtered lines (float64 arrays, reference layout)."""
@@ -188,7 +217,19 @@ class Engine:
             score=torch.empty((N, T), **f), sub2line=torch.empty((N,), dtype=torch.int32, device=dev))
         if K == 0 or N == 0:
             return tb
-        d_recs = torch.from_numpy(recs.view(np.uint8).reshape(-1)).to(dev)
+        last = getattr(self, "_last_host", None)
+        if last is not None and K > 0 and recs.ctypes.data == last["recs_ptr"] and last["B"] == B:
+            # records + prefix sums sit in one pinned blob: ONE async H2D, no host/device synchronisation
+            nb = last["rec_bytes"] + 8 * (B + 1)
+            d_blob = torch.empty(nb, dtype=torch.uint8, device=dev)
+            d_blob.copy_(last["slot"]["buf"][:nb], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            last["slot"]["event"] = ev
+            d_recs = d_blob
+            tb.extra["d_cu_n"] = d_blob[last["rec_bytes"] + 4 * (B + 1):].view(torch.int32)
+        else:
+            d_recs = torch.from_numpy(recs.view(np.uint8).reshape(-1)).to(dev)
         nbytes = self._L.linetr_tokenize_workspace_bytes(B, H, W, N)
         ws = self._workspace("tok", nbytes)
         ct = tb.c_tokens()
@@ -200,7 +241,7 @@ class Engine:
         tb.extra["d_recs"] = d_recs  # keep alive until the stream has consumed it
         return tb
 
-    def forward_tensors(self, sublines, pnt, resp, angle_sub, desc, score, cu_n, out=None) -> torch.Tensor:
+    def forward_tensors(self, sublines, pnt, resp, angle_sub, desc, score, cu_n, out=None, d_cu_n=None) -> torch.Tensor:
         """LineTransformer.forward on flat tensors; returns line_desc [N,256] (row-major)."""
         N, T = int(pnt.shape[0]), int(pnt.shape[1])
         t = nat.Tokens()
@@ -215,12 +256,13 @@ class Engine:
             return out
         nbytes = self._L.linetr_forward_workspace_bytes(self._h, N, T)
         ws = self._workspace("fwd", nbytes)
-        nat.check(self._L.linetr_forward(self._h, C.byref(t), nat.np_ptr(cu), len(cu) - 1, T, out.data_ptr(),
-                                         ws.data_ptr(), ws.numel(), self._stream()))
+        nat.check(self._L.linetr_forward(self._h, C.byref(t), nat.np_ptr(cu), d_cu_n.data_ptr() if d_cu_n is not None else None,
+                                         len(cu) - 1, T, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return out
 
     def forward(self, tb: TokenBatch, out=None) -> torch.Tensor:
-        return self.forward_tensors(tb.sublines, tb.pnt, tb.resp, tb.angle_sub, tb.desc, tb.score, tb.cu_n, out)
+        return self.forward_tensors(tb.sublines, tb.pnt, tb.resp, tb.angle_sub, tb.desc, tb.score, tb.cu_n, out,
+                                    tb.extra.get("d_cu_n"))
 
     def match(self, desc0, cu_n0, sub2line0, cu_k0, desc1, cu_n1, sub2line1, cu_k1, thr, mutual=True):
         """Match image i of side 0 with image i of side 1 for all i.  desc* are [N,256] row-major.
