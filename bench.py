@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="image pairs per GPU per step (default: workload's)")
+    ap.add_argument("--precision", default="bf16x6", choices=["f32", "bf16x6", "bf16x3"],
+                    help="MFMA path of the dense contractions (bf16x6 = fp32-faithful split, the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -182,6 +184,7 @@ def main():
     H, W, n_lines, lo, hi, T, def_pairs = WORKLOADS[args.workload]
     pairs = args.pairs or def_pairs
     eng = Engine(synth.calibrated_state_dict(), device, image_shape=[H, W])
+    eng.set_precision(args.precision)
     lines, dd, ds, hw, T = make_inputs(args.workload, pairs, rank, device)
     pipe = Pipeline(eng, lines, dd, ds, hw, T, world, pairs)
 
@@ -267,7 +270,10 @@ def main():
     out = {
         "metric": "line_descriptors_per_sec", "value": round(value, 1), "unit": "line-descriptors/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"f32": "f32 (v_mfma_f32_32x32x2_f32)", "bf16x6": "f32 in/out; GEMMs as 6 bf16-split MFMA products, fp32 accumulate (fp32-faithful)",
+                  "bf16x3": "f32 in/out; GEMMs as 3 bf16-split MFMA products, fp32 accumulate (~1e-5)"}[args.precision],
+        "precision": args.precision, "data": "synthetic",
         "config": {"workload": f"{args.workload}: {pairs} pairs/GPU of {W}x{H}, {n_lines} lines/image -> "
                                f"{int(tb.N / n_img)} sub-lines x {T} tokens, d_model=256, seeded weights",
                    "pairs_per_gpu": pairs, "descriptors_per_step": int(n_desc_step),

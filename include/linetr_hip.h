@@ -193,14 +193,29 @@ int linetr_match_points(LinetrHandle* h, const float* d_desc0_cn, int32_t n0, co
                         int32_t n1, float nn_thresh, int32_t mutual, float* d_dist, int32_t* d_match01,
                         void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- arithmetic mode of the dense contractions ----------------------------------------------------- */
+
+/* All Linear/Conv1d(k=1) contractions run on one of three MFMA paths (fp32 in, fp32 accumulate, fp32 out):
+ *   LINETR_PREC_F32     v_mfma_f32_32x32x2_f32, exact fp32 products                (157 TF ceiling)
+ *   LINETR_PREC_BF16X6  operands split into 3 bf16 planes, 6 cross products: fp32-faithful (~2^-23 per
+ *                       product, same class as fp32 summation-order noise)          (417 TF-equivalent)
+ *   LINETR_PREC_BF16X3  2 planes, 3 cross products: ~1e-5 relative per product      (833 TF-equivalent)
+ * Default: LINETR_PREC_BF16X6, overridable with the environment variable LINETR_PRECISION=f32|bf16x6|bf16x3
+ * at linetr_create time.  The signature attention and every non-GEMM stage are fp32 in all modes. */
+enum { LINETR_PREC_F32 = 0, LINETR_PREC_BF16X3 = 1, LINETR_PREC_BF16X6 = 2 };
+int linetr_set_precision(LinetrHandle* h, int32_t mode);
+int linetr_get_precision(const LinetrHandle* h);
+
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 
 /* Runs the library's fp32-MFMA GEMM  Y[M,N] = act(A[M,K] W[N,K]^T + bias) (+ R)  on device buffers; used
  * by the unit tests (vs a plain PyTorch fp32 reference) and by the kernel micro-benchmarks.  act: 0 none,
- * 1 ReLU, 2 erf-GELU, 3 max(2-2x,0).  d_bias / d_residual may be NULL.  N % 64 == 0, K % 32 == 0. */
+ * 1 ReLU, 2 erf-GELU, 3 max(2-2x,0).  d_bias / d_residual may be NULL.  N % 64 == 0, K % 32 == 0.
+ * cache_weights != 0 keeps the split-bf16 copy of d_W (keyed by pointer) for later calls, so repeated
+ * calls time the GEMM kernel alone; the caller then promises not to change the contents of d_W. */
 int linetr_debug_gemm(LinetrHandle* h, const float* d_A, const float* d_W, const float* d_bias,
                       const float* d_residual, float* d_Y, int32_t M, int32_t N, int32_t K, int32_t act,
-                      void* stream);
+                      int32_t cache_weights, void* stream);
 
 /* ---- instrumentation ------------------------------------------------------------------------ */
 

@@ -8,6 +8,7 @@
 
 #include "lt_common.h"
 #include "lt_gemm.h"
+#include "lt_gemm_split.h"
 #include "lt_match.h"
 #include "lt_model.h"
 #include "lt_token.h"
@@ -41,6 +42,12 @@ struct LinetrHandle {
   const float *Watt, *batt, *Wfc, *bfc, *ln1g, *ln1b, *Wf1, *bf1, *Wf2, *bf2, *ln2g, *ln2b;
   std::vector<SigLayer> sig;
   const float *Wfin, *bfin;
+  // split-bf16 copies of every GEMM weight (2 and 3 planes), keyed by the fp32 pointer
+  int precision = LINETR_PREC_BF16X6;
+  unsigned char* split_arena = nullptr;
+  struct SplitW { size_t off2, off3; int64_t rows; int K; };
+  std::map<const float*, SplitW> split;
+  std::map<const float*, unsigned char*> debug_split;  // linetr_debug_gemm(cache_weights=1)
   // profiling
   bool profiling = false;
   std::vector<ProfClass> classes;
@@ -94,19 +101,22 @@ struct ProfScope {
   }
 };
 
-const char* gemm_class_name(const GemmArgs& g, int groups) {
-  const char* base;
-  if (g.N % 128 != 0) base = "gemm_f32_128x64";
+const char* gemm_class_name(const GemmArgs& g, int groups, const char* kind) {
+  const char* tile;
+  if (strcmp(kind, "gemm_f32") != 0) {
+    static const char* tile_env = getenv("LINETR_GEMM_TILE");
+    tile = tile_env ? tile_env : split_tile_name(g, groups);
+  } else if (g.N % 128 != 0) tile = "128x64";
   else {
     int64_t big = (int64_t)cdiv(g.M, 128) * (g.N / 128) * groups;
-    base = big >= 384 ? "gemm_f32_128x128" : "gemm_f32_64x128";
+    tile = big >= 384 ? "128x128" : "64x128";
   }
   // LINETR_PROFILE_SHAPES=1: one profile class per GEMM shape (tuning aid)
   static const bool by_shape = getenv("LINETR_PROFILE_SHAPES") != nullptr;
-  if (!by_shape) return base;
   static std::map<std::string, std::string> names;
-  char buf[128];
-  snprintf(buf, sizeof buf, "%s[M=%d,N=%d,K=%d,g=%d]", base, g.M, g.N, g.K, groups);
+  char buf[160];
+  if (by_shape) snprintf(buf, sizeof buf, "%s_%s[M=%d,N=%d,K=%d,g=%d]", kind, tile, g.M, g.N, g.K, groups);
+  else snprintf(buf, sizeof buf, "%s_%s", kind, tile);
   auto it = names.emplace(buf, buf).first;
   return it->second.c_str();
 }
@@ -119,9 +129,26 @@ int run_gemm(LinetrHandle* h, hipStream_t st, const float* A, int lda, const flo
   g.W = W; g.ldw = K; g.bias = bias; g.R = R; g.ldr = ldr; g.Y = Y; g.ldy = ldy;
   g.M = M; g.N = N; g.K = K; g.act = act;
   g.gA = gA; g.gW = gW; g.gBias = gBias; g.gY = gY;
-  ProfScope ps(h, st, gemm_class_name(g, groups), 2.0 * M * (double)N * K * groups,
-               4.0 * groups * ((double)M * K + (double)N * K + (double)M * N));
-  return gemm_launch(g, groups, st);
+  const double fl = 2.0 * M * (double)N * K * groups;
+  const double by = 4.0 * groups * ((double)M * K + (double)N * K + (double)M * N);
+  if (h->precision == LINETR_PREC_F32) {
+    ProfScope ps(h, st, gemm_class_name(g, groups, "gemm_f32"), fl, by);
+    return gemm_launch(g, groups, st);
+  }
+  auto it = h->split.find(W);
+  if (it == h->split.end()) return fail(LINETR_E_ARG, "gemm: weight has no split-bf16 copy");
+  SplitGemmArgs sa;
+  sa.g = g;
+  if (h->precision == LINETR_PREC_BF16X3) {
+    sa.Wsp = h->split_arena + it->second.off2;
+    sa.gWsp = gW * 4;
+    ProfScope ps(h, st, gemm_class_name(g, groups, "gemm_bf16x3"), fl, by);
+    return gemm_split_launch<2>(sa, groups, st);
+  }
+  sa.Wsp = h->split_arena + it->second.off3;
+  sa.gWsp = gW * 6;
+  ProfScope ps(h, st, gemm_class_name(g, groups, "gemm_bf16x6"), fl, by);
+  return gemm_split_launch<3>(sa, groups, st);
 }
 
 // ---- float64 weight preparation ---------------------------------------------------------------
@@ -202,6 +229,12 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
   struct Fix { const float** dst; size_t off; };
   std::vector<Fix> fix;
   auto place = [&](const float** dst, const std::vector<double>& v) { fix.push_back({dst, ar.put(v)}); };
+  struct GemmW { const float** dst; int64_t rows; int K; };
+  std::vector<GemmW> gemm_w;
+  auto place_w = [&](const float** dst, const std::vector<double>& v, int64_t rows, int K) {
+    place(dst, v);
+    gemm_w.push_back({dst, rows, K});
+  };
 
   // ---- positional encoders: 4 x (conv + BN + ReLU) + linear ------------------------------------
   const int ch_w[6] = {3, e0, e1, e2, e3, D}, ch_l[6] = {5, e0, e1, e2, e3, D};
@@ -224,14 +257,14 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
       if (err) return err;
       std::vector<double> Wf, bf;
       fold_bn(W, b, g, be, mu, va, ch[i + 1], ch[i], Wf, bf);
-      place(Wdst[i], Wf);
+      if (i == 0) place(Wdst[i], Wf); else place_w(Wdst[i], Wf, ch[i + 1], ch[i]);
       place(bdst[i], bf);
     }
     const float* W = tm.get(pre + "12.weight", (int64_t)D * e3, err);
     const float* b = tm.get(pre + "12.bias", D, err);
     if (err) return err;
     if (enc == 0) { W5w = to_d(W, (size_t)D * D); b5w = to_d(b, D); }
-    else { place(&H->lW5, to_d(W, (size_t)D * D)); place(&H->lb5, to_d(b, D)); }
+    else { place_w(&H->lW5, to_d(W, (size_t)D * D), D, e3); place(&H->lb5, to_d(b, D)); }
   }
 
   // ---- line-descriptive layer: only the last one matters (line_transformer.py:123-125) ----------
@@ -303,15 +336,15 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
         row[2 * D] = r;
         batt[o] = bb;
       }
-    place(&H->Watt, Watt);
+    place_w(&H->Watt, Watt, HEADS * DH, POOLW);
     place(&H->batt, batt);
-    place(&H->Wfc, to_d(Wfc, D * D));
+    place_w(&H->Wfc, to_d(Wfc, D * D), D, D);
     std::vector<double> bfc2(D);
     for (int i = 0; i < D; ++i) bfc2[i] = (double)bfc[i] + cls[i];  // residual of the CLS row is the constant token
     place(&H->bfc, bfc2);
     place(&H->ln1g, to_d(g1, D)); place(&H->ln1b, to_d(b1, D));
-    place(&H->Wf1, to_d(W1, (size_t)DI * D)); place(&H->bf1, to_d(bb1, DI));
-    place(&H->Wf2, to_d(W2, (size_t)D * DI)); place(&H->bf2, to_d(bb2, D));
+    place_w(&H->Wf1, to_d(W1, (size_t)DI * D), DI, D); place(&H->bf1, to_d(bb1, DI));
+    place_w(&H->Wf2, to_d(W2, (size_t)D * DI), D, DI); place(&H->bf2, to_d(bb2, D));
     place(&H->ln2g, to_d(g2, D)); place(&H->ln2b, to_d(b2, D));
   }
 
@@ -354,32 +387,68 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
     std::vector<double> W1f, b1f;
     fold_bn(W1, b1, g, be, mu, va, 2 * D, 2 * D, W1f, b1f);
     SigLayer& S = H->sig[l];
-    place(&S.Wqkv, Wqkv); place(&S.bqkv, bqkv);
-    place(&S.Wm, Wm2); place(&S.bm, to_d(bm, D));
-    place(&S.W1, W1f); place(&S.b1, b1f);
-    place(&S.W2, to_d(W2, (size_t)2 * D * D)); place(&S.b2, to_d(b2, D));
+    place_w(&S.Wqkv, Wqkv, 3 * D, D); place(&S.bqkv, bqkv);
+    place_w(&S.Wm, Wm2, D, D); place(&S.bm, to_d(bm, D));
+    place_w(&S.W1, W1f, 2 * D, 2 * D); place(&S.b1, b1f);
+    place_w(&S.W2, to_d(W2, (size_t)2 * D * D), D, 2 * D); place(&S.b2, to_d(b2, D));
   }
   {
     const float* W = tm.get("final_proj.weight", D * D, err);
     const float* b = tm.get("final_proj.bias", D, err);
     if (err) return err;
-    place(&H->Wfin, to_d(W, D * D));
+    place_w(&H->Wfin, to_d(W, D * D), D, D);
     place(&H->bfin, to_d(b, D));
   }
 
   LT_HIP(hipMalloc((void**)&H->arena, ar.host.size() * sizeof(float)));
   LT_HIP(hipMemcpy(H->arena, ar.host.data(), ar.host.size() * sizeof(float), hipMemcpyHostToDevice));
   for (auto& f : fix) *f.dst = H->arena + f.off;
+  // split-bf16 copies of the GEMM weights, produced on the device
+  {
+    size_t total = 0;
+    for (auto& w : gemm_w) {
+      LinetrHandle::SplitW sw;
+      sw.rows = w.rows; sw.K = w.K;
+      sw.off2 = total; total += align_up(w.rows * w.K * 4, 256);
+      sw.off3 = total; total += align_up(w.rows * w.K * 6, 256);
+      H->split[*w.dst] = sw;
+    }
+    LT_HIP(hipMalloc((void**)&H->split_arena, total));
+    for (auto& kv : H->split) {
+      const int64_t n4 = kv.second.rows * kv.second.K / 4;
+      hipLaunchKernelGGL(split_rows_kernel<2>, dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, 0, kv.first,
+                         H->split_arena + kv.second.off2, kv.second.rows, kv.second.K);
+      hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, 0, kv.first,
+                         H->split_arena + kv.second.off3, kv.second.rows, kv.second.K);
+    }
+    LT_LAUNCH_CHECK();
+    LT_HIP(hipDeviceSynchronize());
+  }
+  if (const char* e = getenv("LINETR_PRECISION")) {
+    if (!strcmp(e, "f32")) H->precision = LINETR_PREC_F32;
+    else if (!strcmp(e, "bf16x3")) H->precision = LINETR_PREC_BF16X3;
+    else if (!strcmp(e, "bf16x6")) H->precision = LINETR_PREC_BF16X6;
+    else return fail(LINETR_E_ARG, "LINETR_PRECISION must be f32, bf16x3 or bf16x6 (got '%s')", e);
+  }
   *out = H.release();
   return LINETR_OK;
 }
+
+extern "C" int linetr_set_precision(LinetrHandle* h, int32_t mode) {
+  if (!h || mode < LINETR_PREC_F32 || mode > LINETR_PREC_BF16X6) return fail(LINETR_E_ARG, "bad precision mode");
+  h->precision = mode;
+  return LINETR_OK;
+}
+extern "C" int linetr_get_precision(const LinetrHandle* h) { return h ? h->precision : LINETR_E_ARG; }
 
 extern "C" void linetr_destroy(LinetrHandle* h) {
   if (!h) return;
   hipSetDevice(h->device);
   for (auto& p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto e : h->event_pool) hipEventDestroy(e);
-  if (h->arena) hipFree(h->arena);
+  if (h->arena) (void)hipFree(h->arena);
+  if (h->split_arena) (void)hipFree(h->split_arena);
+  for (auto& kv : h->debug_split) (void)hipFree(kv.second);
   delete h;
 }
 
@@ -843,10 +912,36 @@ extern "C" int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_
 }
 
 extern "C" int linetr_debug_gemm(LinetrHandle* h, const float* A, const float* W, const float* bias, const float* R,
-                                 float* Y, int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
+                                 float* Y, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cache_weights,
+                                 void* stream) {
   if (!h || !A || !W || !Y) return fail(LINETR_E_ARG, "debug_gemm: null argument");
+  if (K % 32 || N % 64) return fail(LINETR_E_ARG, "debug_gemm: N %% 64 == 0 and K %% 32 == 0 required");
   LT_HIP(hipSetDevice(h->device));
-  return run_gemm(h, (hipStream_t)stream, A, K, nullptr, 0, 0, W, bias, R, N, Y, N, M, N, K, act);
+  hipStream_t st = (hipStream_t)stream;
+  if (h->precision == LINETR_PREC_F32) return run_gemm(h, st, A, K, nullptr, 0, 0, W, bias, R, N, Y, N, M, N, K, act);
+  // caller-provided weights: split them into a scratch buffer (optionally cached by pointer)
+  auto it = h->debug_split.find(W);
+  unsigned char* buf = it != h->debug_split.end() ? it->second : nullptr;
+  const int64_t b2 = align_up((int64_t)N * K * 4, 256);
+  if (!buf) {
+    LT_HIP(hipMalloc((void**)&buf, b2 + (int64_t)N * K * 6));
+    const int64_t n4 = (int64_t)N * K / 4;
+    hipLaunchKernelGGL(split_rows_kernel<2>, dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, st, W, buf, (int64_t)N, K);
+    hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, st, W, buf + b2, (int64_t)N, K);
+    LT_LAUNCH_CHECK();
+    if (cache_weights) h->debug_split[W] = buf;
+  }
+  h->split[W] = {0, (size_t)b2, N, K};
+  unsigned char* keep = h->split_arena;
+  h->split_arena = buf;  // the lookup inside run_gemm resolves relative to split_arena
+  int e = run_gemm(h, st, A, K, nullptr, 0, 0, W, bias, R, N, Y, N, M, N, K, act);
+  h->split_arena = keep;
+  h->split.erase(W);
+  if (!cache_weights) {
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(buf);
+  }
+  return e;
 }
 
 // =============================================================================================

@@ -1,0 +1,240 @@
+// Split-bf16 MFMA GEMM for gfx950:  Y[M,N] = epi(A[M,K] * W[N,K]^T + bias), fp32 in / fp32 out.
+//
+// fp32-input MFMA runs at the fp32 VECTOR rate on CDNA4 (157 TF, 1/16 of the bf16 MFMA rate).  This
+// kernel instead decomposes every fp32 operand into PL bf16 planes (x = p0 + p1 (+ p2), each plane
+// the round-to-nearest bf16 of the running remainder) and accumulates the significant cross products
+// with v_mfma_f32_32x32x16_bf16 in fp32:
+//     PL = 2  "bf16x3":  a0b0 + a0b1 + a1b0                     rel. error/product ~1e-5  (5.3x the fp32-MFMA ceiling)
+//     PL = 3  "bf16x6":  a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0  ~2^-23, i.e. fp32-faithful (2.7x the ceiling)
+// bf16 x bf16 products are exact in fp32 and the MFMA accumulates in fp32, so the only error is the
+// dropped low-order cross terms (smallest terms are accumulated first).
+//
+// Layout: weights are pre-split once ([N][K/32][PL][32] bf16, same bytes/element as fp32 for PL=2);
+// activations stay fp32 in HBM and are split by the loader on their way into LDS (v_cvt_pk_bf16_f32,
+// 3 VALU ops / element, hidden under the MFMAs).  LDS rows hold the PL planes of a 32-wide K chunk
+// back to back + 16 B pad: row stride 36 (PL=2) / 52 (PL=3) dwords = 4*odd, so ds_read_b128 of the
+// 8-element MFMA fragments is bank-conflict-free (same argument as lt_gemm.h).
+#pragma once
+#include "lt_gemm.h"
+
+namespace lt {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int PL>
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&out)[PL]) {
+  float r0 = x0, r1 = x1;
+#pragma unroll
+  for (int p = 0; p < PL; ++p) {
+    const bf16x2 h = __builtin_convertvector(f32x2{r0, r1}, bf16x2);  // v_cvt_pk_bf16_f32 (RNE)
+    const unsigned u = __builtin_bit_cast(unsigned, h);
+    out[p] = u;
+    if (p + 1 < PL) {
+      r0 -= __builtin_bit_cast(float, u << 16);
+      r1 -= __builtin_bit_cast(float, u & 0xffff0000u);
+    }
+  }
+}
+
+// fp32 [rows][K] -> split planes [rows][K/32][PL][32] bf16.  One thread per 4 consecutive k.
+template <int PL>
+__global__ void split_rows_kernel(const float* __restrict__ W, unsigned char* __restrict__ out, int64_t rows, int K) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int kq = K / 4;
+  if (gid >= rows * kq) return;
+  const int64_t r = gid / kq;
+  const int k = (int)(gid % kq) * 4;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(W + r * K + k);
+  unsigned a[PL], b[PL];
+  split_pair<PL>(v[0], v[1], a);
+  split_pair<PL>(v[2], v[3], b);
+  unsigned char* base = out + (r * (K / 32) + k / 32) * (PL * 64) + (k % 32) * 2;
+#pragma unroll
+  for (int p = 0; p < PL; ++p) *reinterpret_cast<u32x2*>(base + p * 64) = u32x2{a[p], b[p]};
+}
+
+struct SplitGemmArgs {
+  GemmArgs g;                 // g.W unused
+  const unsigned char* Wsp;   // split weights
+  int64_t gWsp;               // bytes between groups
+};
+
+template <int BM, int BN, int WM, int WN, int PL>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs sa) {
+  const GemmArgs& g = sa.g;
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MI = TM / 32, NI = TN / 32;
+  constexpr int RS = PL * 64 + 16;                 // LDS row stride in bytes
+  constexpr int A_F4 = BM * 8 / NT;                // fp32 float4 per thread per A tile
+  constexpr int B_PCS = BN * PL * 4 / NT;          // 16-byte pieces per thread per W tile
+  static_assert(A_F4 >= 1 && B_PCS >= 1 && (BM * 8) % NT == 0 && (BN * PL * 4) % NT == 0, "bad tiling");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+  unsigned char* As = smem_s;                      // [2][BM][RS]
+  unsigned char* Bs = smem_s + 2 * BM * RS;        // [2][BN][RS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int grp = blockIdx.z;
+  const float* A = g.A + grp * g.gA;
+  const float* A2 = g.A2 ? g.A2 + grp * g.gA : nullptr;
+  const unsigned char* Wsp = sa.Wsp + grp * sa.gWsp;
+  const int K1 = g.A2 ? g.K1 : g.K;
+  const int nk = g.K / 32;
+
+  const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
+  f32x4 ra[A_F4];
+  f32x4 rb[B_PCS];
+  auto gload = [&](int kt) {
+    const int k0 = kt * 32;
+    const float* src = A; int ld = g.lda; int kk = k0;
+    if (k0 >= K1) { src = A2; ld = g.lda2; kk = k0 - K1; }
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      int r = m0 + lrow + i * (NT / 8);
+      r = r < g.M ? r : g.M - 1;
+      ra[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)r * ld + kk + lc4);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PCS; ++i) {
+      const int p = tid + i * NT;
+      const int r = p / (PL * 4), pc = p % (PL * 4);
+      rb[i] = *reinterpret_cast<const f32x4*>(Wsp + ((int64_t)(n0 + r) * nk + kt) * (PL * 64) + pc * 16);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      unsigned a[PL], b[PL];
+      split_pair<PL>(ra[i][0], ra[i][1], a);
+      split_pair<PL>(ra[i][2], ra[i][3], b);
+      unsigned char* dst = As + (buf * BM + lrow + i * (NT / 8)) * RS + lc4 * 2;
+#pragma unroll
+      for (int p = 0; p < PL; ++p) *reinterpret_cast<u32x2*>(dst + p * 64) = u32x2{a[p], b[p]};
+    }
+#pragma unroll
+    for (int i = 0; i < B_PCS; ++i) {
+      const int p = tid + i * NT;
+      const int r = p / (PL * 4), pc = p % (PL * 4);
+      *reinterpret_cast<f32x4*>(Bs + (buf * BN + r) * RS + pc * 16) = rb[i];
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int frow = lane & 31, fk = (lane >> 5) * 16;  // byte offset of this lane's 8 bf16 inside a 16-wide K step
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const unsigned char* Ab = As + (buf * BM + wm * TM + frow) * RS + fk;
+    const unsigned char* Bb = Bs + (buf * BN + wn * TN + frow) * RS + fk;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[MI][PL], bf[NI][PL];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int p = 0; p < PL; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * RS + p * 64 + s * 32);
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int p = 0; p < PL; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * RS + p * 64 + s * 32);
+      // smallest cross terms first
+#pragma unroll
+      for (int ord = 2 * (PL - 1); ord >= 0; --ord) {
+        if (ord > PL - 1) continue;  // keep only terms with pa + pb <= PL-1
+#pragma unroll
+        for (int pa = PL - 1; pa >= 0; --pa) {
+          const int pb = ord - pa;
+          if (pb < 0 || pb >= PL) continue;
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], bf[j][pb], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  const float* bias = g.bias ? g.bias + grp * g.gBias : nullptr;
+  float* Y = g.Y + grp * g.gY;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int col = n0 + wn * TN + j * 32 + (lane & 31);
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < g.M) {
+          float v = acc[i][j][r] + bv;
+          if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (g.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+          else if (g.act == ACT_DIST) v = fmaxf(2.f - 2.f * v, 0.f);
+          if (g.R) v += g.R[(int64_t)row * g.ldr + col];
+          Y[(int64_t)row * g.ldy + col] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int PL>
+inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * (BM + BN) * (PL * 64 + 16);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<BM, BN, WM, WN, PL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  dim3 grid(sa.g.N / BN, cdiv(sa.g.M, BM), groups);
+  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL>), grid, dim3(WM * WN * 64), lds, st, sa);
+}
+
+// Tile choice: 8-wave 256x128 blocks (2 waves/SIMD inside one block, half the LDS staging per MFMA) once
+// there are enough of them to occupy most CUs; smaller tiles for small M so the grid still fills the chip.
+inline const char* split_tile_name(const GemmArgs& g, int groups) {
+  if (g.N % 128 != 0) return "128x64";
+  const int64_t t256 = (int64_t)cdiv(g.M, 256) * (g.N / 128) * groups;
+  if (t256 >= 192) return "256x128";
+  const int64_t t128 = (int64_t)cdiv(g.M, 128) * (g.N / 128) * groups;
+  return t128 >= 256 ? "128x128" : "64x128";
+}
+
+template <int PL>
+inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st) {
+  const GemmArgs& g = sa.g;
+  if (g.M <= 0) return 0;
+  if (g.N % 64 != 0 || g.K % 32 != 0 || (g.A2 && g.K1 % 32 != 0))
+    return fail(LINETR_E_ARG, "gemm_split: unsupported shape M=%d N=%d K=%d", g.M, g.N, g.K);
+  static const char* tile_env = getenv("LINETR_GEMM_TILE");  // tuning aid: force a tile
+  const char* tile = tile_env ? tile_env : split_tile_name(g, groups);
+  if (g.N % 128 != 0 || !strcmp(tile, "128x64")) gemm_split_launch_t<128, 64, 4, 1, PL>(sa, groups, st);
+  else if (!strcmp(tile, "256x128")) gemm_split_launch_t<256, 128, 4, 2, PL>(sa, groups, st);
+  else if (!strcmp(tile, "128x256") && g.N % 256 == 0) gemm_split_launch_t<128, 256, 2, 4, PL>(sa, groups, st);
+  else if (!strcmp(tile, "128x128")) gemm_split_launch_t<128, 128, 2, 2, PL>(sa, groups, st);
+  else gemm_split_launch_t<64, 128, 2, 2, PL>(sa, groups, st);
+  LT_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace lt

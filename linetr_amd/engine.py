@@ -308,7 +308,17 @@ class Engine:
                                               ws.numel(), self._stream()))
         return dist, m01
 
-    def debug_gemm(self, A, W, bias=None, residual=None, act=0):
+    PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+
+    def set_precision(self, mode: str):
+        """arithmetic mode of the dense contractions: 'f32' | 'bf16x6' (fp32-faithful, default) | 'bf16x3'."""
+        nat.check(self._L.linetr_set_precision(self._h, self.PRECISIONS[mode]))
+
+    def get_precision(self) -> str:
+        code = self._L.linetr_get_precision(self._h)
+        return {v: k for k, v in self.PRECISIONS.items()}[code]
+
+    def debug_gemm(self, A, W, bias=None, residual=None, act=0, cache_weights=False):
         """Y = act(A @ W.T + bias) (+ residual) on the library's MFMA GEMM (diagnostics / unit tests)."""
         A, W = self._f32(A), self._f32(W)
         M, K = A.shape
@@ -318,7 +328,7 @@ class Engine:
         r = self._f32(residual) if residual is not None else None
         nat.check(self._L.linetr_debug_gemm(self._h, A.data_ptr(), W.data_ptr(), b.data_ptr() if b is not None else None,
                                             r.data_ptr() if r is not None else None, Y.data_ptr(), M, N, K, int(act),
-                                            self._stream()))
+                                            int(cache_weights), self._stream()))
         return Y
 
     # ------------------------------------------------------------------ profiling
