@@ -211,11 +211,12 @@ int linetr_get_precision(const LinetrHandle* h);
 /* Runs the library's fp32-MFMA GEMM  Y[M,N] = act(A[M,K] W[N,K]^T + bias) (+ R)  on device buffers; used
  * by the unit tests (vs a plain PyTorch fp32 reference) and by the kernel micro-benchmarks.  act: 0 none,
  * 1 ReLU, 2 erf-GELU, 3 max(2-2x,0).  d_bias / d_residual may be NULL.  N % 64 == 0, K % 32 == 0.
+ * lda / ldy are the row strides of A and Y (and of the residual) in floats, multiples of 4.
  * cache_weights != 0 keeps the split-bf16 copy of d_W (keyed by pointer) for later calls, so repeated
  * calls time the GEMM kernel alone; the caller then promises not to change the contents of d_W. */
-int linetr_debug_gemm(LinetrHandle* h, const float* d_A, const float* d_W, const float* d_bias,
-                      const float* d_residual, float* d_Y, int32_t M, int32_t N, int32_t K, int32_t act,
-                      int32_t cache_weights, void* stream);
+int linetr_debug_gemm(LinetrHandle* h, const float* d_A, int32_t lda, const float* d_W, const float* d_bias,
+                      const float* d_residual, float* d_Y, int32_t ldy, int32_t M, int32_t N, int32_t K,
+                      int32_t act, int32_t cache_weights, void* stream);
 
 /* ---- instrumentation ------------------------------------------------------------------------ */
 

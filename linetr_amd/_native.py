@@ -54,11 +54,12 @@ def lib():
     # torch ships its own libamdhip64; importing it first makes liblinetr_hip.so bind to the SAME HIP runtime
     # (one context, shared streams and device pointers) instead of a second copy from /opt/rocm.
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("LINETR_LIB", LIB_PATH)   # tuning aid: load an experimental build of the same library
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: the HIP extension has not been built (run `python -m linetr_amd.build`). "
+            f"{path} is missing: the HIP extension has not been built (run `python -m linetr_amd.build`). "
             "linetr_amd has no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i32, i64, f64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_float
     L.linetr_abi_version.restype = i32
     L.linetr_last_error.restype = C.c_char_p
@@ -83,7 +84,7 @@ def lib():
     L.linetr_match_distmat.argtypes = [vp, vp, i32, i32, f32, i32, vp, vp, i64, vp]
     L.linetr_set_precision.argtypes = [vp, i32]
     L.linetr_get_precision.argtypes = [vp]
-    L.linetr_debug_gemm.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.linetr_debug_gemm.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.linetr_set_profiling.argtypes = [vp, i32]
     L.linetr_get_profile.argtypes = [vp, C.POINTER(ProfileEntry), i32, C.POINTER(i32)]
     if L.linetr_abi_version() != 1:

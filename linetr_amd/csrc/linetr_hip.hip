@@ -20,7 +20,7 @@ using namespace lt;
 // =============================================================================================
 
 struct SigLayer {
-  const float *Wqkv, *bqkv, *Wm, *bm, *W1, *b1, *W2, *b2;
+  const float *Wqkv, *bqkv, *W1, *b1, *W2, *b2;  // merge conv folded into W1
 };
 
 struct ProfClass {
@@ -386,10 +386,24 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
         for (int d = 0; d < DH; ++d) Wm2[(size_t)o * D + h * DH + d] = Wm[o * D + d * HEADS + h];
     std::vector<double> W1f, b1f;
     fold_bn(W1, b1, g, be, mu, va, 2 * D, 2 * D, W1f, b1f);
+    // fold the attention's merge conv into the MLP's first layer (both linear, nothing in between):
+    //   W1 [x ; Wm a + bm] + b1 = W1a x + (W1b Wm) a + (W1b bm + b1)            (line_transformer.py:154,:166)
+    std::vector<double> W1m((size_t)2 * D * 2 * D);
+    for (int o = 0; o < 2 * D; ++o) {
+      const double* w1b = &W1f[(size_t)o * 2 * D + D];
+      for (int i = 0; i < D; ++i) W1m[(size_t)o * 2 * D + i] = W1f[(size_t)o * 2 * D + i];
+      for (int i = 0; i < D; ++i) {
+        double sacc = 0.0;
+        for (int m = 0; m < D; ++m) sacc += w1b[m] * Wm2[(size_t)m * D + i];
+        W1m[(size_t)o * 2 * D + D + i] = sacc;
+      }
+      double bacc = b1f[o];
+      for (int m = 0; m < D; ++m) bacc += w1b[m] * (double)bm[m];
+      b1f[o] = bacc;
+    }
     SigLayer& S = H->sig[l];
     place_w(&S.Wqkv, Wqkv, 3 * D, D); place(&S.bqkv, bqkv);
-    place_w(&S.Wm, Wm2, D, D); place(&S.bm, to_d(bm, D));
-    place_w(&S.W1, W1f, 2 * D, 2 * D); place(&S.b1, b1f);
+    place_w(&S.W1, W1m, 2 * D, 2 * D); place(&S.b1, b1f);
     place_w(&S.W2, to_d(W2, (size_t)2 * D * D), D, 2 * D); place(&S.b2, to_d(b2, D));
   }
   {
@@ -780,8 +794,7 @@ extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const in
       hipLaunchKernelGGL(sig_attn_kernel, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
       LT_LAUNCH_CHECK();
     }
-    if ((e = run_gemm(h, st, w.msgp, D, nullptr, 0, 0, S.Wm, S.bm, nullptr, 0, w.msg, D, N, D, D, ACT_NONE))) return e;
-    if ((e = run_gemm(h, st, z, D, w.msg, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ACT_RELU))) return e;
+    if ((e = run_gemm(h, st, z, D, w.msgp, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ACT_RELU))) return e;
     if ((e = run_gemm(h, st, w.hid, 2 * D, nullptr, 0, 0, S.W2, S.b2, z, D, zn, D, N, D, 2 * D, ACT_NONE))) return e;
     std::swap(z, zn);
   }
@@ -911,14 +924,15 @@ extern "C" int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_
   return LINETR_OK;
 }
 
-extern "C" int linetr_debug_gemm(LinetrHandle* h, const float* A, const float* W, const float* bias, const float* R,
-                                 float* Y, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cache_weights,
-                                 void* stream) {
+extern "C" int linetr_debug_gemm(LinetrHandle* h, const float* A, int32_t lda, const float* W, const float* bias,
+                                 const float* R, float* Y, int32_t ldy, int32_t M, int32_t N, int32_t K, int32_t act,
+                                 int32_t cache_weights, void* stream) {
+  if (lda < K || ldy < N || lda % 4 || ldy % 4) return fail(LINETR_E_ARG, "debug_gemm: bad leading dimension");
   if (!h || !A || !W || !Y) return fail(LINETR_E_ARG, "debug_gemm: null argument");
   if (K % 32 || N % 64) return fail(LINETR_E_ARG, "debug_gemm: N %% 64 == 0 and K %% 32 == 0 required");
   LT_HIP(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
-  if (h->precision == LINETR_PREC_F32) return run_gemm(h, st, A, K, nullptr, 0, 0, W, bias, R, N, Y, N, M, N, K, act);
+  if (h->precision == LINETR_PREC_F32) return run_gemm(h, st, A, lda, nullptr, 0, 0, W, bias, R, ldy, Y, ldy, M, N, K, act);
   // caller-provided weights: split them into a scratch buffer (optionally cached by pointer)
   auto it = h->debug_split.find(W);
   unsigned char* buf = it != h->debug_split.end() ? it->second : nullptr;
@@ -934,7 +948,7 @@ extern "C" int linetr_debug_gemm(LinetrHandle* h, const float* A, const float* W
   h->split[W] = {0, (size_t)b2, N, K};
   unsigned char* keep = h->split_arena;
   h->split_arena = buf;  // the lookup inside run_gemm resolves relative to split_arena
-  int e = run_gemm(h, st, A, K, nullptr, 0, 0, W, bias, R, N, Y, N, M, N, K, act);
+  int e = run_gemm(h, st, A, lda, nullptr, 0, 0, W, bias, R, ldy, Y, ldy, M, N, K, act);
   h->split_arena = keep;
   h->split.erase(W);
   if (!cache_weights) {

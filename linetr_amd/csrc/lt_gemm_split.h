@@ -62,7 +62,7 @@ struct SplitGemmArgs {
   int64_t gWsp;               // bytes between groups
 };
 
-template <int BM, int BN, int WM, int WN, int PL>
+template <int BM, int BN, int WM, int WN, int PL, bool DB = true>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs sa) {
   const GemmArgs& g = sa.g;
   constexpr int NT = WM * WN * 64;
@@ -74,13 +74,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
   static_assert(A_F4 >= 1 && B_PCS >= 1 && (BM * 8) % NT == 0 && (BN * PL * 4) % NT == 0, "bad tiling");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
-  unsigned char* As = smem_s;                      // [2][BM][RS]
-  unsigned char* Bs = smem_s + 2 * BM * RS;        // [2][BN][RS]
+  constexpr int NBUF = DB ? 2 : 1;                 // single-buffered variant: less LDS -> more blocks per CU
+  unsigned char* As = smem_s;                      // [NBUF][BM][RS]
+  unsigned char* Bs = smem_s + NBUF * BM * RS;     // [NBUF][BN][RS]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int grp = blockIdx.z;
+  // XCD-aware tile order: hardware places block b on XCD b % 8 (speed assumption only).  Give every XCD a
+  // contiguous run of tiles, column tiles of one row tile adjacent, so the A row tile is fetched into ONE L2.
+  const int gx = g.N / BN, gy = (g.M + BM - 1) / BM;
+  const int ntile = gx * gy;
+  int tile;
+  {
+    const int b = blockIdx.x, q = ntile / 8, r = ntile % 8, xcd = b % 8, k = b / 8;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int m0 = (tile / gx) * BM, n0 = (tile % gx) * BN;
+  const int grp = blockIdx.y;
   const float* A = g.A + grp * g.gA;
   const float* A2 = g.A2 ? g.A2 + grp * g.gA : nullptr;
   const unsigned char* Wsp = sa.Wsp + grp * sa.gWsp;
@@ -135,13 +145,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
 
   gload(0);
   lstore(0);
+  if (nk > 1) gload(1);
   __syncthreads();
   const int frow = lane & 31, fk = (lane >> 5) * 16;  // byte offset of this lane's 8 bf16 inside a 16-wide K step
+  // Main loop.  Registers always hold the NEXT tile, loaded one whole iteration earlier so L2/HBM latency is
+  // covered; it is split and written into the other LDS buffer at the top of the iteration (branch-free).
+  // Measured on MI355X (tools/pmc_gemm.sh): this kernel is bound by the ~10-12 B/clk a CU can pull through its
+  // L1 (TCP_PENDING_STALL 37 %, TA 21 % busy, L2 hit 80 %), not by the split VALU or the LDS writes -- removing
+  // either changes nothing -- so the lever is bytes per MFMA (tile size), not instruction scheduling.
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+    const int buf = DB ? (kt & 1) : 0;
     const unsigned char* Ab = As + (buf * BM + wm * TM + frow) * RS + fk;
     const unsigned char* Bb = Bs + (buf * BN + wn * TN + frow) * RS + fk;
+    if (DB) lstore(buf ^ 1);  // branch-free: on the last iteration this rewrites the idle buffer (never read)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 af[MI][PL], bf[NI][PL];
@@ -169,7 +185,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
         }
       }
     }
-    if (kt + 1 < nk) lstore(buf ^ 1);
+    if (!DB) {
+      __syncthreads();               // everyone done reading the single buffer
+      lstore(0);
+    }
+    if (kt + 2 < nk) gload(kt + 2);
     __syncthreads();
   }
 
@@ -197,17 +217,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
   }
 }
 
-template <int BM, int BN, int WM, int WN, int PL>
+template <int BM, int BN, int WM, int WN, int PL, bool DB = true>
 inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t st) {
-  constexpr size_t lds = (size_t)2 * (BM + BN) * (PL * 64 + 16);
+  constexpr size_t lds = (size_t)(DB ? 2 : 1) * (BM + BN) * (PL * 64 + 16);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<BM, BN, WM, WN, PL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<BM, BN, WM, WN, PL, DB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  dim3 grid(sa.g.N / BN, cdiv(sa.g.M, BM), groups);
-  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL>), grid, dim3(WM * WN * 64), lds, st, sa);
+  dim3 grid((sa.g.N / BN) * cdiv(sa.g.M, BM), groups);
+  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL, DB>), grid, dim3(WM * WN * 64), lds, st, sa);
 }
 
 // Tile choice: 8-wave 256x128 blocks (2 waves/SIMD inside one block, half the LDS staging per MFMA) once
@@ -232,6 +252,8 @@ inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st
   else if (!strcmp(tile, "256x128")) gemm_split_launch_t<256, 128, 4, 2, PL>(sa, groups, st);
   else if (!strcmp(tile, "128x256") && g.N % 256 == 0) gemm_split_launch_t<128, 256, 2, 4, PL>(sa, groups, st);
   else if (!strcmp(tile, "128x128")) gemm_split_launch_t<128, 128, 2, 2, PL>(sa, groups, st);
+  else if (!strcmp(tile, "128x128sb")) gemm_split_launch_t<128, 128, 2, 2, PL, false>(sa, groups, st);
+  else if (!strcmp(tile, "256x128sb")) gemm_split_launch_t<256, 128, 4, 2, PL, false>(sa, groups, st);
   else gemm_split_launch_t<64, 128, 2, 2, PL>(sa, groups, st);
   LT_LAUNCH_CHECK();
   return 0;

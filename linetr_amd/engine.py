@@ -318,17 +318,24 @@ class Engine:
         code = self._L.linetr_get_precision(self._h)
         return {v: k for k, v in self.PRECISIONS.items()}[code]
 
-    def debug_gemm(self, A, W, bias=None, residual=None, act=0, cache_weights=False):
-        """Y = act(A @ W.T + bias) (+ residual) on the library's MFMA GEMM (diagnostics / unit tests)."""
-        A, W = self._f32(A), self._f32(W)
+    def debug_gemm(self, A, W, bias=None, residual=None, act=0, cache_weights=False, out=None):
+        """Y = act(A @ W.T + bias) (+ residual) on the library's MFMA GEMM (diagnostics / unit tests).
+        A / out / residual may be row-strided views (stride(0) multiple of 4, stride(1) == 1)."""
+        W = self._f32(W)
+        if A.dtype != torch.float32 or A.device != self.device or A.stride(1) != 1:
+            A = self._f32(A)
         M, K = A.shape
         N = W.shape[0]
-        Y = torch.empty((M, N), dtype=torch.float32, device=self.device)
+        Y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=self.device)
         b = self._f32(bias) if bias is not None else None
-        r = self._f32(residual) if residual is not None else None
-        nat.check(self._L.linetr_debug_gemm(self._h, A.data_ptr(), W.data_ptr(), b.data_ptr() if b is not None else None,
-                                            r.data_ptr() if r is not None else None, Y.data_ptr(), M, N, K, int(act),
-                                            int(cache_weights), self._stream()))
+        r = residual
+        if r is not None and (r.stride(0) != Y.stride(0) or r.stride(1) != 1):
+            r = self._f32(r) if Y.stride(0) == N else None
+            assert r is not None, "residual must share the output's row stride"
+        nat.check(self._L.linetr_debug_gemm(self._h, A.data_ptr(), A.stride(0), W.data_ptr(),
+                                            b.data_ptr() if b is not None else None,
+                                            r.data_ptr() if r is not None else None, Y.data_ptr(), Y.stride(0), M, N, K,
+                                            int(act), int(cache_weights), self._stream()))
         return Y
 
     # ------------------------------------------------------------------ profiling

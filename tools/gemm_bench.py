@@ -5,15 +5,17 @@ from linetr_amd.engine import Engine
 eng = Engine(synth.make_state_dict(0), 'cuda:0')
 keep=[]
 def bench(M,N,K,reps=20):
-    A = torch.randn(M,K,device='cuda'); W = torch.randn(N,K,device='cuda'); keep.append(W)
+    PAD = int(os.environ.get('PAD','0'))
+    A = torch.randn(M,K+PAD,device='cuda')[:, :K]; W = torch.randn(N,K,device='cuda'); keep.append(W)
+    Ybuf = torch.empty(M,N+PAD,device='cuda')[:, :N]
     ref = (A.double()@W.double().t()).float()
     line = f"M={M:7d} N={N:5d} K={K:5d} "
     for mode in ('f32','bf16x6','bf16x3'):
         eng.set_precision(mode)
-        Y = eng.debug_gemm(A,W,cache_weights=True)
+        Y = eng.debug_gemm(A,W,cache_weights=True,out=Ybuf)
         err = ((Y-ref).abs().max()/ref.abs().max()).item()
         torch.cuda.synchronize(); t0=time.perf_counter()
-        for _ in range(reps): eng.debug_gemm(A,W,cache_weights=True)
+        for _ in range(reps): eng.debug_gemm(A,W,cache_weights=True,out=Ybuf)
         torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/reps
         line += f"| {mode}: {dt*1e6:7.1f} us {2*M*N*K/dt/1e12:6.1f} TF err {err:.1e} "
     t1=time.perf_counter()
