@@ -85,9 +85,7 @@ class Pipeline:
         recs, cu_k, cu_n = e.prefilter(self.cat, self.hw[0], self.hw[1], remove_borders=c["remove_borders"],
                                        min_length=c["min_length"], max_keylines=c["max_keylines"],
                                        token_distance=c["token_distance"], max_tokens=self.T, offsets=self.offsets)
-        tb = e.tokenize(recs, cu_k, cu_n, self.dd, self.ds, token_distance=c["token_distance"], max_tokens=self.T)
-        ld = e.forward(tb)
-        return tb, ld
+        return e.describe(recs, cu_k, cu_n, self.dd, self.ds, token_distance=c["token_distance"], max_tokens=self.T)
 
     def step(self):
         tb, ld = self.describe()

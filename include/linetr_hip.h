@@ -62,7 +62,7 @@ typedef struct {
   int32_t n_sub;       /* ceil(n_tok / max_tokens), models/line_process.py:121                 */
   int32_t image;       /* image index inside the batch                                         */
   int32_t line_local;  /* index of this key-line inside its image                              */
-  int32_t reserved;
+  int32_t first_tok;   /* index of this line's first REAL token in the batch-wide compact list  */
 } LinetrLineRec;       /* 80 bytes */
 
 /* Device outputs of the tokeniser == the tensor entries LineTransformer.preprocess returns
@@ -104,13 +104,13 @@ void linetr_destroy(LinetrHandle* h);
  * max_keylines follows the reference's slice semantics ([:max_keylines], so -1 drops the shortest).
  * Ties in length are ordered by descending original index (== a stable ascending argsort, reversed).
  * Writes up to `capacity` records (first_sub/n_tok/n_sub/image filled as by linetr_pack_lines;
- * `sub_base` = number of sub-lines of the images that precede this one in the batch) and
+ * `sub_base` / `tok_base` = number of sub-lines / real tokens of the images that precede this one in the batch) and
  * returns K' in *k_out, the number of sub-lines of this image in *n_out.  LINETR_E_ASSERT if a token distance
  * exceeds the geometric line length (the reference's AssertionError, line_process.py:44-45). */
 int linetr_prefilter(const double* h_lines6, int32_t K, int32_t height, int32_t width, int32_t border,
                      double min_length, int32_t max_keylines, const double* h_valid_mask,
                      double token_distance, int32_t max_tokens, int32_t image_index, int32_t sub_base,
-                     LinetrLineRec* h_recs, int32_t capacity, int32_t* k_out, int32_t* n_out);
+                     int32_t tok_base, LinetrLineRec* h_recs, int32_t capacity, int32_t* k_out, int32_t* n_out);
 
 /* linetr_prefilter for a whole batch in one call (images processed by up to `n_threads` host threads,
  * 0 = library default).  h_lines6 holds the [K_i,6] blocks of all images back to back, h_line_off [B+1]
@@ -128,7 +128,7 @@ int linetr_prefilter_batch(const double* h_lines6, const int32_t* h_line_off, in
  * h_klines [K,2,2], h_length [K], h_angles [K,2] float64. */
 int linetr_pack_lines(const double* h_klines, const double* h_length, const double* h_angles, int32_t K,
                       double token_distance, int32_t max_tokens, int32_t image_index, int32_t sub_base,
-                      LinetrLineRec* h_recs, int32_t* n_out);
+                      int32_t tok_base, LinetrLineRec* h_recs, int32_t* n_out);
 
 /* ---- device: tokenise ----------------------------------------------------------------------- */
 
@@ -161,6 +161,25 @@ int64_t linetr_forward_workspace_bytes(const LinetrHandle* h, int32_t N, int32_t
 int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const int32_t* h_cu_sub, const int32_t* d_cu_sub,
                    int32_t n_images, int32_t max_tokens, float* d_line_desc, void* d_workspace,
                    int64_t workspace_bytes, void* stream);
+
+/* ---- device: fused tokenise + describe (batched fast path) ---------------------------------------- */
+
+int64_t linetr_describe_workspace_bytes(const LinetrHandle* h, int32_t n_images, int32_t height, int32_t width,
+                                        int32_t N, int64_t n_real_tokens);
+
+/* preprocess + forward of LineTransformer (models/line_transformer.py:251-275 + :225-249) for a batch in one
+ * call, without materialising the [N,T,256] token descriptors: the word-position MLP runs on the REAL tokens
+ * only (n_real_tokens = sum of n_tok over d_recs, plus one shared zero-padding token per image -- every padded
+ * slot of an image holds the same coordinate (0,0), hence the same descriptor, score and key/value), and the
+ * CLS-row attention pooling samples the NHWC descriptor map on the fly, counting the padding token with its
+ * multiplicity.  Results equal linetr_tokenize + linetr_forward up to fp32 rounding.
+ * Small tokeniser outputs (klines, length, angles, sublines, resp, angle_sub) are written when their pointers in
+ * `out` are non-NULL; pnt / mask / score / desc are written only if non-NULL (dense [N,T,...] layout). */
+int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N, int64_t n_real_tokens,
+                    const int32_t* h_cu_sub, const int32_t* d_cu_sub, int32_t n_images, double token_distance,
+                    int32_t max_tokens, const float* d_dense_desc, const float* d_dense_score, int32_t height,
+                    int32_t width, int32_t align_corners, LinetrTokens out, int32_t* d_sub2line,
+                    float* d_line_desc, void* d_workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- device: matcher ------------------------------------------------------------------------ */
 

@@ -24,12 +24,12 @@ class ModelConfig(C.Structure):
 class LineRec(C.Structure):
     _fields_ = [("sp", C.c_double * 2), ("ep", C.c_double * 2), ("length", C.c_double),
                 ("angle", C.c_double * 2), ("first_sub", C.c_int32), ("n_tok", C.c_int32),
-                ("n_sub", C.c_int32), ("image", C.c_int32), ("line_local", C.c_int32), ("reserved", C.c_int32)]
+                ("n_sub", C.c_int32), ("image", C.c_int32), ("line_local", C.c_int32), ("first_tok", C.c_int32)]
 
 
 REC_DTYPE = np.dtype([("sp", "<f8", 2), ("ep", "<f8", 2), ("length", "<f8"), ("angle", "<f8", 2),
                       ("first_sub", "<i4"), ("n_tok", "<i4"), ("n_sub", "<i4"), ("image", "<i4"),
-                      ("line_local", "<i4"), ("reserved", "<i4")])
+                      ("line_local", "<i4"), ("first_tok", "<i4")])
 assert REC_DTYPE.itemsize == C.sizeof(LineRec) == 80
 
 
@@ -67,10 +67,14 @@ def lib():
                                 C.POINTER(vp)]
     L.linetr_destroy.argtypes = [vp]
     L.linetr_destroy.restype = None
-    L.linetr_prefilter.argtypes = [vp, i32, i32, i32, i32, f64, i32, vp, f64, i32, i32, i32, vp, i32, C.POINTER(i32),
+    L.linetr_prefilter.argtypes = [vp, i32, i32, i32, i32, f64, i32, vp, f64, i32, i32, i32, i32, vp, i32, C.POINTER(i32),
                                    C.POINTER(i32)]
     L.linetr_prefilter_batch.argtypes = [vp, vp, i32, i32, i32, i32, f64, i32, vp, f64, i32, i32, vp, i32, vp, vp]
-    L.linetr_pack_lines.argtypes = [vp, vp, vp, i32, f64, i32, i32, i32, vp, C.POINTER(i32)]
+    L.linetr_pack_lines.argtypes = [vp, vp, vp, i32, f64, i32, i32, i32, i32, vp, C.POINTER(i32)]
+    L.linetr_describe_workspace_bytes.argtypes = [vp, i32, i32, i32, i32, i64]
+    L.linetr_describe_workspace_bytes.restype = i64
+    L.linetr_describe.argtypes = [vp, vp, i32, i32, i64, vp, vp, i32, f64, i32, vp, vp, i32, i32, i32, Tokens, vp, vp, vp,
+                                  i64, vp]
     L.linetr_tokenize_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.linetr_tokenize_workspace_bytes.restype = i64
     L.linetr_tokenize.argtypes = [vp, vp, i32, i32, f64, i32, vp, vp, i32, i32, i32, i32, Tokens, vp, vp, i64, vp]
@@ -95,7 +99,7 @@ def lib():
 
 EXPORTS = ["linetr_abi_version", "linetr_last_error", "linetr_create", "linetr_destroy", "linetr_prefilter",
            "linetr_prefilter_batch", "linetr_pack_lines", "linetr_tokenize_workspace_bytes", "linetr_tokenize", "linetr_forward_workspace_bytes",
-           "linetr_forward", "linetr_match_workspace_bytes", "linetr_match", "linetr_match_points",
+           "linetr_forward", "linetr_describe_workspace_bytes", "linetr_describe", "linetr_match_workspace_bytes", "linetr_match", "linetr_match_points",
            "linetr_match_distmat", "linetr_set_precision", "linetr_get_precision", "linetr_debug_gemm", "linetr_set_profiling", "linetr_get_profile"]
 
 

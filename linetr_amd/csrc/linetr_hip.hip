@@ -470,7 +470,7 @@ extern "C" void linetr_destroy(LinetrHandle* h) {
 // host pre-filter
 // =============================================================================================
 
-static int pack_one(LinetrLineRec& r, double td, int T, int image, int line_local, int& sub_cursor) {
+static int pack_one(LinetrLineRec& r, double td, int T, int image, int line_local, int& sub_cursor, int& tok_cursor) {
   if (!(td > 0) || T < 1) return fail(LINETR_E_ARG, "token_distance must be > 0 and max_tokens >= 1");
   const double nt = std::ceil(r.length / td);          // line_process.py:109
   if (!(nt >= 1) || nt > 1e7) return fail(LINETR_E_ARG, "key-line %d has a non-positive / absurd token count", line_local);
@@ -479,8 +479,9 @@ static int pack_one(LinetrLineRec& r, double td, int T, int image, int line_loca
   r.first_sub = sub_cursor;
   r.image = image;
   r.line_local = line_local;
-  r.reserved = 0;
+  r.first_tok = tok_cursor;
   sub_cursor += r.n_sub;
+  tok_cursor += r.n_tok;
   // the reference asserts every walked distance <= geometric length (:44-45)
   if (r.n_tok >= 2) {
     const double dx = r.ep[0] - r.sp[0], dy = r.ep[1] - r.sp[1];
@@ -499,17 +500,17 @@ static void angle_of(LinetrLineRec& r) {  // line_process.py:28-41
 }
 
 extern "C" int linetr_pack_lines(const double* h_klines, const double* h_length, const double* h_angles, int32_t K,
-                                 double td, int32_t T, int32_t image_index, int32_t sub_base,
+                                 double td, int32_t T, int32_t image_index, int32_t sub_base, int32_t tok_base,
                                  LinetrLineRec* h_recs, int32_t* n_out) {
   if (K < 0 || (K > 0 && (!h_klines || !h_length || !h_angles || !h_recs))) return fail(LINETR_E_ARG, "null argument");
-  int cur = sub_base;
+  int cur = sub_base, tcur = tok_base;
   for (int k = 0; k < K; ++k) {
     LinetrLineRec& r = h_recs[k];
     r.sp[0] = h_klines[k * 4 + 0]; r.sp[1] = h_klines[k * 4 + 1];
     r.ep[0] = h_klines[k * 4 + 2]; r.ep[1] = h_klines[k * 4 + 3];
     r.length = h_length[k];
     r.angle[0] = h_angles[k * 2]; r.angle[1] = h_angles[k * 2 + 1];
-    if (int e = pack_one(r, td, T, image_index, k, cur)) return e;
+    if (int e = pack_one(r, td, T, image_index, k, cur, tcur)) return e;
   }
   if (n_out) *n_out = cur - sub_base;
   return LINETR_OK;
@@ -562,16 +563,16 @@ static void prefilter_core(const double* L, int32_t K, int32_t height, int32_t w
 
 extern "C" int linetr_prefilter(const double* L, int32_t K, int32_t height, int32_t width, int32_t border,
                                 double min_length, int32_t max_keylines, const double* vm, double td, int32_t T,
-                                int32_t image_index, int32_t sub_base, LinetrLineRec* h_recs, int32_t capacity,
-                                int32_t* k_out, int32_t* n_out) {
+                                int32_t image_index, int32_t sub_base, int32_t tok_base, LinetrLineRec* h_recs,
+                                int32_t capacity, int32_t* k_out, int32_t* n_out) {
   if (K < 0 || (K > 0 && !L) || !k_out || !n_out) return fail(LINETR_E_ARG, "null argument");
   std::vector<LinetrLineRec> sel;
   prefilter_core(L, K, height, width, border, min_length, max_keylines, vm, sel);
   if ((int64_t)sel.size() > capacity)
     return fail(LINETR_E_CAPACITY, "prefilter: %lld lines exceed capacity %d", (long long)sel.size(), capacity);
-  int cur = sub_base;
+  int cur = sub_base, tcur = tok_base;
   for (size_t i = 0; i < sel.size(); ++i) {
-    if (int e = pack_one(sel[i], td, T, image_index, (int)i, cur)) return e;
+    if (int e = pack_one(sel[i], td, T, image_index, (int)i, cur, tcur)) return e;
     h_recs[i] = sel[i];
   }
   *k_out = (int)sel.size();
@@ -600,13 +601,13 @@ extern "C" int linetr_prefilter_batch(const double* L, const int32_t* off, int32
     for (auto& x : th) x.join();
   }
   cu_k[0] = cu_n[0] = 0;
-  int cur = 0;
+  int cur = 0, tcur = 0;
   int64_t k = 0;
   for (int i = 0; i < B; ++i) {
     if (k + (int64_t)sel[i].size() > capacity)
       return fail(LINETR_E_CAPACITY, "prefilter_batch: more than %d surviving lines", capacity);
     for (size_t j = 0; j < sel[i].size(); ++j) {
-      if (int e = pack_one(sel[i][j], td, T, i, (int)j, cur)) return e;
+      if (int e = pack_one(sel[i][j], td, T, i, (int)j, cur, tcur)) return e;
       h_recs[k++] = sel[i][j];
     }
     cu_k[i + 1] = (int)k;
@@ -650,7 +651,8 @@ extern "C" int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int
   {
     ProfScope ps(h, st, "tokenize", 0, (double)N * T * 16);
     hipLaunchKernelGGL(tokenize_kernel, dim3(N), dim3(64), 0, st, d_recs, s2l_g, N, td, T, height, width,
-                       d_dense_score, out.sublines, out.pnt, out.mask, out.resp, out.angle_sub, out.score);
+                       d_dense_score, out.sublines, out.pnt, out.mask, out.resp, out.angle_sub, out.score, (float*)nullptr,
+                       (float*)nullptr);
     LT_LAUNCH_CHECK();
   }
   if (out.desc) {
@@ -679,11 +681,10 @@ struct FwdWs {
   int* cu;
   int64_t total;
 };
-FwdWs fwd_layout(const LinetrModelConfig& c, int N, int T, int n_images, char* base) {
+FwdWs fwd_layout(const LinetrModelConfig& c, int N, int64_t rows, int n_images, char* base) {
   FwdWs w;
   int64_t off = 0;
   auto take = [&](int64_t floats) { float* p = (float*)(base + off); off += align_up(floats * 4, 256); return p; };
-  const int64_t rows = (int64_t)N * T;
   w.a1 = take(rows * c.enc_channels[0]); w.a2 = take(rows * c.enc_channels[1]);
   w.a3 = take(rows * c.enc_channels[2]); w.a4 = take(rows * c.enc_channels[3]);
   w.pooled = take((int64_t)N * HEADS * POOLW);
@@ -704,35 +705,29 @@ FwdWs fwd_layout(const LinetrModelConfig& c, int N, int T, int n_images, char* b
 extern "C" int64_t linetr_forward_workspace_bytes(const LinetrHandle* h, int32_t N, int32_t T) {
   if (!h) return -1;
   // the image count only sizes a tiny prefix-sum array; reserve for the worst case (every sub-line its own image)
-  return fwd_layout(h->cfg, std::max(N, 1), T, std::max(N, 1), nullptr).total;
+  return fwd_layout(h->cfg, std::max(N, 1), (int64_t)std::max(N, 1) * T, std::max(N, 1), nullptr).total;
 }
 
-extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const int32_t* h_cu, const int32_t* d_cu,
-                              int32_t n_images, int32_t T, float* d_line_desc, void* d_ws, int64_t ws_bytes,
-                              void* stream) {
-  if (!h || !tok || !h_cu || n_images < 1) return fail(LINETR_E_ARG, "forward: null argument");
-  const int N = h_cu[n_images];
-  if (N <= 0) return LINETR_OK;
-  if (!tok->sublines || !tok->pnt || !tok->resp || !tok->angle_sub || !tok->desc || !tok->score || !d_line_desc)
-    return fail(LINETR_E_ARG, "forward: null tensor");
-  int max_n = 0;
-  for (int i = 0; i < n_images; ++i) {
-    if (h_cu[i + 1] < h_cu[i]) return fail(LINETR_E_ARG, "forward: cu_sub not monotone");
-    max_n = std::max(max_n, h_cu[i + 1] - h_cu[i]);
-  }
-  if (h_cu[0] != 0) return fail(LINETR_E_ARG, "forward: cu_sub[0] != 0");
-  if (ws_bytes < linetr_forward_workspace_bytes(h, N, T)) return fail(LINETR_E_WORKSPACE, "forward: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
-  LT_HIP(hipSetDevice(h->device));
+namespace {
+struct TokenStage {            // how the token stage (word MLP + CLS pooling) is fed
+  // dense path (linetr_forward): [N,T] tensors of the reference
+  const float *pnt = nullptr, *score = nullptr, *desc = nullptr;
+  // fused path (linetr_describe): compact real-token list + NHWC map
+  const float *cpnt = nullptr, *cscore = nullptr, *nhwc = nullptr;
+  const LinetrLineRec* recs = nullptr;
+  const int* sub2line_g = nullptr;
+  int64_t rows = 0;            // rows of the word-MLP GEMMs (N*T dense, n_real + n_images fused)
+  int64_t first_pad = 0;
+  int Hc = 0, Wc = 0, align_corners = 0;
+};
+
+int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const float* sublines, const float* resp,
+                 const float* angle_sub, const int32_t* h_cu, const int* cu_dev, int n_images, int N, int T,
+                 float* d_line_desc, FwdWs& w) {
   const LinetrModelConfig& c = h->cfg;
-  FwdWs w = fwd_layout(c, N, T, std::max(N, 1), (char*)d_ws);
-  const int* cu_dev = d_cu;
-  if (!cu_dev) {
-    LT_HIP(hipMemcpyAsync(w.cu, h_cu, (n_images + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-    cu_dev = w.cu;
-  }
-  const int64_t rows = (int64_t)N * T;
-  if (rows > INT32_MAX / 2) return fail(LINETR_E_ARG, "forward: batch too large");
+  int max_n = 0;
+  for (int i = 0; i < n_images; ++i) max_n = std::max(max_n, h_cu[i + 1] - h_cu[i]);
+  const int64_t rows = ts.rows;
   const int e0 = c.enc_channels[0], e1 = c.enc_channels[1], e2 = c.enc_channels[2], e3 = c.enc_channels[3];
   const float cx = c.norm_width / 2.f, cy = c.norm_height / 2.f;           // line_transformer.py:30-32
   const float scale = (float)std::max(c.norm_width, c.norm_height) * 0.7f;
@@ -740,17 +735,27 @@ extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const in
   // ---- word positional encoder up to the last ReLU (a4); its final linear layer is applied after pooling
   {
     ProfScope ps(h, st, "mlp_first", 2.0 * rows * 3 * e0, (double)rows * (12 + 4 * e0));
-    hipLaunchKernelGGL(word_mlp1_kernel, dim3((unsigned)cdiv((int)(rows * 8), 256)), dim3(256), 0, st, tok->pnt,
-                       tok->score, rows, cx, cy, scale, h->wW1, h->wb1, w.a1);
+    hipLaunchKernelGGL(word_mlp1_kernel, dim3((unsigned)cdiv((int)(rows * 8), 256)), dim3(256), 0, st,
+                       ts.cpnt ? ts.cpnt : ts.pnt, ts.cpnt ? ts.cscore : ts.score, rows, cx, cy, scale, h->wW1, h->wb1, w.a1);
     LT_LAUNCH_CHECK();
   }
   if ((e = run_gemm(h, st, w.a1, e0, nullptr, 0, 0, h->wW2, h->wb2, nullptr, 0, w.a2, e1, (int)rows, e1, e0, ACT_RELU))) return e;
   if ((e = run_gemm(h, st, w.a2, e1, nullptr, 0, 0, h->wW3, h->wb3, nullptr, 0, w.a3, e2, (int)rows, e2, e1, ACT_RELU))) return e;
   if ((e = run_gemm(h, st, w.a3, e2, nullptr, 0, 0, h->wW4, h->wb4, nullptr, 0, w.a4, e3, (int)rows, e3, e2, ACT_RELU))) return e;
   // ---- CLS-row attention pooling + value/last-MLP projection
-  {
+  if (ts.cpnt) {
+    ProfScope ps(h, st, "cls_pool_fused", 2.0 * rows * (2.0 * HEADS * D * 2), (double)rows * D * 4 * 5);
+    const size_t lds = ((size_t)(T + 1) * D + HEADS * (T + 2)) * sizeof(float);
+    if (lds > 160 * 1024) return fail(LINETR_E_ARG, "describe: max_tokens too large for the fused pooling kernel");
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cls_pool_fused_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(cls_pool_fused_kernel, dim3(N), dim3(256), lds, st, ts.recs, ts.sub2line_g, ts.cpnt, w.a4,
+                       ts.first_pad, T, ts.nhwc, ts.Hc, ts.Wc, ts.align_corners, h->pool, w.pooled);
+    LT_LAUNCH_CHECK();
+  } else {
     ProfScope ps(h, st, "cls_pool", 2.0 * rows * (2.0 * HEADS * D * 2), (double)rows * D * 8);
-    hipLaunchKernelGGL(cls_pool_kernel, dim3(N), dim3(256), HEADS * (T + 1) * sizeof(float), st, tok->desc, w.a4, T,
+    hipLaunchKernelGGL(cls_pool_kernel, dim3(N), dim3(256), HEADS * (T + 1) * sizeof(float), st, ts.desc, w.a4, T,
                        h->pool, w.pooled);
     LT_LAUNCH_CHECK();
   }
@@ -768,8 +773,8 @@ extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const in
   // ---- line positional encoder
   {
     ProfScope ps(h, st, "mlp_first", 2.0 * N * 5 * e0, (double)N * (28 + 4 * e0));
-    hipLaunchKernelGGL(line_mlp1_kernel, dim3(cdiv(N * 8, 256)), dim3(256), 0, st, tok->sublines, tok->resp,
-                       tok->angle_sub, N, cx, cy, scale, h->lW1, h->lb1, w.l1);
+    hipLaunchKernelGGL(line_mlp1_kernel, dim3(cdiv(N * 8, 256)), dim3(256), 0, st, sublines, resp, angle_sub, N, cx, cy,
+                       scale, h->lW1, h->lb1, w.l1);
     LT_LAUNCH_CHECK();
   }
   if ((e = run_gemm(h, st, w.l1, e0, nullptr, 0, 0, h->lW2, h->lb2, nullptr, 0, w.l2, e1, N, e1, e0, ACT_RELU))) return e;
@@ -806,6 +811,134 @@ extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const in
     LT_LAUNCH_CHECK();
   }
   return LINETR_OK;
+}
+
+int check_cu(const int32_t* h_cu, int n_images) {
+  if (!h_cu || n_images < 1) return fail(LINETR_E_ARG, "null / empty cu_sub");
+  if (h_cu[0] != 0) return fail(LINETR_E_ARG, "cu_sub[0] != 0");
+  for (int i = 0; i < n_images; ++i)
+    if (h_cu[i + 1] < h_cu[i]) return fail(LINETR_E_ARG, "cu_sub not monotone");
+  return 0;
+}
+}  // namespace
+
+extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const int32_t* h_cu, const int32_t* d_cu,
+                              int32_t n_images, int32_t T, float* d_line_desc, void* d_ws, int64_t ws_bytes,
+                              void* stream) {
+  if (!h || !tok) return fail(LINETR_E_ARG, "forward: null argument");
+  if (int e = check_cu(h_cu, n_images)) return e;
+  const int N = h_cu[n_images];
+  if (N <= 0) return LINETR_OK;
+  if (!tok->sublines || !tok->pnt || !tok->resp || !tok->angle_sub || !tok->desc || !tok->score || !d_line_desc)
+    return fail(LINETR_E_ARG, "forward: null tensor");
+  if (ws_bytes < linetr_forward_workspace_bytes(h, N, T)) return fail(LINETR_E_WORKSPACE, "forward: workspace too small");
+  if ((int64_t)N * T > INT32_MAX / 8) return fail(LINETR_E_ARG, "forward: batch too large");
+  hipStream_t st = (hipStream_t)stream;
+  LT_HIP(hipSetDevice(h->device));
+  FwdWs w = fwd_layout(h->cfg, N, (int64_t)N * T, std::max(N, 1), (char*)d_ws);
+  const int* cu_dev = d_cu;
+  if (!cu_dev) {
+    LT_HIP(hipMemcpyAsync(w.cu, h_cu, (n_images + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    cu_dev = w.cu;
+  }
+  TokenStage ts;
+  ts.pnt = tok->pnt; ts.score = tok->score; ts.desc = tok->desc; ts.rows = (int64_t)N * T;
+  return forward_core(h, st, ts, tok->sublines, tok->resp, tok->angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);
+}
+
+// =============================================================================================
+// fused tokenise + describe
+// =============================================================================================
+
+namespace {
+struct DescWs { float *nhwc, *cpnt, *cscore, *sublines, *resp, *angle_sub; int* s2l_g; int64_t fwd_off, total; };
+DescWs desc_layout(int n_images, int height, int width, int N, int64_t rows, char* base) {
+  DescWs d;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { char* p = base + off; off += align_up(bytes, 256); return p; };
+  const int64_t P = (int64_t)(height / 8) * (width / 8);
+  d.nhwc = (float*)take(n_images * P * D * 4);
+  d.cpnt = (float*)take(rows * 8);
+  d.cscore = (float*)take(rows * 4);
+  d.sublines = (float*)take((int64_t)N * 16);
+  d.resp = (float*)take((int64_t)N * 4);
+  d.angle_sub = (float*)take((int64_t)N * 8);
+  d.s2l_g = (int*)take((int64_t)N * 4);
+  d.fwd_off = off;
+  d.total = off;
+  return d;
+}
+}  // namespace
+
+extern "C" int64_t linetr_describe_workspace_bytes(const LinetrHandle* h, int32_t n_images, int32_t height, int32_t width,
+                                                   int32_t N, int64_t n_real) {
+  if (!h) return -1;
+  const int64_t rows = n_real + n_images;
+  return desc_layout(n_images, height, width, std::max(N, 1), rows, nullptr).total +
+         fwd_layout(h->cfg, std::max(N, 1), rows, n_images, nullptr).total;
+}
+
+extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N, int64_t n_real,
+                               const int32_t* h_cu, const int32_t* d_cu, int32_t n_images, double td, int32_t T,
+                               const float* d_dense_desc, const float* d_dense_score, int32_t height, int32_t width,
+                               int32_t align_corners, LinetrTokens out, int32_t* d_sub2line, float* d_line_desc,
+                               void* d_ws, int64_t ws_bytes, void* stream) {
+  if (!h) return fail(LINETR_E_ARG, "describe: null handle");
+  if (int e = check_cu(h_cu, n_images)) return e;
+  if (h_cu[n_images] != N) return fail(LINETR_E_ARG, "describe: cu_sub does not end at N");
+  if (K <= 0 || N <= 0) return LINETR_OK;
+  if (!d_recs || !d_dense_desc || !d_dense_score || !d_line_desc || !d_ws) return fail(LINETR_E_ARG, "describe: null pointer");
+  if (T < 1 || T > 4096 || height % 8 || width % 8) return fail(LINETR_E_ARG, "describe: bad max_tokens / image size");
+  if (n_real < N || n_real > (int64_t)N * T) return fail(LINETR_E_ARG, "describe: implausible real-token count");
+  if (ws_bytes < linetr_describe_workspace_bytes(h, n_images, height, width, N, n_real))
+    return fail(LINETR_E_WORKSPACE, "describe: workspace too small");
+  const int64_t rows = n_real + n_images;
+  if (rows > INT32_MAX / 8) return fail(LINETR_E_ARG, "describe: batch too large");
+  hipStream_t st = (hipStream_t)stream;
+  LT_HIP(hipSetDevice(h->device));
+  DescWs dw = desc_layout(n_images, height, width, N, rows, (char*)d_ws);
+  FwdWs w = fwd_layout(h->cfg, N, rows, n_images, (char*)d_ws + dw.fwd_off);
+  const int Hc = height / 8, Wc = width / 8, P = Hc * Wc;
+  const int* cu_dev = d_cu;
+  if (!cu_dev) {
+    LT_HIP(hipMemcpyAsync(w.cu, h_cu, (n_images + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    cu_dev = w.cu;
+  }
+  float* sublines = out.sublines ? out.sublines : dw.sublines;
+  float* resp = out.resp ? out.resp : dw.resp;
+  float* angle_sub = out.angle_sub ? out.angle_sub : dw.angle_sub;
+  {
+    ProfScope ps(h, st, "line_fill", 0, (double)K * 80 + (double)N * 8);
+    hipLaunchKernelGGL(line_fill_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, d_recs, K, (double)width - 0.6,
+                       (double)height - 0.6, out.klines, out.length, out.angles, dw.s2l_g, d_sub2line);
+    LT_LAUNCH_CHECK();
+  }
+  {
+    ProfScope ps(h, st, "tokenize", 0, (double)n_real * 16);
+    hipLaunchKernelGGL(tokenize_kernel, dim3(N), dim3(64), 0, st, d_recs, dw.s2l_g, N, td, T, height, width,
+                       d_dense_score, sublines, out.pnt, out.mask, resp, angle_sub, out.score, dw.cpnt, dw.cscore);
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv(n_images, 256)), dim3(256), 0, st, d_dense_score, n_images, height,
+                       width, dw.cpnt, dw.cscore, n_real);
+    LT_LAUNCH_CHECK();
+  }
+  {
+    ProfScope ps(h, st, "nchw_to_nhwc", 0, 2.0 * n_images * P * D * 4);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(P, 32), D / 32, n_images), dim3(32, 8), 0, st, d_dense_desc,
+                       dw.nhwc, D, P);
+    LT_LAUNCH_CHECK();
+  }
+  if (out.desc) {  // the reference's dense tensor was asked for as well
+    if (!out.pnt) return fail(LINETR_E_ARG, "describe: out.desc requires out.pnt");
+    const int64_t ntok = (int64_t)N * T;
+    ProfScope ps(h, st, "sample_desc", 0, (double)ntok * D * 4 * 2);
+    hipLaunchKernelGGL(sample_desc_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, st, out.pnt, dw.s2l_g, d_recs,
+                       ntok, T, dw.nhwc, Hc, Wc, align_corners, out.desc);
+    LT_LAUNCH_CHECK();
+  }
+  TokenStage ts;
+  ts.cpnt = dw.cpnt; ts.cscore = dw.cscore; ts.nhwc = dw.nhwc; ts.recs = d_recs; ts.sub2line_g = dw.s2l_g;
+  ts.rows = rows; ts.first_pad = n_real; ts.Hc = Hc; ts.Wc = Wc; ts.align_corners = align_corners;
+  return forward_core(h, st, ts, sublines, resp, angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);
 }
 
 // =============================================================================================

@@ -1,6 +1,7 @@
 // Non-GEMM device stages of LineTransformer.forward (models/line_transformer.py:225-249).
 #pragma once
 #include "lt_common.h"
+#include "lt_token.h"
 
 namespace lt {
 
@@ -131,6 +132,94 @@ __global__ __launch_bounds__(256) void cls_pool_kernel(const float* __restrict__
   if (tid < 4 * 32) {
     const int h = tid >> 5, i = tid & 31;
     out[h * POOLW + 512 + i] = i == 0 ? sm[h * S] : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused variant for the batched fast path (linetr_describe): same mathematics as cls_pool_kernel, but
+//   * token descriptors are sampled from the NHWC map on the fly (sample_one) and kept in LDS -- the
+//     [N,T,256] tensor of the reference is never materialised;
+//   * only REAL tokens are visited; every zero-padding slot of an image holds the same coordinate (0,0)
+//     (models/line_process.py:133-139), i.e. identical descriptor / a4 row / score, so the padding slots
+//     enter the softmax as ONE key with multiplicity n_pad.
+// a4 / cpnt are indexed by the compact token list (rec.first_tok), the image's padding token sits at
+// first_pad + image.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cls_pool_fused_kernel(
+    const LinetrLineRec* __restrict__ recs, const int* __restrict__ sub2line_g, const float* __restrict__ cpnt,
+    const float* __restrict__ a4, int64_t first_pad, int T, const float* __restrict__ nhwc, int Hc, int Wc,
+    int align_corners, ClsPoolConst cc, float* __restrict__ pooled /*[N][4][544]*/) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* descs = sm;                       // [(T+1)][256]
+  float* sc = sm + (T + 1) * D;            // [4][T+2]   scores -> weights
+  const int SS = T + 2;
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const LinetrLineRec r = recs[sub2line_g[n]];
+  const int j = n - r.first_sub;
+  const int n_valid = min(T, r.n_tok - j * T);
+  const int n_pad = T - n_valid;
+  const int ntk = n_valid + (n_pad > 0 ? 1 : 0);
+  const int64_t tok0 = (int64_t)r.first_tok + (int64_t)j * T;
+  const int64_t padrow = first_pad + r.image;
+  const float* nhwc_img = nhwc + (int64_t)r.image * Hc * Wc * D;
+  f32x4 u[4], u2[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    u[h] = *reinterpret_cast<const f32x4*>(cc.U + h * D + lane * 4);
+    u2[h] = *reinterpret_cast<const f32x4*>(cc.U2 + h * D + lane * 4);
+  }
+  for (int jj = wave; jj < ntk; jj += 4) {
+    const int64_t row = jj < n_valid ? tok0 + jj : padrow;
+    const f32x4 dv = sample_one(cpnt[row * 2], cpnt[row * 2 + 1], nhwc_img, Hc, Wc, align_corners, lane);
+    *reinterpret_cast<f32x4*>(descs + jj * D + lane * 4) = dv;
+    const f32x4 av = *reinterpret_cast<const f32x4*>(a4 + row * D + lane * 4);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      float p = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) p += dv[c] * u[h][c] + av[c] * u2[h][c];
+      p = wave_sum(p);
+      if (lane == 0) sc[h * SS + 1 + jj] = p + cc.c_tok[h];
+    }
+  }
+  if (tid < 4) sc[tid * SS] = cc.s_cls[tid];
+  __syncthreads();
+  if (tid < 4) {  // softmax over CLS + n_valid real keys + (padding key x n_pad)
+    float* s = sc + tid * SS;
+    float mx = s[0];
+    for (int i = 1; i <= ntk; ++i) mx = fmaxf(mx, s[i]);
+    float sum = 0.f;
+    for (int i = 0; i <= ntk; ++i) {
+      s[i] = expf(s[i] - mx);
+      sum += (i == n_valid + 1) ? s[i] * (float)n_pad : s[i];
+    }
+    for (int i = 0; i <= ntk; ++i) {
+      const float p = s[i] / sum;
+      s[i] = (i == n_valid + 1) ? p * (float)n_pad : p;
+    }
+  }
+  __syncthreads();
+  float db[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int jj = 0; jj < ntk; ++jj) {
+    const int64_t row = jj < n_valid ? tok0 + jj : padrow;
+    const float dv = descs[jj * D + tid], av = a4[row * D + tid];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const float p = sc[h * SS + 1 + jj];
+      db[h] += p * dv;
+      ab[h] += p * av;
+    }
+  }
+  float* out = pooled + (int64_t)n * 4 * POOLW;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    out[h * POOLW + tid] = db[h];
+    out[h * POOLW + 256 + tid] = ab[h];
+  }
+  if (tid < 4 * 32) {
+    const int h = tid >> 5, i = tid & 31;
+    out[h * POOLW + 512 + i] = i == 0 ? sc[h * SS] : 0.f;
   }
 }
 

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(64) void tokenize_kernel(
     const LinetrLineRec* __restrict__ recs, const int* __restrict__ sub2line_g, int N, double td, int T,
     int height, int width, const float* __restrict__ dense_score, float* __restrict__ sublines,
     float* __restrict__ pnt, float* __restrict__ mask, float* __restrict__ resp,
-    float* __restrict__ angle_sub, float* __restrict__ score) {
+    float* __restrict__ angle_sub, float* __restrict__ score, float* __restrict__ cpnt,
+    float* __restrict__ cscore) {
 #pragma clang fp contract(off)
   const int n = blockIdx.x;
   if (n >= N) return;
@@ -100,19 +101,25 @@ __global__ __launch_bounds__(64) void tokenize_kernel(
     }
     const float fx = (float)x, fy = (float)y;          // :157 .float()
     const int64_t o = (int64_t)n * T + t;
-    pnt[o * 2 + 0] = fx;
-    pnt[o * 2 + 1] = fy;
-    mask[(int64_t)n * (T + 1) + 1 + t] = mk;
+    if (pnt) { pnt[o * 2 + 0] = fx; pnt[o * 2 + 1] = fy; }
+    if (mask) mask[(int64_t)n * (T + 1) + 1 + t] = mk;
     // score gather :174-179 -- torch.round (half to even), clip to the map, index [y][x]
     int ix = (int)rintf(fx), iy = (int)rintf(fy);
     ix = ix < width - 1 ? ix : width - 1;
     iy = iy < height - 1 ? iy : height - 1;
     ix = ix < 0 ? 0 : ix;   // negative coordinates cannot occur after remove_borders; guard the load anyway
     iy = iy < 0 ? 0 : iy;
-    score[o] = dense_score[(int64_t)r.image * height * width + (int64_t)iy * width + ix];
+    const float sc = dense_score[(int64_t)r.image * height * width + (int64_t)iy * width + ix];
+    if (score) score[o] = sc;
+    if (cpnt && mk != 0.f) {  // compact list of real tokens (fused path)
+      const int64_t c = (int64_t)r.first_tok + ti;
+      cpnt[c * 2 + 0] = fx;
+      cpnt[c * 2 + 1] = fy;
+      cscore[c] = sc;
+    }
   }
   if (threadIdx.x == 0) {
-    mask[(int64_t)n * (T + 1)] = 1.f;  // CLS slot :135
+    if (mask) mask[(int64_t)n * (T + 1)] = 1.f;  // CLS slot :135
     double s[2], e[2];
     if (j == 0) { s[0] = r.sp[0]; s[1] = r.sp[1]; }
     else walk_along(r.sp, r.ep, (double)(j * T - 1) * td, s[0], s[1]);        // :125-128
@@ -135,17 +142,10 @@ __global__ __launch_bounds__(64) void tokenize_kernel(
 // descriptor map + L2 normalisation.  One wave64 per token, lane = 4 channels (dwordx4, coalesced
 // 1 KiB per tap).  fp32 arithmetic in the order PyTorch's CPU grid_sampler uses.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sample_desc_kernel(
-    const float* __restrict__ pnt, const int* __restrict__ sub2line_g, const LinetrLineRec* __restrict__ recs,
-    int64_t n_tokens, int T, const float* __restrict__ nhwc, int Hc, int Wc, int align_corners,
-    float* __restrict__ desc) {
+// bilinear sample (zero padding) + L2 normalisation of one token; every lane of the wave returns its 4 channels
+__device__ __forceinline__ f32x4 sample_one(float px, float py, const float* __restrict__ nhwc_img, int Hc, int Wc,
+                                            int align_corners, int lane) {
 #pragma clang fp contract(off)
-  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tok >= n_tokens) return;
-  const int lane = threadIdx.x & 63;
-  const int n = (int)(tok / T);
-  const int img = recs[sub2line_g[n]].image;
-  const float px = pnt[tok * 2 + 0], py = pnt[tok * 2 + 1];
   const float s = 8.f;
   // keypoints - s/2 + 0.5 ; /= (w*s - s/2 - 0.5) ; *2 - 1          (:88-92)
   float gx = ((px - s / 2) + 0.5f) / ((float)Wc * s - s / 2 - 0.5f);
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(
   const float w = ix - x_w, e = 1.f - w, nn = iy - y_n, ss = 1.f - nn;
   const float nw = ss * e, ne = ss * w, sw = nn * e, se = nn * w;
   const int x0 = (int)x_w, y0 = (int)y_n, x1 = x0 + 1, y1 = y0 + 1;
-  const float* base = nhwc + (int64_t)img * Hc * Wc * D + lane * 4;
+  const float* base = nhwc_img + lane * 4;
   auto tap = [&](int yy, int xx) -> f32x4 {
     if (xx < 0 || xx >= Wc || yy < 0 || yy >= Hc) return f32x4{0.f, 0.f, 0.f, 0.f};
     return *reinterpret_cast<const f32x4*>(base + ((int64_t)yy * Wc + xx) * D);
@@ -185,7 +185,31 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(
   const float nrm = fmaxf(sqrtf(sq), 1e-12f);  // F.normalize eps
 #pragma unroll
   for (int c = 0; c < 4; ++c) o[c] = o[c] / nrm;
+  return o;
+}
+
+__global__ __launch_bounds__(256) void sample_desc_kernel(
+    const float* __restrict__ pnt, const int* __restrict__ sub2line_g, const LinetrLineRec* __restrict__ recs,
+    int64_t n_tokens, int T, const float* __restrict__ nhwc, int Hc, int Wc, int align_corners,
+    float* __restrict__ desc) {
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= n_tokens) return;
+  const int lane = threadIdx.x & 63;
+  const int n = (int)(tok / T);
+  const int img = recs[sub2line_g[n]].image;
+  const f32x4 o = sample_one(pnt[tok * 2 + 0], pnt[tok * 2 + 1], nhwc + (int64_t)img * Hc * Wc * D, Hc, Wc,
+                             align_corners, lane);
   *reinterpret_cast<f32x4*>(desc + tok * D + lane * 4) = o;
+}
+
+// one shared padding token per image for the compact token list: coordinate (0,0), score dense_score[img][0][0]
+__global__ void pad_rows_kernel(const float* __restrict__ dense_score, int n_images, int height, int width,
+                                float* __restrict__ cpnt, float* __restrict__ cscore, int64_t first_pad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_images) return;
+  cpnt[(first_pad + i) * 2 + 0] = 0.f;
+  cpnt[(first_pad + i) * 2 + 1] = 0.f;
+  cscore[first_pad + i] = dense_score[(int64_t)i * height * width];
 }
 
 }  // namespace lt

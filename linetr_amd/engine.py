@@ -186,7 +186,7 @@ class Engine:
         ln = np.ascontiguousarray(length, dtype=np.float64)
         an = np.ascontiguousarray(angles, dtype=np.float64)
         nat.check(self._L.linetr_pack_lines(nat.np_ptr(kl), nat.np_ptr(ln), nat.np_ptr(an), K, float(token_distance),
-                                            int(max_tokens), int(image), int(sub_base), nat.np_ptr(recs), C.byref(n_out)))
+                                            int(max_tokens), int(image), int(sub_base), 0, nat.np_ptr(recs), C.byref(n_out)))
         return recs[:K], n_out.value
 
     # ------------------------------------------------------------------ device stages
@@ -240,6 +240,71 @@ class Engine:
                                           ct, tb.sub2line.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         tb.extra["d_recs"] = d_recs  # keep alive until the stream has consumed it
         return tb
+
+    def describe(self, recs, cu_k, cu_n, dense_desc, dense_score, *, token_distance, max_tokens, align_corners=False,
+                 want_tokens=False):
+        """Fused tokenise + descriptor network for a batch (linetr_describe): real tokens only, descriptors sampled
+        on the fly.  Returns (TokenBatch, line_desc [N,256]).  With want_tokens=False the dense [N,T,...] token
+        tensors (pnt / mask / score / desc) are not materialised (zero-sized in the TokenBatch)."""
+        B = len(cu_k) - 1
+        K, N, T = int(cu_k[-1]), int(cu_n[-1]), int(max_tokens)
+        dense_desc = self._f32(dense_desc)
+        dense_score = self._f32(dense_score)
+        if dense_score.dim() == 2:
+            dense_score = dense_score[None]
+        if dense_desc.dim() == 3:
+            dense_desc = dense_desc[None]
+        if dense_desc.shape[0] != B or dense_score.shape[0] != B:
+            raise ValueError("dense maps must have one entry per image")
+        H, W = int(dense_score.shape[-2]), int(dense_score.shape[-1])
+        if dense_desc.shape[1] != D or dense_desc.shape[2] * 8 != H or dense_desc.shape[3] * 8 != W:
+            raise ValueError(f"dense_descriptor shape {tuple(dense_desc.shape)} does not match dense_score {H}x{W}")
+        dev = self.device
+        f = dict(dtype=torch.float32, device=dev)
+        z = torch.empty((0,), **f)
+        tb = TokenBatch(
+            n_images=B, max_tokens=T, cu_k=np.asarray(cu_k, np.int32), cu_n=np.asarray(cu_n, np.int32), recs=recs,
+            klines=torch.empty((K, 2, 2), **f), length=torch.empty((K,), **f), angles=torch.empty((K, 2), **f),
+            sublines=torch.empty((N, 2, 2), **f), pnt=torch.empty((N, T, 2), **f) if want_tokens else z,
+            mask=torch.empty((N, T + 1), **f) if want_tokens else z, resp=torch.empty((N,), **f),
+            angle_sub=torch.empty((N, 2), **f), desc=torch.empty((N, T, D), **f) if want_tokens else z,
+            score=torch.empty((N, T), **f) if want_tokens else z,
+            sub2line=torch.empty((N,), dtype=torch.int32, device=dev))
+        ld = torch.empty((N, D), **f)
+        if K == 0 or N == 0:
+            return tb, ld
+        n_real = int(recs["n_tok"][:K].sum())
+        d_recs, d_cu = self._upload_recs(recs, K, B, tb)
+        ct = tb.c_tokens()
+        if not want_tokens:
+            ct.pnt = ct.mask = ct.desc = ct.score = None
+        nbytes = self._L.linetr_describe_workspace_bytes(self._h, B, H, W, N, n_real)
+        ws = self._workspace("desc", nbytes)
+        cu = np.ascontiguousarray(cu_n, dtype=np.int32)
+        nat.check(self._L.linetr_describe(self._h, d_recs.data_ptr(), K, N, n_real, nat.np_ptr(cu),
+                                          d_cu.data_ptr() if d_cu is not None else None, B, float(token_distance), T,
+                                          dense_desc.data_ptr(), dense_score.data_ptr(), H, W, int(bool(align_corners)),
+                                          ct, tb.sub2line.data_ptr(), ld.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          self._stream()))
+        return tb, ld
+
+    def _upload_recs(self, recs, K, B, tb):
+        """H2D of the line records (+ the sub-line prefix sums when they sit in the same pinned blob)."""
+        dev = self.device
+        last = getattr(self, "_last_host", None)
+        if last is not None and K > 0 and recs.ctypes.data == last["recs_ptr"] and last["B"] == B:
+            nb = last["rec_bytes"] + 8 * (B + 1)
+            d_blob = torch.empty(nb, dtype=torch.uint8, device=dev)
+            d_blob.copy_(last["slot"]["buf"][:nb], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            last["slot"]["event"] = ev
+            d_cu = d_blob[last["rec_bytes"] + 4 * (B + 1):].view(torch.int32)
+            tb.extra["d_recs"], tb.extra["d_cu_n"] = d_blob, d_cu
+            return d_blob, d_cu
+        d_recs = torch.from_numpy(recs.view(np.uint8).reshape(-1)).to(dev)
+        tb.extra["d_recs"] = d_recs
+        return d_recs, None
 
     def forward_tensors(self, sublines, pnt, resp, angle_sub, desc, score, cu_n, out=None, d_cu_n=None) -> torch.Tensor:
         """LineTransformer.forward on flat tensors; returns line_desc [N,256] (row-major)."""

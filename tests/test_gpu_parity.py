@@ -175,3 +175,61 @@ def test_batch_vs_oracle_random(engine):
         assert out["line_desc"].shape[2] == n1 - n0
         assert np.array_equal(tb.pnt[n0:n1].cpu().numpy(), out["pnt_sublines"][0].numpy())
         assert np.abs(ld[n0:n1].T - out["line_desc"][0].numpy()).max() < DESC_TOL
+
+
+def run_fused(eng, rows_list, dd, ds, hw, cfg, align_corners=False, want_tokens=False):
+    recs, cu_k, cu_n = eng.prefilter(rows_list, hw[0], hw[1], remove_borders=cfg["remove_borders"],
+                                     min_length=cfg["min_length"], max_keylines=cfg["max_keylines"],
+                                     token_distance=cfg["token_distance"], max_tokens=cfg["max_tokens"])
+    tb, ld = eng.describe(recs, cu_k, cu_n, dd, ds, token_distance=cfg["token_distance"], max_tokens=cfg["max_tokens"],
+                          align_corners=align_corners, want_tokens=want_tokens)
+    torch.cuda.synchronize()
+    return tb, ld
+
+
+def test_fused_describe_matches_golden_and_dense_path(engine):
+    """linetr_describe (real tokens only, on-the-fly sampling, padding key with multiplicity) vs the reference
+    fixtures and vs the dense linetr_tokenize + linetr_forward path."""
+    g = load("cfg2_pair")
+    hw = (480, 640)
+    maps = [synth.synth_dense_maps(int(g[f"{t}_seed"]), *hw) for t in "ab"]
+    dd = torch.cat([m[0] for m in maps]).cuda()
+    ds = torch.cat([m[1] for m in maps]).cuda()
+    rows = [g["a_lines"], g["b_lines"]]
+    tb, ld = run_fused(engine, rows, dd, ds, hw, BASE_CFG, want_tokens=True)
+    tb_d, ld_d = run_native(engine, rows, dd, ds, hw, BASE_CFG)
+    for i, t in enumerate("ab"):
+        check_tokens(tb, g, prefix=f"{t}_", img=i)
+        n0, n1 = tb.cu_n[i], tb.cu_n[i + 1]
+        assert np.abs(ld[n0:n1].cpu().numpy().T - g[f"{t}_line_desc"][0]).max() < DESC_TOL
+    assert torch.equal(tb.desc, tb_d.desc) and torch.equal(tb.pnt, tb_d.pnt)
+    assert (ld - ld_d).abs().max().item() < 5e-6
+    tb2, ld2 = run_fused(engine, rows, dd, ds, hw, BASE_CFG, want_tokens=False)      # lean variant
+    assert torch.equal(ld2, ld) and tb2.desc.numel() == 0
+    assert torch.equal(tb2.sublines, tb.sublines) and torch.equal(tb2.sub2line, tb.sub2line)
+
+
+@pytest.mark.parametrize("name", ["tiny_default", "tiny_float_td", "tiny_align_true", "tiny_noborder"])
+def test_fused_describe_tiny(engine, name):
+    g = load(name)
+    dd, ds, hw = tiny_maps(g)
+    tb, ld = run_fused(engine, [g["lines"].copy()], dd.cuda(), ds.cuda(), hw, golden_cfg(g), bool(g["align_corners"]))
+    assert np.abs(ld.cpu().numpy().T - g["line_desc"][0]).max() < DESC_TOL
+    assert np.array_equal(tb.sublines.cpu().numpy(), g["sublines"][0])
+
+
+def test_fused_describe_long_tokens_and_ragged_batch():
+    from linetr_amd.engine import Engine
+    g = load("cfg5_small")
+    dd, ds, hw = tiny_maps(g)
+    eng = Engine(weights_for(g), "cuda:0", image_shape=list(hw))
+    cfg = dict(BASE_CFG, max_tokens=int(g["max_tokens"]))
+    tb, ld = run_fused(eng, [g["lines"]], dd.cuda(), ds.cuda(), hw, cfg)
+    assert np.abs(ld.cpu().numpy().T - g["line_desc"][0]).max() < DESC_TOL
+    # ragged batch incl. an image whose only line is dropped by max_keylines=-1 (zero sub-lines)
+    rows = [g["lines"][:50], g["lines"][:1], g["lines"][60:]]
+    dd3, ds3 = torch.cat([dd] * 3).cuda(), torch.cat([ds] * 3).cuda()
+    tb3, ld3 = run_fused(eng, rows, dd3, ds3, hw, cfg)
+    tbd, ldd = run_native(eng, rows, dd3, ds3, hw, cfg)
+    assert list(np.diff(tb3.cu_n))[1] == 0
+    assert (ld3 - ldd).abs().max().item() < 5e-6

@@ -33,7 +33,7 @@ def prefilter(rows, hw, cfg, vm=None):
     rows = np.ascontiguousarray(rows, np.float64)
     code = L.linetr_prefilter(nat.np_ptr(rows), len(rows), hw[0], hw[1], cfg["remove_borders"], float(cfg["min_length"]),
                               cfg["max_keylines"], nat.np_ptr(vm) if vm is not None else None,
-                              float(cfg["token_distance"]), cfg["max_tokens"], 0, 0, nat.np_ptr(recs), len(recs),
+                              float(cfg["token_distance"]), cfg["max_tokens"], 0, 0, 0, nat.np_ptr(recs), len(recs),
                               C.byref(k), C.byref(n))
     nat.check(code)
     return recs[:k.value], n.value
@@ -60,6 +60,7 @@ def test_prefilter_matches_oracle_random(seed):
     assert np.array_equal(recs["n_sub"], -(-ntok // 21))
     assert n == recs["n_sub"].sum()
     assert np.array_equal(recs["first_sub"], np.cumsum(recs["n_sub"]) - recs["n_sub"])
+    assert np.array_equal(recs["first_tok"], np.cumsum(recs["n_tok"]) - recs["n_tok"])
 
 
 @pytest.mark.parametrize("name", ["tiny_default", "tiny_max3", "tiny_noborder", "tiny_float_td"])
@@ -101,7 +102,7 @@ def test_pack_lines_matches_prefilter():
     kl = np.ascontiguousarray(np.stack([recs["sp"], recs["ep"]], 1))
     n2 = C.c_int32()
     nat.check(L.linetr_pack_lines(nat.np_ptr(kl), nat.np_ptr(np.ascontiguousarray(recs["length"])),
-                                  nat.np_ptr(np.ascontiguousarray(recs["angle"])), len(recs), 8.0, 21, 0, 0,
+                                  nat.np_ptr(np.ascontiguousarray(recs["angle"])), len(recs), 8.0, 21, 0, 0, 0,
                                   nat.np_ptr(out), C.byref(n2)))
     assert n2.value == n
     for f in nat.REC_DTYPE.names:
