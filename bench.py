@@ -69,9 +69,10 @@ def make_inputs(workload, pairs, rank, device):
 
 
 class Pipeline:
-    def __init__(self, eng, lines, dd, ds, hw, T, world, pairs):
+    def __init__(self, eng, lines, dd, ds, hw, T, world, pairs, n_streams=1):
         self.eng, self.lines, self.dd, self.ds, self.hw, self.T = eng, lines, dd, ds, hw, T
         self.world, self.pairs = world, pairs
+        self.n_streams = n_streams
         self.n_img_cap = 2 * pairs
         self.rows_cap = sum(len(l) for l in lines)
         self.packed = None
@@ -82,10 +83,9 @@ class Pipeline:
 
     def describe(self):
         e, c = self.eng, LINE_CFG
-        recs, cu_k, cu_n = e.prefilter(self.cat, self.hw[0], self.hw[1], remove_borders=c["remove_borders"],
-                                       min_length=c["min_length"], max_keylines=c["max_keylines"],
-                                       token_distance=c["token_distance"], max_tokens=self.T, offsets=self.offsets)
-        return e.describe(recs, cu_k, cu_n, self.dd, self.ds, token_distance=c["token_distance"], max_tokens=self.T)
+        return e.describe_lines(self.cat, self.offsets, self.dd, self.ds, remove_borders=c["remove_borders"],
+                                min_length=c["min_length"], max_keylines=c["max_keylines"],
+                                token_distance=c["token_distance"], max_tokens=self.T, n_streams=self.n_streams)
 
     def step(self):
         tb, ld = self.describe()
@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="image pairs per GPU per step (default: workload's)")
     ap.add_argument("--precision", default="bf16x6", choices=["f32", "bf16x6", "bf16x3"],
                     help="MFMA path of the dense contractions (bf16x6 = fp32-faithful split, the default)")
+    ap.add_argument("--streams", type=int, default=1, help="independent sub-batches run on this many HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -184,7 +185,7 @@ def main():
     eng = Engine(synth.calibrated_state_dict(), device, image_shape=[H, W])
     eng.set_precision(args.precision)
     lines, dd, ds, hw, T = make_inputs(args.workload, pairs, rank, device)
-    pipe = Pipeline(eng, lines, dd, ds, hw, T, world, pairs)
+    pipe = Pipeline(eng, lines, dd, ds, hw, T, world, pairs, args.streams)
 
     def barrier():
         torch.cuda.synchronize()

@@ -254,6 +254,7 @@ inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st
   else if (!strcmp(tile, "128x128")) gemm_split_launch_t<128, 128, 2, 2, PL>(sa, groups, st);
   else if (!strcmp(tile, "128x128sb")) gemm_split_launch_t<128, 128, 2, 2, PL, false>(sa, groups, st);
   else if (!strcmp(tile, "256x128sb")) gemm_split_launch_t<256, 128, 4, 2, PL, false>(sa, groups, st);
+  else if (!strcmp(tile, "256x256") && g.N % 256 == 0) gemm_split_launch_t<256, 256, 4, 2, PL, false>(sa, groups, st);
   else gemm_split_launch_t<64, 128, 2, 2, PL>(sa, groups, st);
   LT_LAUNCH_CHECK();
   return 0;
