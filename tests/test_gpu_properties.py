@@ -1,0 +1,122 @@
+"""GPU: size-independent properties of the hot path at BASELINE.json's FULL sizes (cfg3: 64 pairs x 200 lines,
+cfg5: 1280x960 / 600 lines / 41 tokens), where the CPU oracle would take minutes:
+
+  * batch invariance      -- an image described inside a 128-image batch == the same image described alone
+  * permutation equivariance of the line-signature attention -- re-ordering the detector output of an image
+    leaves every line's descriptor unchanged (lines are re-sorted by length, so equal output order)
+  * unit-norm descriptors, finite outputs, Dk in [0, 4]
+  * matching a batch against a jittered, permuted copy of itself recovers the permutation (>= 97 %)
+  * precision modes: bf16x6 (default) == exact-fp32 MFMA to fp32 round-off; bf16x3 within 5e-5
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import BASE_CFG
+from linetr_amd import synth
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+HW = (480, 640)
+CFG = dict(remove_borders=8, min_length=16, max_keylines=-1, token_distance=8, max_tokens=21)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from linetr_amd.engine import Engine
+    return Engine(synth.calibrated_state_dict(), "cuda:0")
+
+
+def batch_inputs(n_img, seed0=7000, n_lines=200, hw=HW, lo=17.0, hi=167.0):
+    lines = [synth.synth_lines(seed0 + i, n_lines, hw[0], hw[1], lo, hi) for i in range(n_img)]
+    maps = [synth.synth_dense_maps(seed0 + i, *hw) for i in range(n_img)]
+    dd = torch.cat([m[0] for m in maps]).cuda()
+    ds = torch.cat([m[1] for m in maps]).cuda()
+    off = np.concatenate([[0], np.cumsum([len(l) for l in lines])]).astype(np.int32)
+    return lines, np.concatenate(lines), off, dd, ds
+
+
+def describe(eng, cat, off, dd, ds, cfg=CFG):
+    tb, ld = eng.describe_lines(cat, off, dd, ds, **cfg)
+    torch.cuda.synchronize()
+    return tb, ld
+
+
+def test_cfg3_batch_invariance_and_norms(eng):
+    lines, cat, off, dd, ds = batch_inputs(128)
+    tb, ld = describe(eng, cat, off, dd, ds)
+    assert tb.N == 128 * 199 and torch.isfinite(ld).all()
+    assert (ld.norm(dim=1) - 1).abs().max().item() < 1e-5
+    for i in (0, 57, 127):                         # same image alone: identical up to fp32 round-off
+        tb1, ld1 = describe(eng, lines[i], np.array([0, len(lines[i])], np.int32), dd[i:i + 1], ds[i:i + 1])
+        n0, n1 = tb.cu_n[i], tb.cu_n[i + 1]
+        assert torch.equal(tb1.sublines, tb.sublines[n0:n1])
+        assert (ld1 - ld[n0:n1]).abs().max().item() < 2e-6
+
+
+def test_permutation_equivariance(eng):
+    lines, cat, off, dd, ds = batch_inputs(4, seed0=7100)
+    tb, ld = describe(eng, cat, off, dd, ds)
+    rs = np.random.RandomState(3)
+    shuffled = [l[rs.permutation(len(l))] for l in lines]
+    tb2, ld2 = describe(eng, np.concatenate(shuffled), off, dd, ds)
+    assert torch.equal(tb.klines, tb2.klines)      # the length sort makes the output order canonical
+    assert (ld - ld2).abs().max().item() < 2e-6
+
+
+def test_cfg3_matching_recovers_jittered_permutation(eng):
+    n_pairs = 64
+    lines0 = [synth.synth_lines(7300 + i, 200, *HW) for i in range(n_pairs)]
+    jit = [synth.jitter_pair(l, 7400 + i, 0.3) for i, l in enumerate(lines0)]
+    maps = [synth.synth_dense_maps(7300 + i, *HW) for i in range(n_pairs)]
+    dd = torch.cat([m[0] for m in maps]).cuda()
+    ds = torch.cat([m[1] for m in maps]).cuda()
+    off = np.arange(n_pairs + 1, dtype=np.int32) * 200
+    tb0, ld0 = describe(eng, np.concatenate(lines0), off, dd, ds)
+    tb1, ld1 = describe(eng, np.concatenate([j[0] for j in jit]), off, dd, ds)
+    dk, off_dk, m01 = eng.match(ld0, tb0.cu_n, tb0.sub2line, tb0.cu_k, ld1, tb1.cu_n, tb1.sub2line, tb1.cu_k, 0.8, True)
+    dkc = dk.cpu()
+    assert dkc.min().item() >= 0 and dkc.max().item() <= 4.0 + 1e-5
+    m = m01.cpu().numpy()
+    k0, k1 = tb0.klines.cpu().numpy(), tb1.klines.cpu().numpy()
+    good = total = 0
+    for p in range(n_pairs):
+        a0, a1 = tb0.cu_k[p], tb0.cu_k[p + 1]
+        b0 = tb1.cu_k[p]
+        mm = m[a0:a1]
+        idx = np.nonzero(mm >= 0)[0]
+        d = np.abs(k0[a0:a1][idx] - k1[b0 + mm[idx]]).reshape(len(idx), -1).max(1)
+        d2 = np.abs(k0[a0:a1][idx] - k1[b0 + mm[idx]][:, ::-1]).reshape(len(idx), -1).max(1)
+        good += int((np.minimum(d, d2) < 2.0).sum())
+        total += a1 - a0
+    assert good / total > 0.97, (good, total)
+
+
+def test_cfg5_full_size_long_lines():
+    from linetr_amd.engine import Engine
+    hw = (960, 1280)
+    eng5 = Engine(synth.calibrated_state_dict(), "cuda:0", image_shape=list(hw))
+    cfg = dict(CFG, max_tokens=41)
+    lines, cat, off, dd, ds = batch_inputs(4, seed0=7500, n_lines=600, hw=hw, lo=40.0, hi=327.0)
+    tb, ld = describe(eng5, cat, off, dd, ds, cfg)
+    assert tb.N == 4 * 599 and torch.isfinite(ld).all()
+    assert (ld.norm(dim=1) - 1).abs().max().item() < 1e-5
+    tb1, ld1 = describe(eng5, lines[2], np.array([0, 600], np.int32), dd[2:3], ds[2:3], cfg)
+    assert (ld1 - ld[tb.cu_n[2]:tb.cu_n[3]]).abs().max().item() < 2e-6
+    # fused path == dense reference-layout path at full size
+    recs, cu_k, cu_n = eng5.prefilter(cat, hw[0], hw[1], offsets=off, **cfg)
+    tbd = eng5.tokenize(recs, cu_k, cu_n, dd, ds, token_distance=8, max_tokens=41)
+    ldd = eng5.forward(tbd)
+    assert (ld - ldd).abs().max().item() < 5e-6
+    assert tbd.mask.sum().item() == tbd.N + int(recs["n_tok"].sum())     # tokeniser invariant: 1 CLS + real tokens
+
+
+def test_precision_modes_agree(eng):
+    lines, cat, off, dd, ds = batch_inputs(8, seed0=7600)
+    out = {}
+    for mode in ("f32", "bf16x6", "bf16x3"):
+        eng.set_precision(mode)
+        out[mode] = describe(eng, cat, off, dd, ds)[1].clone()
+    eng.set_precision("bf16x6")
+    assert (out["bf16x6"] - out["f32"]).abs().max().item() < 3e-6      # fp32-faithful
+    assert (out["bf16x3"] - out["f32"]).abs().max().item() < 5e-5      # inside the 1e-4 budget
