@@ -151,6 +151,50 @@ def cpu_baseline(workload, budget_s=12.0, max_pairs=16):
     }
 
 
+PMC_KERNEL_NAMES = {   # profile class -> kernel symbol in profiles/r01_pmc_traffic.json (rocprofv3 --pmc run)
+    "gemm_bf16x6_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 3, true>(lt::SplitGemmArgs)",
+    "gemm_bf16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true>(lt::SplitGemmArgs)",
+    "gemm_f32_128x128": "void lt::gemm_kernel<128, 128, 2, 2>(lt::GemmArgs)",
+}
+
+
+def pmc_traffic(kernel_class):
+    """HBM-side bytes per launch of `kernel_class` from the committed rocprofv3 PMC pass (FETCH_SIZE/WRITE_SIZE in
+    KiB, separate --pmc runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads
+    on gfx950).  None if no PMC data is committed for this kernel."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    name = PMC_KERNEL_NAMES.get(kernel_class)
+    if not name or not os.path.exists(path):
+        return None
+    rec = json.load(open(path)).get(name)
+    if not rec or "FETCH_SIZE_KiB_avg" not in rec or "WRITE_SIZE_KiB_avg" not in rec:
+        return None
+    return (2.0 * rec["FETCH_SIZE_KiB_avg"] + rec["WRITE_SIZE_KiB_avg"]) * 1024.0
+
+
+def roofline_of(dom, prof_steps, tot_ms, precision):
+    """roofline object of the dominant kernel (largest summed HIP-event time over the profiled steps)."""
+    common = {"kernel": dom["name"], "avg_launch_us": round(dom["ms"] / dom["calls"] * 1e3, 2),
+              "launches_per_step": dom["calls"] // prof_steps, "share_of_gpu_time": round(dom["ms"] / tot_ms, 3)}
+    traffic = pmc_traffic(dom["name"])
+    if dom["flops"] > 0:
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12      # algorithmic fp32 flops (2*M*N*K of each launch) / time
+        r = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+             "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["calls"]),
+             "peak_note": "157.3 TF = dense fp32 matrix peak (the contract of the kernel is fp32 in / fp32 out)"}
+        if "bf16x" in dom["name"]:
+            terms = 6 if "bf16x6" in dom["name"] else 3
+            r.update({"mfma_flops_per_algorithmic_flop": terms,
+                      "bf16_pipe_frac": round(ach * terms / 2500.0, 4),
+                      "pipe_note": f"each fp32 product = {terms} bf16 MFMA products; {terms}*achieved / 2.5 PF dense bf16 peak"})
+    else:
+        ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic}
+    return {**common, **r}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,18 +292,7 @@ def main():
     prof.sort(key=lambda e: -e["ms"])
     dom = prof[0]
     tot_ms = sum(e["ms"] for e in prof)
-    if dom["flops"] > 0:
-        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "avg_launch_us": round(dom["ms"] / dom["calls"] * 1e3, 2), "launches_per_step": dom["calls"] // prof_steps,
-                    "share_of_gpu_time": round(dom["ms"] / tot_ms, 3)}
-    else:
-        ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-        roofline = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                    "avg_launch_us": round(dom["ms"] / dom["calls"] * 1e3, 2), "launches_per_step": dom["calls"] // prof_steps,
-                    "share_of_gpu_time": round(dom["ms"] / tot_ms, 3)}
+    roofline = roofline_of(dom, prof_steps, tot_ms, args.precision)
     n_img = 2 * pairs
     alg_flops_step = sum(algorithmic_flops_per_image(int(n), T) for n in np.diff(tb.cu_n))
     breakdown = {e["name"]: {"calls": e["calls"] // prof_steps, "ms": round(e["ms"] / prof_steps, 4),
