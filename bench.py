@@ -183,7 +183,7 @@ def roofline_of(dom, prof_steps, tot_ms, precision):
              "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
              "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["calls"]),
              "peak_note": "157.3 TF = dense fp32 matrix peak (the contract of the kernel is fp32 in / fp32 out)"}
-        if "bf16x" in dom["name"]:
+        if "bf16x" in dom["name"] or "f16x3" in dom["name"]:
             terms = 6 if "bf16x6" in dom["name"] else 3
             r.update({"mfma_flops_per_algorithmic_flop": terms,
                       "bf16_pipe_frac": round(ach * terms / 2500.0, 4),
@@ -202,10 +202,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="image pairs per GPU per step (default: workload's)")
-    ap.add_argument("--precision", default="bf16x6", choices=["f32", "bf16x6", "bf16x3"],
+    ap.add_argument("--precision", default="bf16x6", choices=["f32", "bf16x6", "bf16x3", "f16x3"],
                     help="MFMA path of the dense contractions (bf16x6 = fp32-faithful split, the default)")
     ap.add_argument("--streams", type=int, default=1, help="independent sub-batches run on this many HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-precisions", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -304,7 +305,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"f32": "f32 (v_mfma_f32_32x32x2_f32)", "bf16x6": "f32 in/out; GEMMs as 6 bf16-split MFMA products, fp32 accumulate (fp32-faithful)",
-                  "bf16x3": "f32 in/out; GEMMs as 3 bf16-split MFMA products, fp32 accumulate (~1e-5)"}[args.precision],
+                  "bf16x3": "f32 in/out; GEMMs as 3 bf16-split MFMA products, fp32 accumulate (~1e-5)",
+                  "f16x3": "f32 in/out; GEMMs as 3 fp16-split MFMA products, fp32 accumulate (~1e-6)"}[args.precision],
         "precision": args.precision, "data": "synthetic",
         "config": {"workload": f"{args.workload}: {pairs} pairs/GPU of {W}x{H}, {n_lines} lines/image -> "
                                f"{int(tb.N / n_img)} sub-lines x {T} tokens, d_model=256, seeded weights",
@@ -316,6 +318,22 @@ def main():
         "gpu_ms_per_step_profiled": round(tot_ms / prof_steps, 3),
         "roofline": roofline, "kernels": breakdown,
     }
+    if not args.no_alt_precisions:   # the same step in the other MFMA modes (few steps each), for reference
+        alt = {}
+        for mode in ("f32", "bf16x6", "f16x3", "bf16x3"):
+            if mode == args.precision:
+                continue
+            eng.set_precision(mode)
+            for _ in range(2):
+                pipe.step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                tb_a, _ld, _g = pipe.step()
+            barrier()
+            alt[mode] = round(tb_a.N * 5 / (time.perf_counter() - t0) * world, 1)
+        eng.set_precision(args.precision)
+        out["alt_precisions_desc_per_s"] = alt
     if rank == 0 and not args.no_cpu_baseline:
         cb = cpu_baseline(args.workload, args.cpu_budget)
         out["cpu_baseline"] = {k: (round(v, 1) if isinstance(v, float) else v) for k, v in cb.items()}

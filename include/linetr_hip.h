@@ -219,9 +219,12 @@ int linetr_match_points(LinetrHandle* h, const float* d_desc0_cn, int32_t n0, co
  *   LINETR_PREC_BF16X6  operands split into 3 bf16 planes, 6 cross products: fp32-faithful (~2^-23 per
  *                       product, same class as fp32 summation-order noise)          (417 TF-equivalent)
  *   LINETR_PREC_BF16X3  2 planes, 3 cross products: ~1e-5 relative per product      (833 TF-equivalent)
- * Default: LINETR_PREC_BF16X6, overridable with the environment variable LINETR_PRECISION=f32|bf16x6|bf16x3
+ *   LINETR_PREC_F16X3   2 fp16 planes (22 significand bits), 3 cross products: ~2^-22 per product, i.e. fp32-class
+ *                       (measured 1.1e-6 on the descriptors vs 4.4e-7 for BF16X6), but every GEMM operand must
+ *                       stay below 65504 in magnitude (fp16 range)                  (833 TF-equivalent)
+ * Default: LINETR_PREC_BF16X6, overridable with the environment variable LINETR_PRECISION=f32|bf16x6|bf16x3|f16x3
  * at linetr_create time.  The signature attention and every non-GEMM stage are fp32 in all modes. */
-enum { LINETR_PREC_F32 = 0, LINETR_PREC_BF16X3 = 1, LINETR_PREC_BF16X6 = 2 };
+enum { LINETR_PREC_F32 = 0, LINETR_PREC_BF16X3 = 1, LINETR_PREC_BF16X6 = 2, LINETR_PREC_F16X3 = 3 };
 int linetr_set_precision(LinetrHandle* h, int32_t mode);
 int linetr_get_precision(const LinetrHandle* h);
 

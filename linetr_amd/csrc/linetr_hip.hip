@@ -45,7 +45,7 @@ struct LinetrHandle {
   // split-bf16 copies of every GEMM weight (2 and 3 planes), keyed by the fp32 pointer
   int precision = LINETR_PREC_BF16X6;
   unsigned char* split_arena = nullptr;
-  struct SplitW { size_t off2, off3; int64_t rows; int K; };
+  struct SplitW { size_t off2, off3; int64_t rows; int K; size_t offh = 0; };  // bf16x2 planes, bf16x3 planes, fp16x2 planes
   std::map<const float*, SplitW> split;
   std::map<const float*, unsigned char*> debug_split;  // linetr_debug_gemm(cache_weights=1)
   // profiling
@@ -144,6 +144,12 @@ int run_gemm(LinetrHandle* h, hipStream_t st, const float* A, int lda, const flo
     sa.gWsp = gW * 4;
     ProfScope ps(h, st, gemm_class_name(g, groups, "gemm_bf16x3"), fl, by);
     return gemm_split_launch<2>(sa, groups, st);
+  }
+  if (h->precision == LINETR_PREC_F16X3) {
+    sa.Wsp = h->split_arena + it->second.offh;
+    sa.gWsp = gW * 4;
+    ProfScope ps(h, st, gemm_class_name(g, groups, "gemm_f16x3"), fl, by);
+    return gemm_split_launch<2, 1>(sa, groups, st);
   }
   sa.Wsp = h->split_arena + it->second.off3;
   sa.gWsp = gW * 6;
@@ -425,6 +431,7 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
       sw.rows = w.rows; sw.K = w.K;
       sw.off2 = total; total += align_up(w.rows * w.K * 4, 256);
       sw.off3 = total; total += align_up(w.rows * w.K * 6, 256);
+      sw.offh = total; total += align_up(w.rows * w.K * 4, 256);
       H->split[*w.dst] = sw;
     }
     LT_HIP(hipMalloc((void**)&H->split_arena, total));
@@ -434,6 +441,8 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
                          H->split_arena + kv.second.off2, kv.second.rows, kv.second.K);
       hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, 0, kv.first,
                          H->split_arena + kv.second.off3, kv.second.rows, kv.second.K);
+      hipLaunchKernelGGL((split_rows_kernel<2, 1>), dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, 0, kv.first,
+                         H->split_arena + kv.second.offh, kv.second.rows, kv.second.K);
     }
     LT_LAUNCH_CHECK();
     LT_HIP(hipDeviceSynchronize());
@@ -442,14 +451,15 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
     if (!strcmp(e, "f32")) H->precision = LINETR_PREC_F32;
     else if (!strcmp(e, "bf16x3")) H->precision = LINETR_PREC_BF16X3;
     else if (!strcmp(e, "bf16x6")) H->precision = LINETR_PREC_BF16X6;
-    else return fail(LINETR_E_ARG, "LINETR_PRECISION must be f32, bf16x3 or bf16x6 (got '%s')", e);
+    else if (!strcmp(e, "f16x3")) H->precision = LINETR_PREC_F16X3;
+    else return fail(LINETR_E_ARG, "LINETR_PRECISION must be f32, bf16x3, bf16x6 or f16x3 (got '%s')", e);
   }
   *out = H.release();
   return LINETR_OK;
 }
 
 extern "C" int linetr_set_precision(LinetrHandle* h, int32_t mode) {
-  if (!h || mode < LINETR_PREC_F32 || mode > LINETR_PREC_BF16X6) return fail(LINETR_E_ARG, "bad precision mode");
+  if (!h || mode < LINETR_PREC_F32 || mode > LINETR_PREC_F16X3) return fail(LINETR_E_ARG, "bad precision mode");
   h->precision = mode;
   return LINETR_OK;
 }
@@ -795,8 +805,15 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     {
       double fl = 0;
       for (int i = 0; i < n_images; ++i) { double n = h_cu[i + 1] - h_cu[i]; fl += 2.0 * 2.0 * n * n * D; }
-      ProfScope ps(h, st, "sig_attn", fl, (double)N * D * 16);
-      hipLaunchKernelGGL(sig_attn_kernel, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
+      // exact-fp32 MFMA attention in f32 mode, fp32-faithful split-bf16 (6 products) otherwise
+      static const bool force_f32_attn = getenv("LINETR_ATTN_F32") != nullptr;
+      if (h->precision == LINETR_PREC_F32 || force_f32_attn) {
+        ProfScope ps(h, st, "sig_attn", fl, (double)N * D * 16);
+        hipLaunchKernelGGL(sig_attn_kernel, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
+      } else {
+        ProfScope ps(h, st, "sig_attn_bf16x6", fl, (double)N * D * 16);
+        hipLaunchKernelGGL(sig_attn_split_kernel, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
+      }
       LT_LAUNCH_CHECK();
     }
     if ((e = run_gemm(h, st, z, D, w.msgp, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ACT_RELU))) return e;
@@ -1069,16 +1086,17 @@ extern "C" int linetr_debug_gemm(LinetrHandle* h, const float* A, int32_t lda, c
   // caller-provided weights: split them into a scratch buffer (optionally cached by pointer)
   auto it = h->debug_split.find(W);
   unsigned char* buf = it != h->debug_split.end() ? it->second : nullptr;
-  const int64_t b2 = align_up((int64_t)N * K * 4, 256);
+  const int64_t b2 = align_up((int64_t)N * K * 4, 256), b3 = align_up((int64_t)N * K * 6, 256);
   if (!buf) {
-    LT_HIP(hipMalloc((void**)&buf, b2 + (int64_t)N * K * 6));
+    LT_HIP(hipMalloc((void**)&buf, b2 + b3 + b2));
     const int64_t n4 = (int64_t)N * K / 4;
     hipLaunchKernelGGL(split_rows_kernel<2>, dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, st, W, buf, (int64_t)N, K);
     hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, st, W, buf + b2, (int64_t)N, K);
+    hipLaunchKernelGGL((split_rows_kernel<2, 1>), dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, st, W, buf + b2 + b3, (int64_t)N, K);
     LT_LAUNCH_CHECK();
     if (cache_weights) h->debug_split[W] = buf;
   }
-  h->split[W] = {0, (size_t)b2, N, K};
+  h->split[W] = {0, (size_t)b2, N, K, (size_t)(b2 + b3)};
   unsigned char* keep = h->split_arena;
   h->split_arena = buf;  // the lookup inside run_gemm resolves relative to split_arena
   int e = run_gemm(h, st, A, lda, nullptr, 0, 0, W, bias, R, ldy, Y, ldy, M, N, K, act);

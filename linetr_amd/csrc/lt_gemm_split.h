@@ -24,23 +24,46 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <int PL>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// FMT 0: bf16 planes (fp32 exponent range, 8-bit significand each)
+// FMT 1: fp16 planes (11-bit significand each: 2 planes carry 22 bits -> 3 products give ~2^-22 per product, but
+//        operands must stay below 65504 in magnitude; small remainders fall into fp16 subnormals, which only costs
+//        absolute accuracy below 3e-8)
+template <int PL, int FMT = 0>
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&out)[PL]) {
   float r0 = x0, r1 = x1;
 #pragma unroll
   for (int p = 0; p < PL; ++p) {
-    const bf16x2 h = __builtin_convertvector(f32x2{r0, r1}, bf16x2);  // v_cvt_pk_bf16_f32 (RNE)
-    const unsigned u = __builtin_bit_cast(unsigned, h);
-    out[p] = u;
-    if (p + 1 < PL) {
-      r0 -= __builtin_bit_cast(float, u << 16);
-      r1 -= __builtin_bit_cast(float, u & 0xffff0000u);
+    if constexpr (FMT == 0) {
+      const bf16x2 h = __builtin_convertvector(f32x2{r0, r1}, bf16x2);  // v_cvt_pk_bf16_f32 (RNE)
+      const unsigned u = __builtin_bit_cast(unsigned, h);
+      out[p] = u;
+      if (p + 1 < PL) {
+        r0 -= __builtin_bit_cast(float, u << 16);
+        r1 -= __builtin_bit_cast(float, u & 0xffff0000u);
+      }
+    } else {
+      const f16x2 h = __builtin_convertvector(f32x2{r0, r1}, f16x2);    // v_cvt_pk_f16_f32 (RNE)
+      out[p] = __builtin_bit_cast(unsigned, h);
+      if (p + 1 < PL) {
+        const f32x2 hf = __builtin_convertvector(h, f32x2);
+        r0 -= hf[0];
+        r1 -= hf[1];
+      }
     }
   }
 }
 
+template <int FMT>
+__device__ __forceinline__ f32x16 mfma_split(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (FMT == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
 // fp32 [rows][K] -> split planes [rows][K/32][PL][32] bf16.  One thread per 4 consecutive k.
-template <int PL>
+template <int PL, int FMT = 0>
 __global__ void split_rows_kernel(const float* __restrict__ W, unsigned char* __restrict__ out, int64_t rows, int K) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int kq = K / 4;
@@ -49,8 +72,8 @@ __global__ void split_rows_kernel(const float* __restrict__ W, unsigned char* __
   const int k = (int)(gid % kq) * 4;
   const f32x4 v = *reinterpret_cast<const f32x4*>(W + r * K + k);
   unsigned a[PL], b[PL];
-  split_pair<PL>(v[0], v[1], a);
-  split_pair<PL>(v[2], v[3], b);
+  split_pair<PL, FMT>(v[0], v[1], a);
+  split_pair<PL, FMT>(v[2], v[3], b);
   unsigned char* base = out + (r * (K / 32) + k / 32) * (PL * 64) + (k % 32) * 2;
 #pragma unroll
   for (int p = 0; p < PL; ++p) *reinterpret_cast<u32x2*>(base + p * 64) = u32x2{a[p], b[p]};
@@ -62,7 +85,7 @@ struct SplitGemmArgs {
   int64_t gWsp;               // bytes between groups
 };
 
-template <int BM, int BN, int WM, int WN, int PL, bool DB = true>
+template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs sa) {
   const GemmArgs& g = sa.g;
   constexpr int NT = WM * WN * 64;
@@ -121,8 +144,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
       unsigned a[PL], b[PL];
-      split_pair<PL>(ra[i][0], ra[i][1], a);
-      split_pair<PL>(ra[i][2], ra[i][3], b);
+      split_pair<PL, FMT>(ra[i][0], ra[i][1], a);
+      split_pair<PL, FMT>(ra[i][2], ra[i][3], b);
       unsigned char* dst = As + (buf * BM + lrow + i * (NT / 8)) * RS + lc4 * 2;
 #pragma unroll
       for (int p = 0; p < PL; ++p) *reinterpret_cast<u32x2*>(dst + p * 64) = u32x2{a[p], b[p]};
@@ -181,7 +204,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
           for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], bf[j][pb], acc[i][j], 0, 0, 0);
+              acc[i][j] = mfma_split<FMT>(af[i][pa], bf[j][pb], acc[i][j]);
         }
       }
     }
@@ -217,17 +240,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
   }
 }
 
-template <int BM, int BN, int WM, int WN, int PL, bool DB = true>
+template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0>
 inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t st) {
   constexpr size_t lds = (size_t)(DB ? 2 : 1) * (BM + BN) * (PL * 64 + 16);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<BM, BN, WM, WN, PL, DB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   dim3 grid((sa.g.N / BN) * cdiv(sa.g.M, BM), groups);
-  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL, DB>), grid, dim3(WM * WN * 64), lds, st, sa);
+  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT>), grid, dim3(WM * WN * 64), lds, st, sa);
 }
 
 // Tile choice: 8-wave 256x128 blocks (2 waves/SIMD inside one block, half the LDS staging per MFMA) once
@@ -240,7 +263,7 @@ inline const char* split_tile_name(const GemmArgs& g, int groups) {
   return t128 >= 256 ? "128x128" : "64x128";
 }
 
-template <int PL>
+template <int PL, int FMT = 0>
 inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st) {
   const GemmArgs& g = sa.g;
   if (g.M <= 0) return 0;
@@ -248,14 +271,11 @@ inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st
     return fail(LINETR_E_ARG, "gemm_split: unsupported shape M=%d N=%d K=%d", g.M, g.N, g.K);
   static const char* tile_env = getenv("LINETR_GEMM_TILE");  // tuning aid: force a tile
   const char* tile = tile_env ? tile_env : split_tile_name(g, groups);
-  if (g.N % 128 != 0 || !strcmp(tile, "128x64")) gemm_split_launch_t<128, 64, 4, 1, PL>(sa, groups, st);
-  else if (!strcmp(tile, "256x128")) gemm_split_launch_t<256, 128, 4, 2, PL>(sa, groups, st);
-  else if (!strcmp(tile, "128x256") && g.N % 256 == 0) gemm_split_launch_t<128, 256, 2, 4, PL>(sa, groups, st);
-  else if (!strcmp(tile, "128x128")) gemm_split_launch_t<128, 128, 2, 2, PL>(sa, groups, st);
-  else if (!strcmp(tile, "128x128sb")) gemm_split_launch_t<128, 128, 2, 2, PL, false>(sa, groups, st);
-  else if (!strcmp(tile, "256x128sb")) gemm_split_launch_t<256, 128, 4, 2, PL, false>(sa, groups, st);
-  else if (!strcmp(tile, "256x256") && g.N % 256 == 0) gemm_split_launch_t<256, 256, 4, 2, PL, false>(sa, groups, st);
-  else gemm_split_launch_t<64, 128, 2, 2, PL>(sa, groups, st);
+  if (g.N % 128 != 0 || !strcmp(tile, "128x64")) gemm_split_launch_t<128, 64, 4, 1, PL, true, FMT>(sa, groups, st);
+  else if (!strcmp(tile, "256x128")) gemm_split_launch_t<256, 128, 4, 2, PL, true, FMT>(sa, groups, st);
+  else if (!strcmp(tile, "128x128")) gemm_split_launch_t<128, 128, 2, 2, PL, true, FMT>(sa, groups, st);
+  else if (PL == 2 && !strcmp(tile, "256x256") && g.N % 256 == 0) gemm_split_launch_t<256, 256, 4, 2, 2, true, FMT>(sa, groups, st);
+  else gemm_split_launch_t<64, 128, 2, 2, PL, true, FMT>(sa, groups, st);
   LT_LAUNCH_CHECK();
   return 0;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include "lt_common.h"
 #include "lt_token.h"
+#include "lt_gemm_split.h"
 
 namespace lt {
 
@@ -368,6 +369,180 @@ __global__ __launch_bounds__(256) void sig_attn_kernel(const float* __restrict__
           const float v1 = vp[(kk * 8 + s) * DH + 32];
           o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, st[kk * 4 + s], o0, 0, 0, 0);
           o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, st[kk * 4 + s], o1, 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (wave_active && q < Ni) {
+    const float inv = 1.f / l;
+    float* op = out + (int64_t)(n0 + q) * D + head * DH;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = (r & 3) + 8 * (r >> 2) + 4 * h2;
+      op[d] = o0[r] * inv;
+      op[d + 32] = o1[r] * inv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Same attention with the two contractions on split-bf16 MFMA (3 planes / 6 products = fp32-faithful, see
+// lt_gemm_split.h): v_mfma_f32_32x32x16_bf16 is 16x the rate of the fp32 MFMA, so QK^T + PV cost 48 x 32 cycles
+// per 32-row kv chunk instead of 64 x 64.
+//   * Q fragments: split once into VGPRs (12 x bf16x8).
+//   * K tile in LDS as planes [kv][3][64 d] (row stride 400 B = 4*25 dwords -> conflict-free ds_read_b128).
+//   * V tile in LDS TRANSPOSED as planes [d][3][64 kv] (row stride 392 B = 2*49 dwords -> conflict-free b64):
+//     the PV B-operand P^T[kv][q] comes straight from the S^T accumulator registers (k-slot e of step t is
+//     register 8t+e, i.e. kv = 16t + 4*(lane>>5) + e for e<4 and +8 for e>=4), so the matching A operand
+//     V^T[d][kv] is two 4-element runs of one LDS row.
+//   * softmax stays fp32 and in-lane as in sig_attn_kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int ATS_RK = 3 * 128 + 16;   // K plane row stride (bytes)
+constexpr int ATS_RV = 3 * 128 + 8;    // V^T plane row stride (bytes)
+
+__global__ __launch_bounds__(256) void sig_attn_split_kernel(const float* __restrict__ qkv,
+                                                             const int* __restrict__ cu_sub,
+                                                             float* __restrict__ out /*[N][256] head-major*/) {
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[ATT_KT * ATS_RK];
+  __shared__ __attribute__((aligned(16))) unsigned char Vt[DH * ATS_RV];
+  const int img = blockIdx.x, head = blockIdx.y;
+  const int n0 = cu_sub[img], Ni = cu_sub[img + 1] - n0;
+  const int q0 = blockIdx.z * ATT_QT;
+  if (q0 >= Ni) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h2 = lane >> 5, lq = lane & 31;
+  const int q = q0 + wave * 32 + lq;
+  const bool wave_active = q0 + wave * 32 < Ni;  // wave-uniform
+  const float* base = qkv + (int64_t)n0 * 768;
+
+  bf16x8 qf[4][3];
+  {
+    const int qr = q < Ni ? q : Ni - 1;
+    const float* qp = base + (int64_t)qr * 768 + head * DH + h2 * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + s * 16);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(qp + s * 16 + 4);
+      unsigned a[3], b[3], c[3], d[3];
+      split_pair<3>(x0[0], x0[1], a); split_pair<3>(x0[2], x0[3], b);
+      split_pair<3>(x1[0], x1[1], c); split_pair<3>(x1[2], x1[3], d);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        union { bf16x8 v; unsigned w[4]; } u;
+        u.w[0] = a[p]; u.w[1] = b[p]; u.w[2] = c[p]; u.w[3] = d[p];
+        qf[s][p] = u.v;
+      }
+    }
+  }
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+
+  const int srow = tid >> 4, sc4 = (tid & 15) * 4;  // staging: 16 rows x 16 float4 per pass
+  for (int t0 = 0; t0 < Ni; t0 += ATT_KT) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = srow + i * 16;
+      const int kv = t0 + r;
+      f32x4 kx = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+      if (kv < Ni) {
+        const float* p = base + (int64_t)kv * 768 + head * DH + sc4;
+        kx = *reinterpret_cast<const f32x4*>(p + 256);
+        vx = *reinterpret_cast<const f32x4*>(p + 512);
+      }
+      unsigned a[3], b[3];
+      split_pair<3>(kx[0], kx[1], a);
+      split_pair<3>(kx[2], kx[3], b);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(Ks + r * ATS_RK + p * 128 + sc4 * 2) = u32x2{a[p], b[p]};
+      split_pair<3>(vx[0], vx[1], a);
+      split_pair<3>(vx[2], vx[3], b);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {  // transposed: element (kv=r, d=sc4+j) -> Vt[d][p][r]
+        unsigned short* col = reinterpret_cast<unsigned short*>(Vt + p * 128 + r * 2);
+        col[(sc4 + 0) * (ATS_RV / 2)] = (unsigned short)(a[p] & 0xffffu);
+        col[(sc4 + 1) * (ATS_RV / 2)] = (unsigned short)(a[p] >> 16);
+        col[(sc4 + 2) * (ATS_RV / 2)] = (unsigned short)(b[p] & 0xffffu);
+        col[(sc4 + 3) * (ATS_RV / 2)] = (unsigned short)(b[p] >> 16);
+      }
+    }
+    __syncthreads();
+    if (!wave_active) continue;
+#pragma unroll
+    for (int c = 0; c < ATT_KT / 32; ++c) {
+      const int kv0 = t0 + c * 32;
+      if (kv0 >= Ni) break;
+      f32x16 st;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+      const unsigned char* kp = Ks + (c * 32 + lq) * ATS_RK + h2 * 16;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 ka[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) ka[p] = *reinterpret_cast<const bf16x8*>(kp + p * 128 + s * 32);
+        // six products, smallest first: (2,0) (1,1) (0,2) (1,0) (0,1) (0,0)
+        st = mfma_split<0>(ka[2], qf[s][0], st);
+        st = mfma_split<0>(ka[1], qf[s][1], st);
+        st = mfma_split<0>(ka[0], qf[s][2], st);
+        st = mfma_split<0>(ka[1], qf[s][0], st);
+        st = mfma_split<0>(ka[0], qf[s][1], st);
+        st = mfma_split<0>(ka[0], qf[s][0], st);
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+        if (kv >= Ni) st[r] = -INFINITY;
+        mx = fmaxf(mx, st[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m, mx);
+      const float alpha = expf(m - m_new);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = expf(st[r] - m_new); ps += st[r]; }
+      ps += __shfl_xor(ps, 32, 64);
+      l = l * alpha + ps;
+      m = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      // P^T planes straight from the accumulator registers
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf16x8 pp[3];
+        {
+          unsigned w[4][3];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split_pair<3>(st[8 * t + 2 * e], st[8 * t + 2 * e + 1], w[e]);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            union { bf16x8 v; unsigned u[4]; } x;
+            x.u[0] = w[0][p]; x.u[1] = w[1][p]; x.u[2] = w[2][p]; x.u[3] = w[3][p];
+            pp[p] = x.v;
+          }
+        }
+        const unsigned char* vp = Vt + lq * ATS_RV + (c * 32 + 16 * t + 4 * h2) * 2;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          bf16x8 va[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(vp + dt * 32 * ATS_RV + p * 128);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(vp + dt * 32 * ATS_RV + p * 128 + 16);
+            union { bf16x8 v; unsigned u[4]; } x;
+            x.u[0] = lo[0]; x.u[1] = lo[1]; x.u[2] = hi[0]; x.u[3] = hi[1];
+            va[p] = x.v;
+          }
+          f32x16& o = dt == 0 ? o0 : o1;
+          o = mfma_split<0>(va[2], pp[0], o);
+          o = mfma_split<0>(va[1], pp[1], o);
+          o = mfma_split<0>(va[0], pp[2], o);
+          o = mfma_split<0>(va[1], pp[0], o);
+          o = mfma_split<0>(va[0], pp[1], o);
+          o = mfma_split<0>(va[0], pp[0], o);
         }
       }
     }

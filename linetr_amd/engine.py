@@ -436,7 +436,7 @@ class Engine:
                                               ws.numel(), self._stream()))
         return dist, m01
 
-    PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+    PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}
 
     def set_precision(self, mode: str):
         """arithmetic mode of the dense contractions: 'f32' | 'bf16x6' (fp32-faithful, default) | 'bf16x3'."""

@@ -26,6 +26,21 @@ def test_gemm_shapes(eng, M, N, K):
     assert (Y - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-6), ("bf16x6", 2e-6), ("f16x3", 4e-6), ("bf16x3", 3e-5)])
+def test_gemm_precision_modes(eng, mode, tol):
+    """every MFMA path against a float64 reference (relative to the largest output magnitude)."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.randn(3000, 512, device="cuda", generator=g)
+    W = torch.randn(512, 512, device="cuda", generator=g) / 512 ** 0.5
+    eng.set_precision(mode)
+    try:
+        Y = eng.debug_gemm(A, W)
+    finally:
+        eng.set_precision("bf16x6")
+    ref = (A.double() @ W.double().t()).float()
+    assert ((Y - ref).abs().max() / ref.abs().max()).item() < tol
+
+
 @pytest.mark.parametrize("act", [0, 1, 2, 3])
 def test_gemm_epilogues(eng, act):
     g = torch.Generator(device="cuda").manual_seed(act)

@@ -114,9 +114,10 @@ def test_cfg5_full_size_long_lines():
 def test_precision_modes_agree(eng):
     lines, cat, off, dd, ds = batch_inputs(8, seed0=7600)
     out = {}
-    for mode in ("f32", "bf16x6", "bf16x3"):
+    for mode in ("f32", "bf16x6", "bf16x3", "f16x3"):
         eng.set_precision(mode)
         out[mode] = describe(eng, cat, off, dd, ds)[1].clone()
     eng.set_precision("bf16x6")
     assert (out["bf16x6"] - out["f32"]).abs().max().item() < 3e-6      # fp32-faithful
     assert (out["bf16x3"] - out["f32"]).abs().max().item() < 5e-5      # inside the 1e-4 budget
+    assert (out["f16x3"] - out["f32"]).abs().max().item() < 6e-6       # fp32-class (2^-22 per product)

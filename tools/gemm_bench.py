@@ -10,7 +10,7 @@ def bench(M,N,K,reps=20):
     Ybuf = torch.empty(M,N+PAD,device='cuda')[:, :N]
     ref = (A.double()@W.double().t()).float()
     line = f"M={M:7d} N={N:5d} K={K:5d} "
-    for mode in ('f32','bf16x6','bf16x3'):
+    for mode in ('f32','bf16x6','bf16x3','f16x3'):
         eng.set_precision(mode)
         Y = eng.debug_gemm(A,W,cache_weights=True,out=Ybuf)
         err = ((Y-ref).abs().max()/ref.abs().max()).item()
