@@ -152,8 +152,9 @@ def cpu_baseline(workload, budget_s=12.0, max_pairs=16):
 
 
 PMC_KERNEL_NAMES = {   # profile class -> kernel symbol in profiles/r01_pmc_traffic.json (rocprofv3 --pmc run)
-    "gemm_bf16x6_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 3, true>(lt::SplitGemmArgs)",
-    "gemm_bf16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true>(lt::SplitGemmArgs)",
+    "gemm_bf16x6_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 3, true, 0>(lt::SplitGemmArgs)",
+    "gemm_bf16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 0>(lt::SplitGemmArgs)",
+    "gemm_f16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 1>(lt::SplitGemmArgs)",
     "gemm_f32_128x128": "void lt::gemm_kernel<128, 128, 2, 2>(lt::GemmArgs)",
 }
 
