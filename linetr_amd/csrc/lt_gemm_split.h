@@ -171,8 +171,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
   if (nk > 1) gload(1);
   __syncthreads();
   const int frow = lane & 31, fk = (lane >> 5) * 16;  // byte offset of this lane's 8 bf16 inside a 16-wide K step
-  // Main loop.  Registers always hold the NEXT tile, loaded one whole iteration earlier so L2/HBM latency is
-  // covered; it is split and written into the other LDS buffer at the top of the iteration (branch-free).
+  // Main loop.  Registers hold the NEXT tile: it is split and written into the other LDS buffer at the top of the
+  // iteration (branch-free) and the registers are immediately refilled with tile kt+2, whose L2/HBM latency is
+  // then covered by this iteration's MFMAs.
   // Measured on MI355X (tools/pmc_gemm.sh): this kernel is bound by the ~10-12 B/clk a CU can pull through its
   // L1 (TCP_PENDING_STALL 37 %, TA 21 % busy, L2 hit 80 %), not by the split VALU or the LDS writes -- removing
   // either changes nothing -- so the lever is bytes per MFMA (tile size), not instruction scheduling.
@@ -180,7 +181,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
     const int buf = DB ? (kt & 1) : 0;
     const unsigned char* Ab = As + (buf * BM + wm * TM + frow) * RS + fk;
     const unsigned char* Bb = Bs + (buf * BN + wn * TN + frow) * RS + fk;
-    if (DB) lstore(buf ^ 1);  // branch-free: on the last iteration this rewrites the idle buffer (never read)
+    if (DB) {
+      lstore(buf ^ 1);               // branch-free: on the last iteration this rewrites the idle buffer (never read)
+      if (kt + 2 < nk) gload(kt + 2);  // registers are free again: next-next tile flies during this tile's MFMAs
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 af[MI][PL], bf[NI][PL];
@@ -211,8 +215,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
     if (!DB) {
       __syncthreads();               // everyone done reading the single buffer
       lstore(0);
+      if (kt + 2 < nk) gload(kt + 2);
     }
-    if (kt + 2 < nk) gload(kt + 2);
     __syncthreads();
   }
 
