@@ -754,14 +754,21 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   if ((e = run_gemm(h, st, w.a3, e2, nullptr, 0, 0, h->wW4, h->wb4, nullptr, 0, w.a4, e3, (int)rows, e3, e2, ACT_RELU))) return e;
   // ---- CLS-row attention pooling + value/last-MLP projection
   if (ts.cpnt) {
-    ProfScope ps(h, st, "cls_pool_fused", 2.0 * rows * (2.0 * HEADS * D * 2), (double)rows * D * 4 * 5);
-    const size_t lds = ((size_t)(T + 1) * D + HEADS * (T + 2)) * sizeof(float);
-    if (lds > 160 * 1024) return fail(LINETR_E_ARG, "describe: max_tokens too large for the fused pooling kernel");
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cls_pool_fused_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(cls_pool_fused_kernel, dim3(N), dim3(256), lds, st, ts.recs, ts.sub2line_g, ts.cpnt, w.a4,
-                       ts.first_pad, T, ts.nhwc, ts.Hc, ts.Wc, ts.align_corners, h->pool, w.pooled);
+    static const bool two_pass = getenv("LINETR_POOL_TWO_PASS") != nullptr;  // tuning aid: the LDS two-pass variant
+    if (!two_pass) {
+      ProfScope ps(h, st, "cls_pool_online", 2.0 * rows * (2.0 * HEADS * D * 2), (double)rows * D * 4 * 5);
+      hipLaunchKernelGGL(cls_pool_online_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, ts.recs, ts.sub2line_g, ts.cpnt,
+                         w.a4, ts.first_pad, N, T, ts.nhwc, ts.Hc, ts.Wc, ts.align_corners, h->pool, w.pooled);
+    } else {
+      ProfScope ps(h, st, "cls_pool_fused", 2.0 * rows * (2.0 * HEADS * D * 2), (double)rows * D * 4 * 5);
+      const size_t lds = ((size_t)(T + 1) * D + HEADS * (T + 2)) * sizeof(float);
+      if (lds > 160 * 1024) return fail(LINETR_E_ARG, "describe: max_tokens too large for the fused pooling kernel");
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cls_pool_fused_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(cls_pool_fused_kernel, dim3(N), dim3(256), lds, st, ts.recs, ts.sub2line_g, ts.cpnt, w.a4,
+                         ts.first_pad, T, ts.nhwc, ts.Hc, ts.Wc, ts.align_corners, h->pool, w.pooled);
+    }
     LT_LAUNCH_CHECK();
   } else {
     ProfScope ps(h, st, "cls_pool", 2.0 * rows * (2.0 * HEADS * D * 2), (double)rows * D * 8);

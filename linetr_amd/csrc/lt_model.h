@@ -225,6 +225,96 @@ __global__ __launch_bounds__(256) void cls_pool_fused_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// One-pass form of cls_pool_fused_kernel: ONE WAVE PER SUB-LINE (4 per block), online softmax (running max / sum
+// per head, rescaled accumulators) so every token is visited once, nothing is staged in LDS and there is no
+// barrier; the bilinear taps and the a4 row of token j+1 are in flight while token j is reduced.
+// Same mathematics as cls_pool_kernel up to fp32 rounding (the softmax normalisation is applied at the end).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cls_pool_online_kernel(
+    const LinetrLineRec* __restrict__ recs, const int* __restrict__ sub2line_g, const float* __restrict__ cpnt,
+    const float* __restrict__ a4, int64_t first_pad, int N, int T, const float* __restrict__ nhwc, int Hc, int Wc,
+    int align_corners, ClsPoolConst cc, float* __restrict__ pooled /*[N][4][544]*/) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const LinetrLineRec r = recs[sub2line_g[n]];
+  const int j = n - r.first_sub;
+  const int n_valid = min(T, r.n_tok - j * T);
+  const int n_pad = T - n_valid;
+  const int ntk = n_valid + (n_pad > 0 ? 1 : 0);
+  const int64_t tok0 = (int64_t)r.first_tok + (int64_t)j * T;
+  const int64_t padrow = first_pad + r.image;
+  const float* nhwc_img = nhwc + (int64_t)r.image * Hc * Wc * D;
+  f32x4 u[4], u2[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    u[h] = *reinterpret_cast<const f32x4*>(cc.U + h * D + lane * 4);
+    u2[h] = *reinterpret_cast<const f32x4*>(cc.U2 + h * D + lane * 4);
+  }
+  // running state per head: max m, sum l, weight of the CLS key w0, pooled sums (this lane's 4 channels)
+  float m[4], l[4], w0[4];
+  f32x4 db[4], ab[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    m[h] = cc.s_cls[h]; l[h] = 1.f; w0[h] = 1.f;
+    db[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ab[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto row_of = [&](int jj) -> int64_t { return jj < n_valid ? tok0 + jj : padrow; };
+  TapSet cur, nxt;
+  f32x4 a_cur, a_nxt;
+  {
+    const int64_t row = row_of(0);
+    taps_issue(cpnt[row * 2], cpnt[row * 2 + 1], nhwc_img, Hc, Wc, align_corners, lane, cur);
+    a_cur = *reinterpret_cast<const f32x4*>(a4 + row * D + lane * 4);
+  }
+  for (int jj = 0; jj < ntk; ++jj) {
+    if (jj + 1 < ntk) {  // wave-uniform
+      const int64_t row = row_of(jj + 1);
+      taps_issue(cpnt[row * 2], cpnt[row * 2 + 1], nhwc_img, Hc, Wc, align_corners, lane, nxt);
+      a_nxt = *reinterpret_cast<const f32x4*>(a4 + row * D + lane * 4);
+    }
+    const f32x4 dv = taps_finish(cur);
+    const float mult = jj < n_valid ? 1.f : (float)n_pad;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      float p = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) p += dv[c] * u[h][c] + a_cur[c] * u2[h][c];
+      const float sh = wave_sum(p) + cc.c_tok[h];
+      const float m_new = fmaxf(m[h], sh);
+      const float alpha = expf(m[h] - m_new);
+      const float e = expf(sh - m_new) * mult;
+      m[h] = m_new;
+      l[h] = l[h] * alpha + e;
+      w0[h] *= alpha;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        db[h][c] = db[h][c] * alpha + e * dv[c];
+        ab[h][c] = ab[h][c] * alpha + e * a_cur[c];
+      }
+    }
+    cur = nxt;
+    a_cur = a_nxt;
+  }
+  float* out = pooled + (int64_t)n * 4 * POOLW;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const float inv = 1.f / l[h];
+    f32x4 d = db[h], a = ab[h];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { d[c] *= inv; a[c] *= inv; }
+    *reinterpret_cast<f32x4*>(out + h * POOLW + lane * 4) = d;
+    *reinterpret_cast<f32x4*>(out + h * POOLW + 256 + lane * 4) = a;
+    if (lane < 8) {  // [p_h0, 0 x 31]
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      if (lane == 0) z[0] = w0[h] * inv;
+      *reinterpret_cast<f32x4*>(out + h * POOLW + 512 + lane * 4) = z;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Row kernels over [rows][256]; one wave64 per row, lane = 4 channels.
 //   mode 0: y = LayerNorm(x) * gamma + beta (+ add)      eps = 1e-6 (models/line_attention.py:40,83)
 //   mode 1: y = x / max(||x||_2, 1e-12)                  F.normalize (models/line_transformer.py:246)

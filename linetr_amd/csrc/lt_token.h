@@ -142,6 +142,62 @@ __global__ __launch_bounds__(64) void tokenize_kernel(
 // descriptor map + L2 normalisation.  One wave64 per token, lane = 4 channels (dwordx4, coalesced
 // 1 KiB per tap).  fp32 arithmetic in the order PyTorch's CPU grid_sampler uses.
 // ---------------------------------------------------------------------------------------------
+// --- the same sampling split into "issue the 4 tap loads" and "finish", so a caller can keep the next
+// token's loads in flight while it works on the current one -----------------------------------------------
+struct TapSet { f32x4 v[4]; float w[4]; };   // nw, ne, sw, se values and weights
+
+__device__ __forceinline__ void taps_issue(float px, float py, const float* __restrict__ nhwc_img, int Hc, int Wc,
+                                           int align_corners, int lane, TapSet& t) {
+#pragma clang fp contract(off)
+  const float s = 8.f;
+  float gx = ((px - s / 2) + 0.5f) / ((float)Wc * s - s / 2 - 0.5f);
+  float gy = ((py - s / 2) + 0.5f) / ((float)Hc * s - s / 2 - 0.5f);
+  gx = gx * 2.f - 1.f;
+  gy = gy * 2.f - 1.f;
+  float ix, iy;
+  if (align_corners) {
+    ix = ((gx + 1.f) / 2.f) * (float)(Wc - 1);
+    iy = ((gy + 1.f) / 2.f) * (float)(Hc - 1);
+  } else {
+    ix = ((gx + 1.f) * (float)Wc - 1.f) / 2.f;
+    iy = ((gy + 1.f) * (float)Hc - 1.f) / 2.f;
+  }
+  const float x_w = floorf(ix), y_n = floorf(iy);
+  const float w = ix - x_w, e = 1.f - w, nn = iy - y_n, ss = 1.f - nn;
+  t.w[0] = ss * e; t.w[1] = ss * w; t.w[2] = nn * e; t.w[3] = nn * w;
+  const int x0 = (int)x_w, y0 = (int)y_n;
+  const float* base = nhwc_img + lane * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
+    const bool in = xx >= 0 && xx < Wc && yy >= 0 && yy < Hc;
+    // clamp the address, zero the weight-less value afterwards: keeps the load unconditional (no branch)
+    const int yc = min(max(yy, 0), Hc - 1), xc = min(max(xx, 0), Wc - 1);
+    t.v[k] = *reinterpret_cast<const f32x4*>(base + ((int64_t)yc * Wc + xc) * D);
+    if (!in) t.v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+__device__ __forceinline__ f32x4 taps_finish(const TapSet& t) {
+#pragma clang fp contract(off)
+  f32x4 o;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float v = t.v[0][c] * t.w[0];
+    v = v + t.v[1][c] * t.w[1];
+    v = v + t.v[2][c] * t.w[2];
+    v = v + t.v[3][c] * t.w[3];
+    o[c] = v;
+    sq += v * v;
+  }
+  sq = wave_sum(sq);
+  const float nrm = fmaxf(sqrtf(sq), 1e-12f);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) o[c] = o[c] / nrm;
+  return o;
+}
+
 // bilinear sample (zero padding) + L2 normalisation of one token; every lane of the wave returns its 4 channels
 __device__ __forceinline__ f32x4 sample_one(float px, float py, const float* __restrict__ nhwc_img, int Hc, int Wc,
                                             int align_corners, int lane) {
