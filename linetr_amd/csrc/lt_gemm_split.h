@@ -85,7 +85,7 @@ struct SplitGemmArgs {
   int64_t gWsp;               // bytes between groups
 };
 
-template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0>
+template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0, int PFD = 1>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs sa) {
   const GemmArgs& g = sa.g;
   constexpr int NT = WM * WN * 64;
@@ -121,9 +121,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
   const int nk = g.K / 32;
 
   const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
-  f32x4 ra[A_F4];
-  f32x4 rb[B_PCS];
-  auto gload = [&](int kt) {
+  static_assert(PFD >= 1 && (DB || PFD == 1), "deep prefetch needs the double-buffered LDS");
+  f32x4 ra_[PFD][A_F4];   // PFD tiles in flight in registers (PFD > 1: small-M launches, where one tile's MFMAs are
+  f32x4 rb_[PFD][B_PCS];  // far shorter than the L2/HBM latency and one-deep prefetch leaves the CU waiting)
+  auto gload_set = [&](int kt, f32x4 (&ra)[A_F4], f32x4 (&rb)[B_PCS]) {
     const int k0 = kt * 32;
     const float* src = A; int ld = g.lda; int kk = k0;
     if (k0 >= K1) { src = A2; ld = g.lda2; kk = k0 - K1; }
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
       rb[i] = *reinterpret_cast<const f32x4*>(Wsp + ((int64_t)(n0 + r) * nk + kt) * (PL * 64) + pc * 16);
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore_set = [&](int buf, const f32x4 (&ra)[A_F4], const f32x4 (&rb)[B_PCS]) {
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
       unsigned a[PL], b[PL];
@@ -157,6 +158,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
       *reinterpret_cast<f32x4*>(Bs + (buf * BN + r) * RS + pc * 16) = rb[i];
     }
   };
+  auto gload = [&](int kt) { gload_set(kt, ra_[0], rb_[0]); };
+  auto lstore = [&](int buf) { lstore_set(buf, ra_[0], rb_[0]); };
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -166,25 +169,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  gload(0);
-  lstore(0);
-  if (nk > 1) gload(1);
-  __syncthreads();
   const int frow = lane & 31, fk = (lane >> 5) * 16;  // byte offset of this lane's 8 bf16 inside a 16-wide K step
-  // Main loop.  Registers hold the NEXT tile: it is split and written into the other LDS buffer at the top of the
-  // iteration (branch-free) and the registers are immediately refilled with tile kt+2, whose L2/HBM latency is
-  // then covered by this iteration's MFMAs.
-  // Measured on MI355X (tools/pmc_gemm.sh): this kernel is bound by the ~10-12 B/clk a CU can pull through its
-  // L1 (TCP_PENDING_STALL 37 %, TA 21 % busy, L2 hit 80 %), not by the split VALU or the LDS writes -- removing
-  // either changes nothing -- so the lever is bytes per MFMA (tile size), not instruction scheduling.
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = DB ? (kt & 1) : 0;
+  auto compute = [&](int buf) {
     const unsigned char* Ab = As + (buf * BM + wm * TM + frow) * RS + fk;
     const unsigned char* Bb = Bs + (buf * BN + wn * TN + frow) * RS + fk;
-    if (DB) {
-      lstore(buf ^ 1);               // branch-free: on the last iteration this rewrites the idle buffer (never read)
-      if (kt + 2 < nk) gload(kt + 2);  // registers are free again: next-next tile flies during this tile's MFMAs
-    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 af[MI][PL], bf[NI][PL];
@@ -212,12 +200,53 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
         }
       }
     }
-    if (!DB) {
-      __syncthreads();               // everyone done reading the single buffer
-      lstore(0);
-      if (kt + 2 < nk) gload(kt + 2);
-    }
+  };
+
+  gload(0);
+  lstore(0);
+  if constexpr (PFD == 1) {
+    if (nk > 1) gload(1);
     __syncthreads();
+    // Registers hold the NEXT tile: it is split and written into the other LDS buffer at the top of the iteration
+    // (branch-free) and the registers are immediately refilled with tile kt+2, whose L2/HBM latency is then covered
+    // by this iteration's MFMAs.
+    // Measured on MI355X (tools/pmc_gemm.sh): this kernel is bound by the ~10-12 B/clk a CU can pull through its
+    // L1 (TCP_PENDING_STALL 37 %, TA 21 % busy, L2 hit 80 %), not by the split VALU or the LDS writes -- removing
+    // either changes nothing -- so the lever is bytes per MFMA (tile size), not instruction scheduling.
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = DB ? (kt & 1) : 0;
+      if (DB) {
+        lstore(buf ^ 1);               // branch-free: on the last iteration this rewrites the idle buffer (never read)
+        if (kt + 2 < nk) gload(kt + 2);  // registers are free again: next-next tile flies during this tile's MFMAs
+      }
+      compute(buf);
+      if (!DB) {
+        __syncthreads();               // everyone done reading the single buffer
+        lstore(0);
+        if (kt + 2 < nk) gload(kt + 2);
+      }
+      __syncthreads();
+    }
+  } else {
+    // deep prefetch: register set u holds tile kt+1 for kt = u (mod PFD); it is refilled with tile kt+1+PFD right
+    // after being written to LDS, so PFD tiles are always in flight.
+#pragma unroll
+    for (int u = 0; u < PFD; ++u)
+      if (1 + u < nk) gload_set(1 + u, ra_[u], rb_[u]);
+    __syncthreads();
+    for (int kt0 = 0; kt0 < nk; kt0 += PFD) {
+#pragma unroll
+      for (int u = 0; u < PFD; ++u) {
+        const int kt = kt0 + u;
+        if (kt < nk) {                 // block-uniform
+          const int buf = kt & 1;
+          lstore_set(buf ^ 1, ra_[u], rb_[u]);
+          if (kt + 1 + PFD < nk) gload_set(kt + 1 + PFD, ra_[u], rb_[u]);
+          compute(buf);
+          __syncthreads();
+        }
+      }
+    }
   }
 
   const float* bias = g.bias ? g.bias + grp * g.gBias : nullptr;
@@ -244,17 +273,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
   }
 }
 
-template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0>
+template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0, int PFD = 1>
 inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t st) {
   constexpr size_t lds = (size_t)(DB ? 2 : 1) * (BM + BN) * (PL * 64 + 16);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT, PFD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   dim3 grid((sa.g.N / BN) * cdiv(sa.g.M, BM), groups);
-  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT>), grid, dim3(WM * WN * 64), lds, st, sa);
+  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT, PFD>), grid, dim3(WM * WN * 64), lds, st, sa);
 }
 
 // Tile choice: 8-wave 256x128 blocks (2 waves/SIMD inside one block, half the LDS staging per MFMA) once
@@ -264,7 +293,10 @@ inline const char* split_tile_name(const GemmArgs& g, int groups) {
   const int64_t t256 = (int64_t)cdiv(g.M, 256) * (g.N / 128) * groups;
   if (t256 >= 192) return "256x128";
   const int64_t t128 = (int64_t)cdiv(g.M, 128) * (g.N / 128) * groups;
-  return t128 >= 256 ? "128x128" : "64x128";
+  if (t128 >= 256) return "128x128";
+  // small problems (single pair: M ~ 400): latency-bound -> more, smaller blocks with a deep register prefetch
+  const int64_t t64 = (int64_t)cdiv(g.M, 64) * (g.N / 128) * groups;
+  return t64 >= 96 ? "64x128" : "64x64";
 }
 
 template <int PL, int FMT = 0>
@@ -279,7 +311,8 @@ inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st
   else if (!strcmp(tile, "256x128")) gemm_split_launch_t<256, 128, 4, 2, PL, true, FMT>(sa, groups, st);
   else if (!strcmp(tile, "128x128")) gemm_split_launch_t<128, 128, 2, 2, PL, true, FMT>(sa, groups, st);
   else if (PL == 2 && !strcmp(tile, "256x256") && g.N % 256 == 0) gemm_split_launch_t<256, 256, 4, 2, 2, true, FMT>(sa, groups, st);
-  else gemm_split_launch_t<64, 128, 2, 2, PL, true, FMT>(sa, groups, st);
+  else if (!strcmp(tile, "64x64")) gemm_split_launch_t<64, 64, 2, 2, PL, true, FMT, 4>(sa, groups, st);
+  else gemm_split_launch_t<64, 128, 2, 2, PL, true, FMT, 3>(sa, groups, st);
   LT_LAUNCH_CHECK();
   return 0;
 }
