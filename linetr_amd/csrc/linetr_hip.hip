@@ -48,6 +48,10 @@ struct LinetrHandle {
   struct SplitW { size_t off2, off3; int64_t rows; int K; size_t offh = 0; };  // bf16x2 planes, bf16x3 planes, fp16x2 planes
   std::map<const float*, SplitW> split;
   std::map<const float*, unsigned char*> debug_split;  // linetr_debug_gemm(cache_weights=1)
+  // side stream: work that is independent of the token-MLP GEMMs (NHWC transpose, line-position MLP) runs here and
+  // is joined back with events; created lazily, disabled with LINETR_NO_SIDE_STREAM=1
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_tok = nullptr, ev_nhwc = nullptr, ev_lpos = nullptr;
   // profiling
   bool profiling = false;
   std::vector<ProfClass> classes;
@@ -57,6 +61,19 @@ struct LinetrHandle {
 };
 
 namespace {
+
+// Measured on MI355X: at cfg3 (25 k sub-lines) overlapping the NHWC transpose / line-position MLP with the
+// token-MLP GEMMs buys ~2 % (both sides contend for the same per-CU fetch path); for a single pair the extra
+// event waits COST 0.4 ms.  Hence only large batches fork.
+bool side_stream_ready(LinetrHandle* h, int n_sublines) {
+  static const bool off = getenv("LINETR_NO_SIDE_STREAM") != nullptr;
+  if (off || n_sublines < 8192) return false;
+  if (h->side) return true;
+  if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; return false; }
+  for (hipEvent_t* e : {&h->ev_fork, &h->ev_tok, &h->ev_nhwc, &h->ev_lpos})
+    if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return false;
+  return true;
+}
 
 int prof_class(LinetrHandle* h, const char* name) {
   for (size_t i = 0; i < h->classes.size(); ++i)
@@ -470,6 +487,9 @@ extern "C" void linetr_destroy(LinetrHandle* h) {
   hipSetDevice(h->device);
   for (auto& p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto e : h->event_pool) hipEventDestroy(e);
+  if (h->side) (void)hipStreamDestroy(h->side);
+  for (hipEvent_t e : {h->ev_fork, h->ev_tok, h->ev_nhwc, h->ev_lpos})
+    if (e) (void)hipEventDestroy(e);
   if (h->arena) (void)hipFree(h->arena);
   if (h->split_arena) (void)hipFree(h->split_arena);
   for (auto& kv : h->debug_split) (void)hipFree(kv.second);
@@ -729,6 +749,7 @@ struct TokenStage {            // how the token stage (word MLP + CLS pooling) i
   int64_t rows = 0;            // rows of the word-MLP GEMMs (N*T dense, n_real + n_images fused)
   int64_t first_pad = 0;
   int Hc = 0, Wc = 0, align_corners = 0;
+  bool use_side = false;       // h->side carries the NHWC transpose (ev_nhwc) and may take the line-position MLP
 };
 
 int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const float* sublines, const float* resp,
@@ -752,6 +773,22 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   if ((e = run_gemm(h, st, w.a1, e0, nullptr, 0, 0, h->wW2, h->wb2, nullptr, 0, w.a2, e1, (int)rows, e1, e0, ACT_RELU))) return e;
   if ((e = run_gemm(h, st, w.a2, e1, nullptr, 0, 0, h->wW3, h->wb3, nullptr, 0, w.a3, e2, (int)rows, e2, e1, ACT_RELU))) return e;
   if ((e = run_gemm(h, st, w.a3, e2, nullptr, 0, 0, h->wW4, h->wb4, nullptr, 0, w.a4, e3, (int)rows, e3, e2, ACT_RELU))) return e;
+  // ---- line positional encoder: independent of everything above -> side stream when available
+  hipStream_t ls = ts.use_side ? h->side : st;
+  {
+    ProfScope ps(h, ls, "mlp_first", 2.0 * N * 5 * e0, (double)N * (28 + 4 * e0));
+    hipLaunchKernelGGL(line_mlp1_kernel, dim3(cdiv(N * 8, 256)), dim3(256), 0, ls, sublines, resp, angle_sub, N, cx, cy,
+                       scale, h->lW1, h->lb1, w.l1);
+    LT_LAUNCH_CHECK();
+  }
+  if ((e = run_gemm(h, ls, w.l1, e0, nullptr, 0, 0, h->lW2, h->lb2, nullptr, 0, w.l2, e1, N, e1, e0, ACT_RELU))) return e;
+  if ((e = run_gemm(h, ls, w.l2, e1, nullptr, 0, 0, h->lW3, h->lb3, nullptr, 0, w.l3, e2, N, e2, e1, ACT_RELU))) return e;
+  if ((e = run_gemm(h, ls, w.l3, e2, nullptr, 0, 0, h->lW4, h->lb4, nullptr, 0, w.l4, e3, N, e3, e2, ACT_RELU))) return e;
+  if ((e = run_gemm(h, ls, w.l4, e3, nullptr, 0, 0, h->lW5, h->lb5, nullptr, 0, w.lpos, D, N, D, e3, ACT_NONE))) return e;
+  if (ts.use_side) {
+    LT_HIP(hipEventRecord(h->ev_lpos, h->side));
+    if (ts.cpnt) LT_HIP(hipStreamWaitEvent(st, h->ev_nhwc, 0));   // the pooling kernel samples the NHWC copy
+  }
   // ---- CLS-row attention pooling + value/last-MLP projection
   if (ts.cpnt) {
     static const bool two_pass = getenv("LINETR_POOL_TWO_PASS") != nullptr;  // tuning aid: the LDS two-pass variant
@@ -787,17 +824,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   }
   if ((e = run_gemm(h, st, w.o, D, nullptr, 0, 0, h->Wf1, h->bf1, nullptr, 0, w.f1, c.d_inner, N, c.d_inner, D, ACT_GELU))) return e;
   if ((e = run_gemm(h, st, w.f1, c.d_inner, nullptr, 0, 0, h->Wf2, h->bf2, w.o, D, w.f2, D, N, D, c.d_inner, ACT_NONE))) return e;
-  // ---- line positional encoder
-  {
-    ProfScope ps(h, st, "mlp_first", 2.0 * N * 5 * e0, (double)N * (28 + 4 * e0));
-    hipLaunchKernelGGL(line_mlp1_kernel, dim3(cdiv(N * 8, 256)), dim3(256), 0, st, sublines, resp, angle_sub, N, cx, cy,
-                       scale, h->lW1, h->lb1, w.l1);
-    LT_LAUNCH_CHECK();
-  }
-  if ((e = run_gemm(h, st, w.l1, e0, nullptr, 0, 0, h->lW2, h->lb2, nullptr, 0, w.l2, e1, N, e1, e0, ACT_RELU))) return e;
-  if ((e = run_gemm(h, st, w.l2, e1, nullptr, 0, 0, h->lW3, h->lb3, nullptr, 0, w.l3, e2, N, e2, e1, ACT_RELU))) return e;
-  if ((e = run_gemm(h, st, w.l3, e2, nullptr, 0, 0, h->lW4, h->lb4, nullptr, 0, w.l4, e3, N, e3, e2, ACT_RELU))) return e;
-  if ((e = run_gemm(h, st, w.l4, e3, nullptr, 0, 0, h->lW5, h->lb5, nullptr, 0, w.lpos, D, N, D, e3, ACT_NONE))) return e;
+  if (ts.use_side) LT_HIP(hipStreamWaitEvent(st, h->ev_lpos, 0));
   {  // sentence = line_pos + LN(ffn) (line_transformer.py:128)
     ProfScope ps(h, st, "row_norm", 0, (double)N * D * 12);
     hipLaunchKernelGGL(row_norm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, w.f2, N, 0, h->ln2g, h->ln2b, w.lpos, 1e-6f, w.zA);
@@ -867,6 +894,11 @@ extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const in
   }
   TokenStage ts;
   ts.pnt = tok->pnt; ts.score = tok->score; ts.desc = tok->desc; ts.rows = (int64_t)N * T;
+  if (side_stream_ready(h, N)) {   // fork: the side stream may only start after everything already queued on `st`
+    ts.use_side = true;
+    LT_HIP(hipEventRecord(h->ev_fork, st));
+    LT_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+  }
   return forward_core(h, st, ts, tok->sublines, tok->resp, tok->angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);
 }
 
@@ -931,6 +963,15 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
   float* sublines = out.sublines ? out.sublines : dw.sublines;
   float* resp = out.resp ? out.resp : dw.resp;
   float* angle_sub = out.angle_sub ? out.angle_sub : dw.angle_sub;
+  const bool use_side = side_stream_ready(h, N);
+  if (use_side) {  // NHWC transpose on the side stream, concurrent with tokenise + token-MLP GEMMs
+    LT_HIP(hipEventRecord(h->ev_fork, st));
+    LT_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    ProfScope ps(h, h->side, "nchw_to_nhwc", 0, 2.0 * n_images * P * D * 4);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(P, 32), D / 32, n_images), dim3(32, 8), 0, h->side, d_dense_desc,
+                       dw.nhwc, D, P);
+    LT_LAUNCH_CHECK();
+  }
   {
     ProfScope ps(h, st, "line_fill", 0, (double)K * 80 + (double)N * 8);
     hipLaunchKernelGGL(line_fill_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, d_recs, K, (double)width - 0.6,
@@ -945,13 +986,18 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
                        width, dw.cpnt, dw.cscore, n_real);
     LT_LAUNCH_CHECK();
   }
-  {
+  if (use_side) {
+    LT_HIP(hipEventRecord(h->ev_nhwc, h->side));   // joined by forward_core before the pooling kernel
+    LT_HIP(hipEventRecord(h->ev_tok, st));         // sub-lines / resp / angles exist: the line-position MLP may start
+    LT_HIP(hipStreamWaitEvent(h->side, h->ev_tok, 0));
+  } else {
     ProfScope ps(h, st, "nchw_to_nhwc", 0, 2.0 * n_images * P * D * 4);
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(P, 32), D / 32, n_images), dim3(32, 8), 0, st, d_dense_desc,
                        dw.nhwc, D, P);
     LT_LAUNCH_CHECK();
   }
   if (out.desc) {  // the reference's dense tensor was asked for as well
+    if (use_side) LT_HIP(hipStreamWaitEvent(st, h->ev_nhwc, 0));
     if (!out.pnt) return fail(LINETR_E_ARG, "describe: out.desc requires out.pnt");
     const int64_t ntok = (int64_t)N * T;
     ProfScope ps(h, st, "sample_desc", 0, (double)ntok * D * 4 * 2);
@@ -962,6 +1008,7 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
   TokenStage ts;
   ts.cpnt = dw.cpnt; ts.cscore = dw.cscore; ts.nhwc = dw.nhwc; ts.recs = d_recs; ts.sub2line_g = dw.s2l_g;
   ts.rows = rows; ts.first_pad = n_real; ts.Hc = Hc; ts.Wc = Wc; ts.align_corners = align_corners;
+  ts.use_side = use_side;
   return forward_core(h, st, ts, sublines, resp, angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);
 }
 
