@@ -173,13 +173,16 @@ int64_t linetr_describe_workspace_bytes(const LinetrHandle* h, int32_t n_images,
  * slot of an image holds the same coordinate (0,0), hence the same descriptor, score and key/value), and the
  * CLS-row attention pooling samples the NHWC descriptor map on the fly, counting the padding token with its
  * multiplicity.  Results equal linetr_tokenize + linetr_forward up to fp32 rounding.
+ * dense_is_nhwc != 0: d_dense_desc is already [B, H/8, W/8, 256] (a producer that emits channel-last, e.g. a fused
+ * SuperPoint descriptor head) and the NCHW->NHWC copy is skipped.
  * Small tokeniser outputs (klines, length, angles, sublines, resp, angle_sub) are written when their pointers in
  * `out` are non-NULL; pnt / mask / score / desc are written only if non-NULL (dense [N,T,...] layout). */
 int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N, int64_t n_real_tokens,
                     const int32_t* h_cu_sub, const int32_t* d_cu_sub, int32_t n_images, double token_distance,
                     int32_t max_tokens, const float* d_dense_desc, const float* d_dense_score, int32_t height,
-                    int32_t width, int32_t align_corners, LinetrTokens out, int32_t* d_sub2line,
-                    float* d_line_desc, void* d_workspace, int64_t workspace_bytes, void* stream);
+                    int32_t width, int32_t align_corners, int32_t dense_is_nhwc, LinetrTokens out,
+                    int32_t* d_sub2line, float* d_line_desc, void* d_workspace, int64_t workspace_bytes,
+                    void* stream);
 
 /* ---- device: matcher ------------------------------------------------------------------------ */
 

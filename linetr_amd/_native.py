@@ -73,8 +73,8 @@ def lib():
     L.linetr_pack_lines.argtypes = [vp, vp, vp, i32, f64, i32, i32, i32, i32, vp, C.POINTER(i32)]
     L.linetr_describe_workspace_bytes.argtypes = [vp, i32, i32, i32, i32, i64]
     L.linetr_describe_workspace_bytes.restype = i64
-    L.linetr_describe.argtypes = [vp, vp, i32, i32, i64, vp, vp, i32, f64, i32, vp, vp, i32, i32, i32, Tokens, vp, vp, vp,
-                                  i64, vp]
+    L.linetr_describe.argtypes = [vp, vp, i32, i32, i64, vp, vp, i32, f64, i32, vp, vp, i32, i32, i32, i32, Tokens, vp, vp,
+                                  vp, i64, vp]
     L.linetr_tokenize_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.linetr_tokenize_workspace_bytes.restype = i64
     L.linetr_tokenize.argtypes = [vp, vp, i32, i32, f64, i32, vp, vp, i32, i32, i32, i32, Tokens, vp, vp, i64, vp]

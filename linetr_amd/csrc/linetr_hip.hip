@@ -937,8 +937,8 @@ extern "C" int64_t linetr_describe_workspace_bytes(const LinetrHandle* h, int32_
 extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N, int64_t n_real,
                                const int32_t* h_cu, const int32_t* d_cu, int32_t n_images, double td, int32_t T,
                                const float* d_dense_desc, const float* d_dense_score, int32_t height, int32_t width,
-                               int32_t align_corners, LinetrTokens out, int32_t* d_sub2line, float* d_line_desc,
-                               void* d_ws, int64_t ws_bytes, void* stream) {
+                               int32_t align_corners, int32_t dense_is_nhwc, LinetrTokens out, int32_t* d_sub2line,
+                               float* d_line_desc, void* d_ws, int64_t ws_bytes, void* stream) {
   if (!h) return fail(LINETR_E_ARG, "describe: null handle");
   if (int e = check_cu(h_cu, n_images)) return e;
   if (h_cu[n_images] != N) return fail(LINETR_E_ARG, "describe: cu_sub does not end at N");
@@ -963,8 +963,9 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
   float* sublines = out.sublines ? out.sublines : dw.sublines;
   float* resp = out.resp ? out.resp : dw.resp;
   float* angle_sub = out.angle_sub ? out.angle_sub : dw.angle_sub;
+  const float* nhwc_map = dense_is_nhwc ? d_dense_desc : dw.nhwc;
   const bool use_side = side_stream_ready(h, N);
-  if (use_side) {  // NHWC transpose on the side stream, concurrent with tokenise + token-MLP GEMMs
+  if (use_side && !dense_is_nhwc) {  // NHWC transpose on the side stream, concurrent with tokenise + token-MLP GEMMs
     LT_HIP(hipEventRecord(h->ev_fork, st));
     LT_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     ProfScope ps(h, h->side, "nchw_to_nhwc", 0, 2.0 * n_images * P * D * 4);
@@ -987,10 +988,14 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
     LT_LAUNCH_CHECK();
   }
   if (use_side) {
+    if (dense_is_nhwc) {  // nothing to transpose: the fork only carries the line-position MLP
+      LT_HIP(hipEventRecord(h->ev_fork, st));
+      LT_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    }
     LT_HIP(hipEventRecord(h->ev_nhwc, h->side));   // joined by forward_core before the pooling kernel
     LT_HIP(hipEventRecord(h->ev_tok, st));         // sub-lines / resp / angles exist: the line-position MLP may start
     LT_HIP(hipStreamWaitEvent(h->side, h->ev_tok, 0));
-  } else {
+  } else if (!dense_is_nhwc) {
     ProfScope ps(h, st, "nchw_to_nhwc", 0, 2.0 * n_images * P * D * 4);
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(P, 32), D / 32, n_images), dim3(32, 8), 0, st, d_dense_desc,
                        dw.nhwc, D, P);
@@ -1002,11 +1007,11 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
     const int64_t ntok = (int64_t)N * T;
     ProfScope ps(h, st, "sample_desc", 0, (double)ntok * D * 4 * 2);
     hipLaunchKernelGGL(sample_desc_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, st, out.pnt, dw.s2l_g, d_recs,
-                       ntok, T, dw.nhwc, Hc, Wc, align_corners, out.desc);
+                       ntok, T, nhwc_map, Hc, Wc, align_corners, out.desc);
     LT_LAUNCH_CHECK();
   }
   TokenStage ts;
-  ts.cpnt = dw.cpnt; ts.cscore = dw.cscore; ts.nhwc = dw.nhwc; ts.recs = d_recs; ts.sub2line_g = dw.s2l_g;
+  ts.cpnt = dw.cpnt; ts.cscore = dw.cscore; ts.nhwc = nhwc_map; ts.recs = d_recs; ts.sub2line_g = dw.s2l_g;
   ts.rows = rows; ts.first_pad = n_real; ts.Hc = Hc; ts.Wc = Wc; ts.align_corners = align_corners;
   ts.use_side = use_side;
   return forward_core(h, st, ts, sublines, resp, angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);

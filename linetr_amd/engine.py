@@ -242,7 +242,7 @@ class Engine:
         return tb
 
     def describe(self, recs, cu_k, cu_n, dense_desc, dense_score, *, token_distance, max_tokens, align_corners=False,
-                 want_tokens=False):
+                 want_tokens=False, dense_layout="nchw"):
         """Fused tokenise + descriptor network for a batch (linetr_describe): real tokens only, descriptors sampled
         on the fly.  Returns (TokenBatch, line_desc [N,256]).  With want_tokens=False the dense [N,T,...] token
         tensors (pnt / mask / score / desc) are not materialised (zero-sized in the TokenBatch)."""
@@ -257,8 +257,10 @@ class Engine:
         if dense_desc.shape[0] != B or dense_score.shape[0] != B:
             raise ValueError("dense maps must have one entry per image")
         H, W = int(dense_score.shape[-2]), int(dense_score.shape[-1])
-        if dense_desc.shape[1] != D or dense_desc.shape[2] * 8 != H or dense_desc.shape[3] * 8 != W:
-            raise ValueError(f"dense_descriptor shape {tuple(dense_desc.shape)} does not match dense_score {H}x{W}")
+        nhwc = dense_layout == "nhwc"
+        want = (B, H // 8, W // 8, D) if nhwc else (B, D, H // 8, W // 8)
+        if tuple(dense_desc.shape) != want:
+            raise ValueError(f"dense_descriptor shape {tuple(dense_desc.shape)} does not match {want} ({dense_layout})")
         dev = self.device
         f = dict(dtype=torch.float32, device=dev)
         z = torch.empty((0,), **f)
@@ -284,12 +286,13 @@ class Engine:
         nat.check(self._L.linetr_describe(self._h, d_recs.data_ptr(), K, N, n_real, nat.np_ptr(cu),
                                           d_cu.data_ptr() if d_cu is not None else None, B, float(token_distance), T,
                                           dense_desc.data_ptr(), dense_score.data_ptr(), H, W, int(bool(align_corners)),
-                                          ct, tb.sub2line.data_ptr(), ld.data_ptr(), ws.data_ptr(), ws.numel(),
-                                          self._stream()))
+                                          int(nhwc), ct, tb.sub2line.data_ptr(), ld.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), self._stream()))
         return tb, ld
 
     def describe_lines(self, lines6, offsets, dense_desc, dense_score, *, remove_borders, min_length, max_keylines,
-                       token_distance, max_tokens, align_corners=False, n_streams=1, want_tokens=False):
+                       token_distance, max_tokens, align_corners=False, n_streams=1, want_tokens=False,
+                       dense_layout="nchw"):
         """prefilter + describe for a batch given as one [sum K,6] array + row offsets [B+1].
 
         With n_streams > 1 the images are cut into contiguous groups that run as independent sub-batches on
@@ -307,7 +310,8 @@ class Engine:
         if G == 1:
             recs, cu_k, cu_n = self.prefilter(lines6, H, W, offsets=offsets, **kw)
             return self.describe(recs, cu_k, cu_n, dense_desc, dense_score, token_distance=token_distance,
-                                 max_tokens=max_tokens, align_corners=align_corners, want_tokens=want_tokens)
+                                 max_tokens=max_tokens, align_corners=align_corners, want_tokens=want_tokens,
+                                 dense_layout=dense_layout)
         # contiguous image groups of (nearly) equal line count
         target = offsets[-1] / G
         cuts = [0] + [int(np.searchsorted(offsets, target * g)) for g in range(1, G)] + [B]
@@ -329,7 +333,7 @@ class Engine:
                 self._ws_tag = f"desc{g}"
                 tb, ld = self.describe(recs, cu_k, cu_n, dense_desc[i0:i1], dense_score[i0:i1],
                                        token_distance=token_distance, max_tokens=max_tokens,
-                                       align_corners=align_corners, want_tokens=want_tokens)
+                                       align_corners=align_corners, want_tokens=want_tokens, dense_layout=dense_layout)
                 self._ws_tag = None
                 done = torch.cuda.Event()
                 done.record(st)

@@ -82,6 +82,85 @@ class Matching(torch.nn.Module):
         pred["matching_scores_l"] = torch.from_numpy(d_l)
         return pred
 
+    def forward_batch(self, pairs):
+        """Batched counterpart of forward() (section 8(f)-3: the reference's surface is one pair per call).
+
+        `pairs` is a list of dicts with 'image0' / 'image1' ([1,1,H,W], all pairs the same size).  SuperPoint and
+        LSD still run per image (out-of-scope front-ends); line tokenisation + description of ALL 2P images is ONE
+        fused native call (linetr_prefilter_batch + linetr_describe) and the line matching of all P pairs is ONE
+        linetr_match call.  Returns a list of P dicts with the keys forward() produces, except that the dense
+        per-token tensors (pnt/mask/desc/score_sublines) are not materialised.  Key-line order follows the native
+        pre-filter (ties in length: stable), everything else is identical to forward()."""
+        from .synth import keylines_to_array
+        lt = self.linetransformer
+        P = len(pairs)
+        if P == 0:
+            return []
+        shape = tuple(pairs[0]["image0"].shape)
+        sp_out, lines, valid = [], [], []
+        for d in pairs:
+            for s in ("0", "1"):
+                img = d["image" + s]
+                if tuple(img.shape) != shape:
+                    raise ValueError("forward_batch needs equally sized images")
+                sp = self.superpoint({"image": img})
+                sp_out.append(sp)
+                lines.append(keylines_to_array(self.lsd.detect_torch(img)))
+        if self.auto_min_length:
+            lt.config["min_length"] = max(16, max(shape) / 40)
+            lt.config["token_distance"] = max(8, max(shape) / 80)
+        lt.config["image_shape"] = shape
+        c = lt.config
+        dd = torch.cat([sp["dense_descriptor"] for sp in sp_out])
+        ds = torch.cat([sp["dense_score"] for sp in sp_out])
+        eng = lt.engine(dd.device)
+        off = np.concatenate([[0], np.cumsum([len(l) for l in lines])]).astype(np.int32)
+        cat = np.concatenate(lines) if off[-1] else np.zeros((0, 6))
+        align = int(torch.__version__[2]) > 2
+        tb, ld = eng.describe_lines(cat, off, dd, ds, remove_borders=c["remove_borders"], min_length=c["min_length"],
+                                    max_keylines=c["max_keylines"], token_distance=c["token_distance"],
+                                    max_tokens=c["max_tokens"], align_corners=align)
+        cu_n, cu_k = tb.cu_n, tb.cu_k
+        n, k = np.diff(cu_n), np.diff(cu_k)
+        dev = ld.device
+        idx0 = torch.cat([torch.arange(cu_n[i], cu_n[i + 1]) for i in range(0, 2 * P, 2)]).to(dev)
+        idx1 = torch.cat([torch.arange(cu_n[i], cu_n[i + 1]) for i in range(1, 2 * P, 2)]).to(dev)
+        cs = lambda v: np.concatenate([[0], np.cumsum(v)]).astype(np.int32)
+        dk, off_dk, m01 = eng.match(ld[idx0], cs(n[0::2]), tb.sub2line[idx0], cs(k[0::2]), ld[idx1], cs(n[1::2]),
+                                    tb.sub2line[idx1], cs(k[1::2]), float(np.float32(c["nn_threshold"])), True)
+        dk_h, m01_h = dk.cpu().numpy(), m01.cpu().numpy()
+        ck0 = cs(k[0::2])
+        preds = []
+        for p in range(P):
+            pred = {}
+            for s, img_i in (("0", 2 * p), ("1", 2 * p + 1)):
+                pred.update({key + s: v for key, v in sp_out[img_i].items()})
+                k0, k1, n0, n1 = cu_k[img_i], cu_k[img_i + 1], cu_n[img_i], cu_n[img_i + 1]
+                K, N = int(k1 - k0), int(n1 - n0)
+                s2l = tb.sub2line[n0:n1].long()
+                A = torch.zeros((K, N), device=dev)
+                if N:
+                    cnt = torch.bincount(s2l, minlength=K).clamp(min=1)
+                    A[s2l, torch.arange(N, device=dev)] = (1.0 / cnt.double())[s2l].float()
+                pred.update({"klines" + s: tb.klines[k0:k1][None], "length_klines" + s: tb.length[k0:k1][None],
+                             "angles" + s: tb.angles[k0:k1][None], "sublines" + s: tb.sublines[n0:n1][None],
+                             "resp_sublines" + s: tb.resp[n0:n1][None, :, None],
+                             "angle_sublines" + s: tb.angle_sub[n0:n1][None],
+                             "line_desc" + s: ld[n0:n1].t()[None], "mat_klines2sublines" + s: A[None]})
+            desc0 = torch.stack(list(pred["descriptors0"]))[0] if isinstance(pred["descriptors0"], (list, tuple)) else pred["descriptors0"][0]
+            desc1 = torch.stack(list(pred["descriptors1"]))[0] if isinstance(pred["descriptors1"], (list, tuple)) else pred["descriptors1"][0]
+            m_p, d_p = nn_matcher(desc0.detach().cpu().numpy(), desc1.detach().cpu().numpy(),
+                                  self.superpoint.config["nn_threshold"], is_mutual_NN=True)
+            pred["matches_p"], pred["matching_scores_p"] = torch.from_numpy(m_p), torch.from_numpy(d_p)
+            K0, K1 = int(k[2 * p]), int(k[2 * p + 1])
+            pred["matches_l"] = torch.from_numpy(match01_to_matrix(m01_h[ck0[p]:ck0[p] + K0], K1))
+            pred["matching_scores_l"] = torch.from_numpy(dk_h[off_dk[p]:off_dk[p + 1]].reshape(1, K0, K1).copy())
+            for key in list(pred):
+                if isinstance(pred[key], (list, tuple)):
+                    pred[key] = torch.stack(list(pred[key]))
+            preds.append(pred)
+        return preds
+
     def match_lines(self, line_desc0, mat0, line_desc1, mat1, thr):
         """(matches [1,K0,K1] float64, Dk [1,K0,K1] float32) as NumPy, like matching.py:77-84."""
         K0, N0 = int(mat0.shape[1]), int(mat0.shape[2])

@@ -129,6 +129,49 @@ def test_matching_pipeline_outputs():
     assert out["klines0"].shape == (199, 2, 2) and out["matches_l"].shape == (199, 199)
 
 
+def test_matching_forward_batch_equals_per_pair():
+    """forward_batch (one fused describe + one match call for all pairs) vs forward() pair by pair."""
+    from models.matching import Matching
+    seeds = [31, 32, 33, 34, 35, 36]
+    line_sets = [synth.synth_lines(s, 150 + 10 * i, 480, 640) for i, s in enumerate(seeds)]
+
+    def build():
+        mt = Matching({"auto_min_length": True, "linetransformer": {**LT_CFG}}, superpoint=FakeSuperPoint(seeds),
+                      lsd=FakeLSD(line_sets))
+        mt.linetransformer.load_state_dict(synth.to_torch_state_dict(synth.calibrated_state_dict()))
+        return mt.eval().to("cuda")
+    img = torch.zeros(1, 1, 480, 640, device="cuda")
+    pairs = [{"image0": img, "image1": img.clone()} for _ in range(3)]
+    batch = build().forward_batch(pairs)
+    single = build()
+    assert len(batch) == 3
+    for p in range(3):
+        ref = single({"image0": img, "image1": img.clone()})
+        got = batch[p]
+        for k in ("matches_l", "matches_p"):
+            assert torch.equal(got[k], ref[k]), (p, k)
+        assert (got["matching_scores_l"] - ref["matching_scores_l"]).abs().max().item() < 1e-5
+        for k in ("klines0", "klines1", "mat_klines2sublines0", "sublines1"):
+            assert torch.equal(got[k].cpu(), ref[k].cpu()), (p, k)
+        assert (got["line_desc0"] - ref["line_desc0"]).abs().max().item() < 5e-6
+        for v in got.values():
+            v[0]
+
+
+def test_nhwc_dense_layout_matches_nchw():
+    from linetr_amd.engine import Engine
+    eng = Engine(synth.calibrated_state_dict(), "cuda:0")
+    rows = [synth.synth_lines(41, 120, 480, 640), synth.synth_lines(42, 90, 480, 640)]
+    maps = [synth.synth_dense_maps(s, 480, 640) for s in (41, 42)]
+    dd = torch.cat([m[0] for m in maps]).cuda()
+    ds = torch.cat([m[1] for m in maps]).cuda()
+    off = np.array([0, 120, 210], np.int32)
+    kw = dict(remove_borders=8, min_length=16, max_keylines=-1, token_distance=8, max_tokens=21)
+    _, a = eng.describe_lines(np.concatenate(rows), off, dd, ds, **kw)
+    _, b = eng.describe_lines(np.concatenate(rows), off, dd.permute(0, 2, 3, 1).contiguous(), ds, dense_layout="nhwc", **kw)
+    assert torch.equal(a, b)
+
+
 def test_nn_matcher_known_answers():
     from models.nn_matcher import nn_matcher, nn_matcher_distmat
     g = load("matcher_cases")
