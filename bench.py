@@ -75,7 +75,9 @@ class Pipeline:
         self.n_streams = n_streams
         self.n_img_cap = 2 * pairs
         self.rows_cap = sum(len(l) for l in lines)
-        self.packed = None
+        self.packed = [None, None]      # double-buffered: the all-gather of step i overlaps the compute of step i+1
+        self.pending = [None, None]
+        self.slot = 0
         # the detector output of the batch as one host array + row offsets (input format of the batched API)
         self.offsets = np.zeros(len(lines) + 1, dtype=np.int32)
         np.cumsum([len(l) for l in lines], out=self.offsets[1:])
@@ -91,9 +93,21 @@ class Pipeline:
         tb, ld = self.describe()
         gathered = None
         if self.world > 1:
-            self.packed = parallel.pack_descriptors(ld, tb.cu_n, self.n_img_cap, self.rows_cap, self.packed)
-            gathered = parallel.allgather_descriptors(self.packed)
+            s = self.slot
+            if self.pending[s] is not None:            # the buffer we are about to overwrite: its gather must be done
+                self.pending[s][0].wait()
+            self.packed[s] = parallel.pack_descriptors(ld, tb.cu_n, self.n_img_cap, self.rows_cap, self.packed[s])
+            work, gathered = parallel.allgather_descriptors(self.packed[s], async_op=True)
+            self.pending[s] = (work, gathered)
+            self.slot ^= 1
         return tb, ld, gathered
+
+    def drain(self):
+        """wait for every outstanding all-gather (called before the closing barrier of a timed region)."""
+        for i, p in enumerate(self.pending):
+            if p is not None:
+                p[0].wait()
+                self.pending[i] = None
 
     def match(self, tb, ld):
         """image 2p vs image 2p+1 for every local pair."""
@@ -216,13 +230,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the LineTR hot path has no CPU fallback")
+    # test hooks (single-GPU box): LINETR_BENCH_ONE_DEVICE=1 maps every rank to cuda:0, LINETR_BENCH_BACKEND=gloo
+    # replaces RCCL, so the N>1 code path can be exercised without N GPUs.  Never set by the driver.
+    if os.environ.get("LINETR_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("LINETR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -234,6 +256,7 @@ def main():
     pipe = Pipeline(eng, lines, dd, ds, hw, T, world, pairs, args.streams)
 
     def barrier():
+        pipe.drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -258,6 +281,15 @@ def main():
         n_desc_step = float(tb.N)
     ms_per_step = elapsed / args.steps * 1e3
     value = n_desc_step * args.steps / elapsed
+    gathered_ok = None
+    if world > 1 and _g is not None:     # every rank's slab of the last all-gather carries that rank's descriptors
+        gathered_ok = True
+        for r in range(world):
+            d_r, cu_r = parallel.unpack_descriptors(_g[r], pipe.n_img_cap)
+            gathered_ok &= bool(len(cu_r) == 2 * pairs + 1 and d_r.shape[0] == cu_r[-1])
+            if r == rank:
+                gathered_ok &= bool(torch.equal(d_r, ld))
+            gathered_ok &= bool(((d_r.norm(dim=1) - 1).abs() < 1e-4).all().item())
 
     # ---- pair-match ms (a19-a21) on the descriptors just produced --------------------------------------------
     margs = pipe.match(tb, ld)
@@ -309,6 +341,7 @@ def main():
                   "bf16x3": "f32 in/out; GEMMs as 3 bf16-split MFMA products, fp32 accumulate (~1e-5)",
                   "f16x3": "f32 in/out; GEMMs as 3 fp16-split MFMA products, fp32 accumulate (~1e-6)"}[args.precision],
         "precision": args.precision, "data": "synthetic",
+        "gathered_rows_checked": gathered_ok,
         "config": {"workload": f"{args.workload}: {pairs} pairs/GPU of {W}x{H}, {n_lines} lines/image -> "
                                f"{int(tb.N / n_img)} sub-lines x {T} tokens, d_model=256, seeded weights",
                    "pairs_per_gpu": pairs, "descriptors_per_step": int(n_desc_step),

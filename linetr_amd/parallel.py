@@ -55,10 +55,13 @@ def unpack_descriptors(buf: torch.Tensor, n_images_cap: int):
     return buf[hr:hr + int(cu[-1])], cu
 
 
-def allgather_descriptors(packed: torch.Tensor, group=None) -> torch.Tensor:
-    """ONE collective: every rank contributes its packed slab, receives [world, rows, 256]."""
+def allgather_descriptors(packed: torch.Tensor, group=None, async_op: bool = False):
+    """ONE collective: every rank contributes its packed slab, receives [world, rows, 256].
+    async_op=True returns (work, out): the caller overlaps the transfer with the next batch's compute and calls
+    work.wait() before touching `out` or re-using `packed`."""
     world = dist.get_world_size(group)
     rows = packed.shape[0]
     out = torch.empty((world * rows,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(out, packed.contiguous(), group=group)   # dim-0 concatenation of the slabs
-    return out.view((world, rows) + tuple(packed.shape[1:]))
+    work = dist.all_gather_into_tensor(out, packed.contiguous(), group=group, async_op=async_op)  # dim-0 concatenation
+    out = out.view((world, rows) + tuple(packed.shape[1:]))
+    return (work, out) if async_op else out
