@@ -688,7 +688,7 @@ extern "C" int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int
   if (out.desc) {
     {
       ProfScope ps(h, st, "nchw_to_nhwc", 0, 2.0 * n_images * P * D * 4);
-      hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(P, 32), D / 32, n_images), dim3(32, 8), 0, st, d_dense_desc,
+      hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(P, 64), D / 64, n_images), dim3(256), 0, st, d_dense_desc,
                          nhwc, D, P);
       LT_LAUNCH_CHECK();
     }
@@ -969,7 +969,7 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
     LT_HIP(hipEventRecord(h->ev_fork, st));
     LT_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     ProfScope ps(h, h->side, "nchw_to_nhwc", 0, 2.0 * n_images * P * D * 4);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(P, 32), D / 32, n_images), dim3(32, 8), 0, h->side, d_dense_desc,
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(P, 64), D / 64, n_images), dim3(256), 0, h->side, d_dense_desc,
                        dw.nhwc, D, P);
     LT_LAUNCH_CHECK();
   }
@@ -997,7 +997,7 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
     LT_HIP(hipStreamWaitEvent(h->side, h->ev_tok, 0));
   } else if (!dense_is_nhwc) {
     ProfScope ps(h, st, "nchw_to_nhwc", 0, 2.0 * n_images * P * D * 4);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(P, 32), D / 32, n_images), dim3(32, 8), 0, st, d_dense_desc,
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(P, 64), D / 64, n_images), dim3(256), 0, st, d_dense_desc,
                        dw.nhwc, D, P);
     LT_LAUNCH_CHECK();
   }

@@ -9,22 +9,47 @@ namespace lt {
 // ---------------------------------------------------------------------------------------------
 // NCHW -> NHWC copy of the dense descriptor map so that each bilinear tap is one coalesced 1 KiB
 // row (SuperPoint emits [1,256,H/8,W/8], models/superpoint.py:193).  32x32 LDS-tiled transpose.
-// grid (P/32 ceil, C/32, B), block (32, 8)
+// grid (P/64 ceil, C/64, B), block 256
 // ---------------------------------------------------------------------------------------------
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int P) {
-  __shared__ float tile[32][33];
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           int C, int P) {
+  // 64 channels x 64 positions per block, dwordx4 on both sides: reads 16 B along p (NCHW rows), writes 16 B along c
+  // (NHWC rows).  LDS tile [64 c][64 p + 1]: the odd stride keeps the 4-way column gather conflict-free.
+  __shared__ float tile[64][65];
   const int b = blockIdx.z;
-  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const float* src = in + (int64_t)b * C * P;
   float* dst = out + (int64_t)b * C * P;
-  for (int i = threadIdx.y; i < 32; i += 8) {
-    int p = p0 + threadIdx.x;
-    tile[i][threadIdx.x] = p < P ? src[(int64_t)(c0 + i) * P + p] : 0.f;
+  const int tid = threadIdx.x;
+  {
+    const int pq = (tid & 15) * 4;          // 16 threads cover 64 positions
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = (tid >> 4) + i * 16;
+      const float* row = src + (int64_t)(c0 + c) * P + p0 + pq;
+      f32x4 v;
+      if (p0 + pq + 3 < P && (((uintptr_t)row) & 15) == 0) v = *reinterpret_cast<const f32x4*>(row);
+      else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = p0 + pq + k < P ? row[k] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tile[c][pq + k] = v[k];
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.y; i < 32; i += 8) {
-    int p = p0 + i;
-    if (p < P) dst[(int64_t)p * C + c0 + threadIdx.x] = tile[threadIdx.x][i];
+  {
+    const int cq = (tid & 15) * 4;          // 16 threads cover 64 channels of one position
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = (tid >> 4) + i * 16;
+      if (p0 + p < P) {
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = tile[cq + k][p];
+        *reinterpret_cast<f32x4*>(dst + (int64_t)(p0 + p) * C + c0 + cq) = v;
+      }
+    }
   }
 }
 
