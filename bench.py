@@ -166,10 +166,11 @@ def cpu_baseline(workload, budget_s=12.0, max_pairs=16):
 
 
 PMC_KERNEL_NAMES = {   # profile class -> kernel symbol in profiles/r01_pmc_traffic.json (rocprofv3 --pmc run)
-    "gemm_bf16x6_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 3, true, 0>(lt::SplitGemmArgs)",
-    "gemm_bf16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 0>(lt::SplitGemmArgs)",
-    "gemm_f16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 1>(lt::SplitGemmArgs)",
-    "gemm_f32_128x128": "void lt::gemm_kernel<128, 128, 2, 2>(lt::GemmArgs)",
+    # matched as a prefix of the demangled name (trailing template arguments may grow)
+    "gemm_bf16x6_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 3, true, 0",
+    "gemm_bf16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 0",
+    "gemm_f16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 1",
+    "gemm_f32_128x128": "void lt::gemm_kernel<128, 128, 2, 2>",
 }
 
 
@@ -181,7 +182,7 @@ def pmc_traffic(kernel_class):
     name = PMC_KERNEL_NAMES.get(kernel_class)
     if not name or not os.path.exists(path):
         return None
-    rec = json.load(open(path)).get(name)
+    rec = next((v for k, v in json.load(open(path)).items() if k.startswith(name)), None)
     if not rec or "FETCH_SIZE_KiB_avg" not in rec or "WRITE_SIZE_KiB_avg" not in rec:
         return None
     return (2.0 * rec["FETCH_SIZE_KiB_avg"] + rec["WRITE_SIZE_KiB_avg"]) * 1024.0
