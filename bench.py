@@ -304,17 +304,39 @@ def main():
     torch.cuda.synchronize()
     pair_match_ms = (time.perf_counter() - t0) / reps / pairs * 1e3
     n_matches = int((m01 >= 0).sum().item())
+    # ... and for ONE pair at a time (latency of get_dist_matrix + subline2keyline + nn_matcher_distmat)
+    n0, n1 = int(tb.cu_n[1]), int(tb.cu_n[2] - tb.cu_n[1])
+    k0, k1 = int(tb.cu_k[1]), int(tb.cu_k[2] - tb.cu_k[1])
+    one_args = (ld[:n0], np.array([0, n0]), tb.sub2line[:n0], np.array([0, k0]), ld[n0:n0 + n1], np.array([0, n1]),
+                tb.sub2line[n0:n0 + n1], np.array([0, k1]))
+    for _ in range(3):
+        eng.match(*one_args, LINE_CFG["nn_threshold"], True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        eng.match(*one_args, LINE_CFG["nn_threshold"], True)
+    torch.cuda.synchronize()
+    pair_match_latency_ms = (time.perf_counter() - t0) / 20 * 1e3
 
     # ---- single-pair latency (cfg2 shape, tokenise + forward + match) -----------------------------------------
     one = Pipeline(eng, lines[:2], dd[:2], ds[:2], hw, T, 1, 1)
     for _ in range(3):
+        pipe.step()                       # bring the clocks back up after the light matcher section
+    for _ in range(20):
         tb1, ld1 = one.describe()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(10):
+    for _ in range(30):
         tb1, ld1 = one.describe()
     torch.cuda.synchronize()
-    pair_latency_ms = (time.perf_counter() - t0) / 10 * 1e3
+    pair_latency_ms = (time.perf_counter() - t0) / 30 * 1e3   # back-to-back single pairs (throughput-latency)
+    lat = []
+    for _ in range(10):                   # and strictly one at a time: submit, wait, repeat
+        t1 = time.perf_counter()
+        one.describe()
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t1)
+    pair_latency_sync_ms = float(np.median(lat)) * 1e3
 
     # ---- per-kernel HIP-event profile of the same step (roofline of the dominant kernel) ----------------------
     prof_steps = 3
@@ -347,7 +369,8 @@ def main():
                                f"{int(tb.N / n_img)} sub-lines x {T} tokens, d_model=256, seeded weights",
                    "pairs_per_gpu": pairs, "descriptors_per_step": int(n_desc_step),
                    "collective": "all_gather(line_desc)" if world > 1 else "none"},
-        "pair_match_ms": round(pair_match_ms, 4), "pair_latency_ms": round(pair_latency_ms, 3),
+        "pair_match_ms": round(pair_match_ms, 4), "pair_match_latency_ms": round(pair_match_latency_ms, 4),
+        "pair_latency_ms": round(pair_latency_ms, 3), "pair_latency_sync_ms": round(pair_latency_sync_ms, 3),
         "matches_per_step": n_matches,
         "whole_step_algorithmic_tflops": round(alg_flops_step / (ms_per_step * 1e-3) / 1e12 * (world if world > 1 else 1) / max(world, 1), 2),
         "gpu_ms_per_step_profiled": round(tot_ms / prof_steps, 3),

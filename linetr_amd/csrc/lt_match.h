@@ -110,14 +110,25 @@ __global__ __launch_bounds__(256) void pair_match_kernel(const PairDesc* __restr
     Dk[e] = v;
   }
   __syncthreads();
-  // argmin over clip(min=0) values; np.argmin returns the first minimum
-  for (int i = tid; i < pd.k0; i += 256) {
-    float best = INFINITY; int arg = 0;
-    for (int j = 0; j < pd.k1; ++j) {
-      const float v = fmaxf(Dk[(int64_t)i * pd.k1 + j], 0.f);
-      if (v < best) { best = v; arg = j; }
+  // argmin over clip(min=0) values; np.argmin returns the first minimum.
+  // Rows: one wave per row, lanes stride over the columns (coalesced), (value, index) butterfly reduction that
+  // keeps the smaller index on ties.  Columns: one thread per column, coalesced across threads.
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int i = wave; i < pd.k0; i += 4) {
+      float best = INFINITY; int arg = 0x7fffffff;
+      for (int j = lane; j < pd.k1; j += 64) {
+        const float v = fmaxf(Dk[(int64_t)i * pd.k1 + j], 0.f);
+        if (v < best) { best = v; arg = j; }       // ascending j per lane: strict < keeps the first
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oa = __shfl_xor(arg, o, 64);
+        if (ov < best || (ov == best && oa < arg)) { best = ov; arg = oa; }
+      }
+      if (lane == 0) { row_arg[i] = arg; row_min[i] = best; }
     }
-    row_arg[i] = arg; row_min[i] = best;
   }
   for (int j = tid; j < pd.k1; j += 256) {
     float best = INFINITY; int arg = 0;
