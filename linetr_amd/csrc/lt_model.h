@@ -487,6 +487,7 @@ __global__ __launch_bounds__(256) void sig_attn_kernel(const float* __restrict__
 //     V^T[d][kv] is two 4-element runs of one LDS row.
 //   * softmax stays fp32 and in-lane as in sig_attn_kernel.
 // ---------------------------------------------------------------------------------------------
+constexpr float LOG2E = 1.44269504088896340736f;
 constexpr int ATS_RK = 3 * 128 + 16;   // K plane row stride (bytes)
 constexpr int ATS_RV = 3 * 128 + 8;    // V^T plane row stride (bytes)
 
@@ -511,8 +512,10 @@ __global__ __launch_bounds__(256) void sig_attn_split_kernel(const float* __rest
     const float* qp = base + (int64_t)qr * 768 + head * DH + h2 * 8;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + s * 16);
-      const f32x4 x1 = *reinterpret_cast<const f32x4*>(qp + s * 16 + 4);
+      f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + s * 16);
+      f32x4 x1 = *reinterpret_cast<const f32x4*>(qp + s * 16 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x0[e] *= LOG2E; x1[e] *= LOG2E; }   // scores in log2 units: exp -> v_exp_f32
       unsigned a[3], b[3], c[3], d[3];
       split_pair<3>(x0[0], x0[1], a); split_pair<3>(x0[2], x0[3], b);
       split_pair<3>(x1[0], x1[1], c); split_pair<3>(x1[2], x1[3], d);
@@ -590,15 +593,18 @@ __global__ __launch_bounds__(256) void sig_attn_split_kernel(const float* __rest
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m, mx);
-      const float alpha = expf(m - m_new);
       float ps = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { st[r] = expf(st[r] - m_new); ps += st[r]; }
+      for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - m_new); ps += st[r]; }
       ps += __shfl_xor(ps, 32, 64);
-      l = l * alpha + ps;
-      m = m_new;
+      if (__any(m_new != m)) {      // wave-uniform: once the running max has settled the accumulators need no rescale
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);   // m = -inf on the first chunk -> 0
+        l *= alpha;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      }
+      l += ps;
+      m = m_new;
       // P^T planes straight from the accumulator registers
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
