@@ -32,8 +32,10 @@ __global__ __launch_bounds__(512) void fetch_kernel(const float* __restrict__ A,
 
 int main() {
   const int K = 4096;
-  for (int big = 0; big < 2; ++big) {
-    const int row_tiles = big ? 256 : 2;              // 256 tiles x 4 MB = 1 GB (HBM)  |  2 tiles x 4 MB = 8 MB... L2+MALL
+  const int tiles_list[5] = {2, 8, 24, 48, 256};    // 8 MB (L2), 32 MB (L2 aggregate), 96 MB / 192 MB (Infinity Cache), 1 GB (HBM)
+  for (int ti = 0; ti < 5; ++ti) {
+    const int row_tiles = tiles_list[ti];
+    const int big = ti;
     const size_t elems = (size_t)row_tiles * 256 * K;
     float *A, *out;
     hipMalloc(&A, elems * 4); hipMalloc(&out, 64);
@@ -49,7 +51,7 @@ int main() {
       }
       float ms; hipEventElapsedTime(&ms, e0, e1);
       const double bytes = (double)blocks * steps * 32768;
-      printf("%s pattern=%s : %.1f us, %.2f TB/s total, %.1f GB/s per CU (%.1f B/clk @2.1GHz)\n", big ? "HBM(1GB)" : "L2/MALL(8MB)",
+      printf("working set %4d MB pattern=%s : %.1f us, %.2f TB/s total, %.1f GB/s per CU (%.1f B/clk @2.1GHz)\n", row_tiles * 4,
              pat ? "tile-major" : "row-major ", ms * 1e3, bytes / ms / 1e9, bytes / ms / 1e6 / 256, bytes / ms / 1e6 / 256 / 2.1);
     }
     hipFree(A); hipFree(out);
