@@ -85,7 +85,7 @@ struct SplitGemmArgs {
   int64_t gWsp;               // bytes between groups
 };
 
-template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0, int PFD = 1>
+template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0, int PFD = 1, bool PIPE = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs sa) {
   const GemmArgs& g = sa.g;
   constexpr int NT = WM * WN * 64;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
   const int nk = g.K / 32;
 
   const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
-  static_assert(PFD >= 1 && (DB || PFD == 1), "deep prefetch needs the double-buffered LDS");
+  static_assert(PFD >= 1 && (DB || PFD == 1) && (!PIPE || PFD <= 2), "deep prefetch needs the double-buffered LDS");
   f32x4 ra_[PFD][A_F4];   // PFD tiles in flight in registers (PFD > 1: small-M launches, where one tile's MFMAs are
   f32x4 rb_[PFD][B_PCS];  // far shorter than the L2/HBM latency and one-deep prefetch leaves the CU waiting)
   auto gload_set = [&](int kt, f32x4 (&ra)[A_F4], f32x4 (&rb)[B_PCS]) {
@@ -170,42 +170,50 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int frow = lane & 31, fk = (lane >> 5) * 16;  // byte offset of this lane's 8 bf16 inside a 16-wide K step
+  // Fragments of one 16-wide K step: MI + NI rows x PL planes, one ds_read_b128 each.
+  auto read_frags = [&](int buf, int s, bf16x8 (&af)[MI][PL], bf16x8 (&bf)[NI][PL]) {
+    const unsigned char* Ab = As + (buf * BM + wm * TM + frow) * RS + fk + s * 32;
+    const unsigned char* Bb = Bs + (buf * BN + wn * TN + frow) * RS + fk + s * 32;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int p = 0; p < PL; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * RS + p * 64);
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int p = 0; p < PL; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * RS + p * 64);
+  };
+  auto mma = [&](const bf16x8 (&af)[MI][PL], const bf16x8 (&bf)[NI][PL]) {
+    // smallest cross terms first
+#pragma unroll
+    for (int ord = 2 * (PL - 1); ord >= 0; --ord) {
+      if (ord > PL - 1) continue;  // keep only terms with pa + pb <= PL-1
+#pragma unroll
+      for (int pa = PL - 1; pa >= 0; --pa) {
+        const int pb = ord - pa;
+        if (pb < 0 || pb >= PL) continue;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = mfma_split<FMT>(af[i][pa], bf[j][pb], acc[i][j]);
+      }
+    }
+  };
   auto compute = [&](int buf) {
-    const unsigned char* Ab = As + (buf * BM + wm * TM + frow) * RS + fk;
-    const unsigned char* Bb = Bs + (buf * BN + wn * TN + frow) * RS + fk;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 af[MI][PL], bf[NI][PL];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int p = 0; p < PL; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * RS + p * 64 + s * 32);
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int p = 0; p < PL; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * RS + p * 64 + s * 32);
-      // smallest cross terms first
-#pragma unroll
-      for (int ord = 2 * (PL - 1); ord >= 0; --ord) {
-        if (ord > PL - 1) continue;  // keep only terms with pa + pb <= PL-1
-#pragma unroll
-        for (int pa = PL - 1; pa >= 0; --pa) {
-          const int pb = ord - pa;
-          if (pb < 0 || pb >= PL) continue;
-#pragma unroll
-          for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-              acc[i][j] = mfma_split<FMT>(af[i][pa], bf[j][pb], acc[i][j]);
-        }
-      }
+      read_frags(buf, s, af, bf);
+      mma(af, bf);
     }
   };
 
   gload(0);
   lstore(0);
-  if constexpr (PFD == 1) {
-    if (nk > 1) gload(1);
+  if constexpr (PFD == 1 || PIPE) {
+    if (nk > 1) gload_set(1, ra_[PFD - 1], rb_[PFD - 1]);
+    if constexpr (PIPE && PFD == 2) gload_set(nk > 2 ? 2 : nk - 1, ra_[0], rb_[0]);
     __syncthreads();
     // Registers hold the NEXT tile: it is split and written into the other LDS buffer at the top of the iteration
     // (branch-free) and the registers are immediately refilled with tile kt+2, whose L2/HBM latency is then covered
@@ -213,6 +221,162 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
     // Measured on MI355X (tools/pmc_gemm.sh): this kernel is bound by the ~10-12 B/clk a CU can pull through its
     // L1 (TCP_PENDING_STALL 37 %, TA 21 % busy, L2 hit 80 %), not by the split VALU or the LDS writes -- removing
     // either changes nothing -- so the lever is bytes per MFMA (tile size), not instruction scheduling.
+    if constexpr (DB && PIPE) {
+      // Software pipeline inside the wave, in a FIXED issue order.
+      // Why: the per-tile barrier keeps all waves of the block in the same phase, and the LDS and the texture-address
+      // unit take ~8 / ~16 clocks per 16-byte-per-lane wave instruction with short queues, so a wave that issues its
+      // fragment reads (or its global loads) back to back sits in instruction issue for >1000 clocks while the MFMA
+      // pipe idles (tools/gemm_phase_timing.py: MFMA, LDS and address work ran one after the other, each at full
+      // rate).  Here every MFMA is followed by at most one memory mini-step, pinned with sched_barrier(0):
+      //   first half  (MFMAs of K step 0): ds_reads of step 1, then split + ds_write of tile kt+1   -> barrier
+      //   second half (MFMAs of K step 1): global loads of tile kt+2, then ds_reads of step 0 of tile kt+1
+      bf16x8 af0[MI][PL], bf0[NI][PL], af1[MI][PL], bf1[NI][PL];
+      constexpr int N_TERM = PL * (PL + 1) / 2;
+      constexpr int N_MMA = MI * NI * N_TERM;                // MFMAs per 16-wide K step
+      constexpr int N_FRAG = (MI + NI) * PL;                 // ds_read_b128 per K step
+      constexpr int N_GLD = A_F4 + B_PCS;                    // global loads per tile
+      constexpr int E1 = 2 * A_F4 + B_PCS;                   // first-half store / refill steps
+      // fragment read order = order of first use by the MFMAs (plane PL-1 of A and plane 0 of B first)
+#define FRAG_ORDER(k) (((k) / (MI + NI)) == 0 ? (((k) % (MI + NI)) < MI ? ((k) % (MI + NI)) * PL + (PL - 1) : MI * PL + (((k) % (MI + NI)) - MI) * PL) \
+                     : ((k) / (MI + NI)) == PL - 1 ? (((k) % (MI + NI)) < MI ? ((k) % (MI + NI)) * PL : MI * PL + (((k) % (MI + NI)) - MI) * PL + (PL - 1)) \
+                     : (((k) % (MI + NI)) < MI ? ((k) % (MI + NI)) * PL + 1 : MI * PL + (((k) % (MI + NI)) - MI) * PL + 1))
+      // cross terms, smallest first: (pa, pb) with pa + pb descending
+      constexpr int TPA[6] = {PL == 3 ? 2 : 1, PL == 3 ? 1 : 0, 0, 1, 0, 0};
+      constexpr int TPB[6] = {0, 1, PL == 3 ? 2 : 0, 0, 1, 0};
+#ifdef LT_GEMM_DEBUG_SKIP   // debug builds (tools/gemm_skip_sweep.sh): bit mask of components compiled out of the main loop
+      constexpr int dbg_mode = LT_GEMM_DEBUG_SKIP;
+#else
+      constexpr int dbg_mode = 0;
+#endif
+      auto step_mma = [&](int m, const bf16x8 (&af)[MI][PL], const bf16x8 (&bf)[NI][PL]) {
+        if (dbg_mode & 8) return;
+        const int t = m / (MI * NI), ij = m % (MI * NI), i = ij / NI, j = ij % NI;
+        acc[i][j] = mfma_split<FMT>(af[i][TPA[t]], bf[j][TPB[t]], acc[i][j]);
+      };
+      // Fragment k of a K step, in the order the MFMAs consume them (lowest planes last).
+      auto step_read = [&](int k, int buf, int s, bf16x8 (&af)[MI][PL], bf16x8 (&bf)[NI][PL]) {
+        if (dbg_mode & 32) return;
+        const unsigned char* Ab = As + (buf * BM + wm * TM + frow) * RS + fk + s * 32;
+        const unsigned char* Bb = Bs + (buf * BN + wn * TN + frow) * RS + fk + s * 32;
+        if (k < MI * PL) { const int i = k / PL, pp = k % PL; af[i][pp] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * RS + pp * 64); }
+        else { const int q = k - MI * PL, j = q / PL, pp = q % PL; bf[j][pp] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * RS + pp * 64); }
+      };
+      auto step_gload = [&](int u, int kt, f32x4 (&ra)[A_F4], f32x4 (&rb)[B_PCS]) {
+        if (dbg_mode & 2) return;
+        if (dbg_mode & 1) {
+          if (u < A_F4) ra[u] = *reinterpret_cast<const f32x4*>(A + (int64_t)(lrow + u * (NT / 8)) * g.lda + lc4);
+          else { const int pq = tid + (u - A_F4) * NT; rb[u - A_F4] = *reinterpret_cast<const f32x4*>(Wsp + (int64_t)(pq / (PL * 4)) * nk * (PL * 64) + (pq % (PL * 4)) * 16); }
+          return;
+        }
+        if (u < A_F4) {
+          const int k0 = kt * 32;
+          const float* src = A; int ld = g.lda; int kk = k0;
+          if (k0 >= K1) { src = A2; ld = g.lda2; kk = k0 - K1; }
+          int r = m0 + lrow + u * (NT / 8);
+          r = r < g.M ? r : g.M - 1;
+          ra[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)r * ld + kk + lc4);
+        } else {
+          const int pq = tid + (u - A_F4) * NT;
+          const int r = pq / (PL * 4), pc = pq % (PL * 4);
+          rb[u - A_F4] = *reinterpret_cast<const f32x4*>(Wsp + ((int64_t)(n0 + r) * nk + kt) * (PL * 64) + pc * 16);
+        }
+      };
+      auto step_store = [&](int u, int buf, const f32x4 (&ra)[A_F4], const f32x4 (&rb)[B_PCS]) {
+        if (dbg_mode & 4) return;
+        if (u < A_F4) {
+          unsigned a[PL], b[PL];
+          if (dbg_mode & 64) {   // debug: ds_writes without the split VALU
+#pragma unroll
+            for (int pp = 0; pp < PL; ++pp) { a[pp] = __builtin_bit_cast(unsigned, ra[u][pp & 1]); b[pp] = __builtin_bit_cast(unsigned, ra[u][2 + (pp & 1)]); }
+          } else {
+            split_pair<PL, FMT>(ra[u][0], ra[u][1], a);
+            split_pair<PL, FMT>(ra[u][2], ra[u][3], b);
+          }
+          unsigned char* dst = As + (buf * BM + lrow + u * (NT / 8)) * RS + lc4 * 2;
+#pragma unroll
+          for (int pp = 0; pp < PL; ++pp) *reinterpret_cast<u32x2*>(dst + pp * 64) = u32x2{a[pp], b[pp]};
+        } else {
+          const int pq = tid + (u - A_F4) * NT;
+          const int r = pq / (PL * 4), pc = pq % (PL * 4);
+          *reinterpret_cast<f32x4*>(Bs + (buf * BN + r) * RS + pc * 16) = rb[u - A_F4];
+        }
+      };
+      // Slot assignment.  tools/gemm_skip_sweep.sh (components compiled out one at a time, bf16x6 8192x4096x4096):
+      // MFMAs + barrier alone run at 2.07 PF; the fragment reads add 39 % to that, the global loads + LDS stores 31 %
+      // (almost all of it the vmcnt waits in front of the stores), the split VALU 4 %, the barrier 1 %.  The spans
+      // below say over which part of a half the LDS instructions are spread; PFD is how many tiles ahead the global
+      // loads run (register sets).
+#ifndef LT_RSPAN_PCT
+#define LT_RSPAN_PCT 100   // measured: spreading over the whole half (100/100) beats front-loading (50/75) by 1-2 %
+#endif
+#ifndef LT_SSPAN_PCT
+#define LT_SSPAN_PCT 100
+#endif
+      constexpr int R_SPAN = (N_MMA * LT_RSPAN_PCT / 100) > N_FRAG ? (N_MMA * LT_RSPAN_PCT / 100) : N_FRAG;
+      constexpr int S_SPAN = N_MMA * LT_SSPAN_PCT / 100;
+      // first half of tile kt: MFMAs of K step 0.  Memory stream 1: fragment reads of step 1.  Stream 2: for every
+      // staged register, split + ds_write (tile kt+1) followed one step later by its refill (tile kt+1+PFD).
+      auto first_half = [&](int kt, f32x4 (&ra)[A_F4], f32x4 (&rb)[B_PCS]) {
+        const int buf = kt & 1;
+        const int ktn = kt + 1 + PFD < nk ? kt + 1 + PFD : nk - 1;   // branch-free tail: reloads the last tile (never consumed)
+#pragma unroll
+        for (int m = 0; m < N_MMA; ++m) {
+          step_mma(m, af0, bf0);
+#pragma unroll
+          for (int k = 0; k < N_FRAG; ++k)
+            if (k * R_SPAN / N_FRAG == m) step_read(FRAG_ORDER(k), buf, 1, af1, bf1);
+#pragma unroll
+          for (int e = 0; e < E1; ++e)
+            if ((2 * e + 1) * S_SPAN / (2 * E1) == m) {
+              if (e < 2 * A_F4) { if (e % 2 == 0) step_store(e / 2, buf ^ 1, ra, rb); else step_gload(e / 2, ktn, ra, rb); }
+              else step_store(A_F4 + (e - 2 * A_F4), buf ^ 1, ra, rb);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      // second half: MFMAs of K step 1; fragment reads of step 0 of tile kt+1 and the refill of the W registers
+      auto second_half = [&](int kt, f32x4 (&ra)[A_F4], f32x4 (&rb)[B_PCS]) {
+        const int buf = kt & 1;
+        const int ktn = kt + 1 + PFD < nk ? kt + 1 + PFD : nk - 1;
+#pragma unroll
+        for (int m = 0; m < N_MMA; ++m) {
+          step_mma(m, af1, bf1);
+#pragma unroll
+          for (int k = 0; k < N_FRAG; ++k)
+            if (k * R_SPAN / N_FRAG == m) step_read(FRAG_ORDER(k), buf ^ 1, 0, af0, bf0);
+#pragma unroll
+          for (int e = 0; e < B_PCS; ++e)
+            if ((2 * e + 1) * N_MMA / (2 * B_PCS) == m) step_gload(A_F4 + e, ktn, ra, rb);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      // (A rotated body [barrier | second half | first half of the next tile] makes the compiler's lgkmcnt waits exact
+      // at the loop header but costs a peeled prologue/epilogue: same speed at K = 4096, 12 % slower at K = 128.)
+#pragma unroll
+      for (int k = 0; k < N_FRAG; ++k) step_read(FRAG_ORDER(k), 0, 0, af0, bf0);
+      if constexpr (PFD == 1) {
+        for (int kt = 0; kt < nk; ++kt) {
+          first_half(kt, ra_[0], rb_[0]);
+          if (!(dbg_mode & 16)) __syncthreads();   // tile kt+1 visible; every wave holds its step-1 fragments of tile kt
+          __builtin_amdgcn_sched_barrier(0);
+          second_half(kt, ra_[0], rb_[0]);
+        }
+      } else {
+        // two register sets: set 1 holds odd tiles, set 0 even tiles; tile kt+1 is stored while tile kt+3 is requested
+        for (int kt = 0; kt < nk; kt += 2) {
+          first_half(kt, ra_[1], rb_[1]);
+          __syncthreads();
+          __builtin_amdgcn_sched_barrier(0);
+          second_half(kt, ra_[1], rb_[1]);
+          if (kt + 1 < nk) {
+            first_half(kt + 1, ra_[0], rb_[0]);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            second_half(kt + 1, ra_[0], rb_[0]);
+          }
+        }
+      }
+    } else
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = DB ? (kt & 1) : 0;
       if (DB) {
@@ -273,17 +437,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
   }
 }
 
-template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0, int PFD = 1>
+template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0, int PFD = 1, bool PIPE = false>
 inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t st) {
   constexpr size_t lds = (size_t)(DB ? 2 : 1) * (BM + BN) * (PL * 64 + 16);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT, PFD>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT, PFD, PIPE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   dim3 grid((sa.g.N / BN) * cdiv(sa.g.M, BM), groups);
-  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT, PFD>), grid, dim3(WM * WN * 64), lds, st, sa);
+  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT, PFD, PIPE>), grid, dim3(WM * WN * 64), lds, st, sa);
 }
 
 // Tile choice: 8-wave 256x128 blocks (2 waves/SIMD inside one block, half the LDS staging per MFMA) once
@@ -291,7 +455,8 @@ inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t
 inline const char* split_tile_name(const GemmArgs& g, int groups) {
   if (g.N % 128 != 0) return "128x64";
   const int64_t t256 = (int64_t)cdiv(g.M, 256) * (g.N / 128) * groups;
-  if (t256 >= 192) return "256x128";
+  // same block size either way; 128x256 halves the A rows a block has to split per MFMA (+2-4 % measured)
+  if (t256 >= 192) return g.N % 256 == 0 ? "128x256" : "256x128";
   const int64_t t128 = (int64_t)cdiv(g.M, 128) * (g.N / 128) * groups;
   if (t128 >= 256) return "128x128";
   // small problems (single pair: M ~ 400): latency-bound -> more, smaller blocks with a deep register prefetch
@@ -308,7 +473,12 @@ inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st
   static const char* tile_env = getenv("LINETR_GEMM_TILE");  // tuning aid: force a tile
   const char* tile = tile_env ? tile_env : split_tile_name(g, groups);
   if (g.N % 128 != 0 || !strcmp(tile, "128x64")) gemm_split_launch_t<128, 64, 4, 1, PL, true, FMT>(sa, groups, st);
-  else if (!strcmp(tile, "256x128")) gemm_split_launch_t<256, 128, 4, 2, PL, true, FMT>(sa, groups, st);
+  else if (!strcmp(tile, "256x128")) {
+    static const bool nopipe = getenv("LINETR_GEMM_NOPIPE") != nullptr;   // tuning aid: the pre-pipelining main loop
+    if (nopipe) gemm_split_launch_t<256, 128, 4, 2, PL, true, FMT>(sa, groups, st);
+    else gemm_split_launch_t<256, 128, 4, 2, PL, true, FMT, 1, true>(sa, groups, st);
+  }
+  else if (!strcmp(tile, "128x256") && g.N % 256 == 0) gemm_split_launch_t<128, 256, 2, 4, PL, true, FMT, PL == 3 ? 2 : 1, true>(sa, groups, st);
   else if (!strcmp(tile, "128x128")) gemm_split_launch_t<128, 128, 2, 2, PL, true, FMT>(sa, groups, st);
   else if (PL == 2 && !strcmp(tile, "256x256") && g.N % 256 == 0) gemm_split_launch_t<256, 256, 4, 2, 2, true, FMT>(sa, groups, st);
   else if (!strcmp(tile, "64x64")) gemm_split_launch_t<64, 64, 2, 2, PL, true, FMT, 4>(sa, groups, st);
