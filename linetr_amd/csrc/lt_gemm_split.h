@@ -218,16 +218,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
     // Registers hold the NEXT tile: it is split and written into the other LDS buffer at the top of the iteration
     // (branch-free) and the registers are immediately refilled with tile kt+2, whose L2/HBM latency is then covered
     // by this iteration's MFMAs.
-    // Measured on MI355X (tools/pmc_gemm.sh): this kernel is bound by the ~10-12 B/clk a CU can pull through its
-    // L1 (TCP_PENDING_STALL 37 %, TA 21 % busy, L2 hit 80 %), not by the split VALU or the LDS writes -- removing
-    // either changes nothing -- so the lever is bytes per MFMA (tile size), not instruction scheduling.
+    // Measured on MI355X (tools/gemm_clock_probe.py): the 8-wave kernels run at the 1400 W package power cap
+    // (shader clock throttled to ~1.7 GHz), so what counts is energy per MFMA; see DESIGN.md 4.1.
     if constexpr (DB && PIPE) {
       // Software pipeline inside the wave, in a FIXED issue order.
-      // Why: the per-tile barrier keeps all waves of the block in the same phase, and the LDS and the texture-address
-      // unit take ~8 / ~16 clocks per 16-byte-per-lane wave instruction with short queues, so a wave that issues its
-      // fragment reads (or its global loads) back to back sits in instruction issue for >1000 clocks while the MFMA
-      // pipe idles (tools/gemm_phase_timing.py: MFMA, LDS and address work ran one after the other, each at full
-      // rate).  Here every MFMA is followed by at most one memory mini-step, pinned with sched_barrier(0):
+      // Why: the per-tile barrier keeps all waves of the block in the same phase, so "all fragment reads, wait, all
+      // MFMAs, all stores, all loads" makes 8 waves hit the LDS, then the matrix pipe, then the address unit together
+      // and every s_waitcnt in front of a cluster stalls in-order issue (no MFMAs either).  Here every MFMA is
+      // followed by at most one memory mini-step, pinned with sched_barrier(0) (+8-11 % in same-box A/B runs):
       //   first half  (MFMAs of K step 0): ds_reads of step 1, then split + ds_write of tile kt+1   -> barrier
       //   second half (MFMAs of K step 1): global loads of tile kt+2, then ds_reads of step 0 of tile kt+1
       bf16x8 af0[MI][PL], bf0[NI][PL], af1[MI][PL], bf1[NI][PL];
