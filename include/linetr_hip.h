@@ -215,6 +215,19 @@ int linetr_match_points(LinetrHandle* h, const float* d_desc0_cn, int32_t n0, co
                         int32_t n1, float nn_thresh, int32_t mutual, float* d_dist, int32_t* d_match01,
                         void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- dense-map producer (section 8(f) "next" row 2) ------------------------------------------------- */
+
+/* Post-processing of SuperPoint's two heads, fused with the layout change the tokeniser needs; replaces
+ *   models/superpoint.py:161-167  scores = softmax(convPb(.), 1)[:, :-1]; permute/reshape to [B, 8Hc, 8Wc]
+ *   models/superpoint.py:190-193  dense_descriptor = F.normalize(convDb(.), p=2, dim=1)
+ * d_score_logits [B,65,Hc,Wc] and d_desc_raw [B,256,Hc,Wc] are the raw convPb / convDb outputs (float32, NCHW,
+ * contiguous).  Outputs (any may be NULL): d_dense_score [B,8Hc,8Wc]; d_dense_desc_nhwc [B,Hc,Wc,256] -- pass it
+ * to linetr_describe with dense_is_nhwc = 1 and the NCHW->NHWC pass disappears; d_dense_desc_nchw [B,256,Hc,Wc],
+ * the reference's 'dense_descriptor' layout.  `h` may be NULL (no weights involved; current HIP device). */
+int linetr_superpoint_heads(LinetrHandle* h, const float* d_score_logits, const float* d_desc_raw, int32_t B,
+                            int32_t Hc, int32_t Wc, float* d_dense_score, float* d_dense_desc_nhwc,
+                            float* d_dense_desc_nchw, void* stream);
+
 /* ---- arithmetic mode of the dense contractions ----------------------------------------------------- */
 
 /* All Linear/Conv1d(k=1) contractions run on one of three MFMA paths (fp32 in, fp32 accumulate, fp32 out):

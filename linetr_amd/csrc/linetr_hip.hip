@@ -12,6 +12,7 @@
 #include "lt_gemm_dma.h"
 #include "lt_match.h"
 #include "lt_model.h"
+#include "lt_producer.h"
 #include "lt_token.h"
 
 using namespace lt;
@@ -1131,6 +1132,32 @@ extern "C" int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_
                      (const int*)(base + o_id1), d_dist, thr, mutual, (float*)(base + o_dk), d_match01, (int*)(base + o_scr));
   LT_LAUNCH_CHECK();
   LT_HIP(hipStreamSynchronize(st));
+  return LINETR_OK;
+}
+
+extern "C" int linetr_superpoint_heads(LinetrHandle* h, const float* d_score_logits, const float* d_desc_raw, int32_t B,
+                                       int32_t Hc, int32_t Wc, float* d_dense_score, float* d_dense_desc_nhwc,
+                                       float* d_dense_desc_nchw, void* stream) {
+  if (B < 0 || Hc <= 0 || Wc <= 0) return fail(LINETR_E_ARG, "superpoint_heads: bad shape B=%d Hc=%d Wc=%d", B, Hc, Wc);
+  if (d_dense_score && !d_score_logits) return fail(LINETR_E_ARG, "superpoint_heads: score output without score logits");
+  if ((d_dense_desc_nhwc || d_dense_desc_nchw) && !d_desc_raw)
+    return fail(LINETR_E_ARG, "superpoint_heads: descriptor output without the raw descriptor head");
+  if (B == 0) return LINETR_OK;
+  if (h) LT_HIP(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int HW = Hc * Wc;
+  const dim3 grid((unsigned)cdiv(HW, 64), (unsigned)B);
+  if (d_dense_desc_nhwc || d_dense_desc_nchw) {
+    const double by = (double)B * HW * D * 4.0 * (1 + (d_dense_desc_nhwc ? 1 : 0) + (d_dense_desc_nchw ? 1 : 0));
+    ProfScope ps(h, st, "sp_desc_head", 3.0 * B * HW * D, by);
+    hipLaunchKernelGGL(sp_desc_head_kernel, grid, dim3(256), 0, st, d_desc_raw, d_dense_desc_nhwc, d_dense_desc_nchw, HW);
+    LT_LAUNCH_CHECK();
+  }
+  if (d_dense_score) {
+    ProfScope ps(h, st, "sp_score_head", 0, (double)B * HW * (65 + 64) * 4.0);
+    hipLaunchKernelGGL(sp_score_head_kernel, grid, dim3(256), 0, st, d_score_logits, d_dense_score, Hc, Wc);
+    LT_LAUNCH_CHECK();
+  }
   return LINETR_OK;
 }
 

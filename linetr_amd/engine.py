@@ -95,6 +95,22 @@ class Engine:
         self._L = L
         self._ws = {}
 
+    @classmethod
+    def heads_only(cls, device="cuda:0"):
+        """An Engine without a LineTR model: only the weight-free entry points work (superpoint_heads, match_points,
+        match_distmat).  Used by FusedHeadSuperPoint when no LineTransformer engine is at hand."""
+        self = cls.__new__(cls)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("linetr_amd.Engine needs a HIP device (torch device 'cuda:N'); there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.cfg = dict(DEFAULT_MODEL)
+        self._L = nat.lib()
+        self._h = None
+        self._ws = {}
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.linetr_destroy(self._h)
@@ -439,6 +455,34 @@ class Engine:
                                               int(bool(mutual)), dist.data_ptr(), m01.data_ptr(), ws.data_ptr(),
                                               ws.numel(), self._stream()))
         return dist, m01
+
+    def superpoint_heads(self, score_logits: torch.Tensor = None, desc_raw: torch.Tensor = None, *, nhwc=True,
+                         nchw=False):
+        """Fused SuperPoint head post-processing (models/superpoint.py:161-167, 190-193).
+
+        score_logits [B,65,Hc,Wc] (convPb output) -> dense_score [B,8Hc,8Wc];
+        desc_raw [B,256,Hc,Wc] (convDb output) -> L2-normalised descriptors as [B,Hc,Wc,256] (`nhwc`, the layout
+        `describe_lines(..., dense_layout='nhwc')` consumes without a transposition pass) and/or [B,256,Hc,Wc]
+        (`nchw`, the reference's 'dense_descriptor').  Returns (dense_score, desc_nhwc, desc_nchw), None where not
+        requested."""
+        sl = self._f32(score_logits) if score_logits is not None else None
+        dr = self._f32(desc_raw) if desc_raw is not None else None
+        ref = sl if sl is not None else dr
+        if ref is None:
+            raise ValueError("superpoint_heads needs at least one head")
+        B, _, Hc, Wc = (int(v) for v in ref.shape)
+        if sl is not None and tuple(sl.shape) != (B, 65, Hc, Wc):
+            raise ValueError(f"score_logits must be [B,65,Hc,Wc], got {tuple(sl.shape)}")
+        if dr is not None and tuple(dr.shape) != (B, D, Hc, Wc):
+            raise ValueError(f"desc_raw must be [B,{D},Hc,Wc], got {tuple(dr.shape)}")
+        score = torch.empty((B, Hc * 8, Wc * 8), dtype=torch.float32, device=self.device) if sl is not None else None
+        o_nhwc = torch.empty((B, Hc, Wc, D), dtype=torch.float32, device=self.device) if (dr is not None and nhwc) else None
+        o_nchw = torch.empty((B, D, Hc, Wc), dtype=torch.float32, device=self.device) if (dr is not None and nchw) else None
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(self.device):     # a heads-only engine has no handle: the current device is used
+            nat.check(self._L.linetr_superpoint_heads(self._h, ptr(sl), ptr(dr), B, Hc, Wc, ptr(score), ptr(o_nhwc),
+                                                      ptr(o_nchw), self._stream()))
+        return score, o_nhwc, o_nchw
 
     PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}
 

@@ -217,3 +217,26 @@ def calibrated_state_dict(n_desc_layers: int = 1) -> "OrderedDict[str, np.ndarra
             assert k in sd and sd[k].shape == cal[k].shape, k
             sd[k] = cal[k].astype(np.float32)
     return sd
+
+
+# ---- SuperPoint (only for the fused head producer) -------------------------
+
+SUPERPOINT_LAYERS = (  # name, out channels, in channels, kernel   (models/superpoint.py:117-134)
+    ("conv1a", 64, 1, 3), ("conv1b", 64, 64, 3), ("conv2a", 64, 64, 3), ("conv2b", 64, 64, 3),
+    ("conv3a", 128, 64, 3), ("conv3b", 128, 128, 3), ("conv4a", 128, 128, 3), ("conv4b", 128, 128, 3),
+    ("convPa", 256, 128, 3), ("convPb", 65, 256, 1), ("convDa", 256, 128, 3), ("convDb", 256, 256, 1),
+)
+
+
+def superpoint_state_dict(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """Seeded SuperPoint weights in the reference's state_dict layout (the authors' blob is not redistributable
+    here).  He-scaled normals keep activations O(1); the score head gets a larger gain so the softmax is peaked
+    enough for some cells to pass the 0.005 keypoint threshold."""
+    rs = np.random.RandomState(1234 + seed)
+    sd = OrderedDict()
+    for name, co, ci, k in SUPERPOINT_LAYERS:
+        gain = 3.0 if name == "convPb" else 1.0
+        std = gain * math.sqrt(2.0 / (ci * k * k))
+        sd[name + ".weight"] = (rs.standard_normal((co, ci, k, k)) * std).astype(np.float32)
+        sd[name + ".bias"] = (rs.standard_normal(co) * 0.05).astype(np.float32)
+    return sd

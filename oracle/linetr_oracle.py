@@ -20,6 +20,7 @@ Stages (reference file:line):
   tokenize             models/line_process.py:100-196   line_tokenizer
   sample_token_desc    models/line_process.py:86-98     sample_descriptors
   preprocess           models/line_transformer.py:251-275
+  superpoint_heads     models/superpoint.py:161-167, 190-193   (8(f) row 2: dense score / dense descriptor producer)
   forward              models/line_transformer.py:225-249 (+ :22-183, models/line_attention.py)
   dist_matrix          models/line_process.py:198-201   get_dist_matrix
   subline2keyline      models/line_transformer.py:277-282
@@ -350,3 +351,22 @@ def point_nn(desc0: np.ndarray, desc1: np.ndarray, thr=0.8, mutual=True):
     """nn_matcher.py:33-42 (point matcher, the section-8(f) 'next' row)."""
     dm = (2.0 - 2.0 * (desc0.T @ desc1)).clip(min=0)[None]
     return mutual_nn(dm, thr, mutual), dm
+
+
+# ---- SuperPoint head post-processing (SURVEY.md 8(f) row 2) -------------------------------------
+
+def superpoint_heads(score_logits, desc_raw):
+    """models/superpoint.py:161-167 and :190-193, stock PyTorch-CPU fp32 ops.
+
+    score_logits [B,65,Hc,Wc] (convPb output) -> dense_score [B,8Hc,8Wc]: softmax over the 65 channels, dustbin
+    (last channel) dropped, channel c = 8*dy + dx moved to pixel (8h+dy, 8w+dx).
+    desc_raw [B,256,Hc,Wc] (convDb output) -> dense_descriptor [B,256,Hc,Wc] = x / max(||x||_2, 1e-12) over channels.
+    """
+    import torch
+    sl = torch.as_tensor(np.asarray(score_logits, dtype=np.float32))
+    dr = torch.as_tensor(np.asarray(desc_raw, dtype=np.float32))
+    p = torch.softmax(sl, 1)[:, :-1]
+    b, _, h, w = p.shape
+    p = p.permute(0, 2, 3, 1).reshape(b, h, w, 8, 8).permute(0, 1, 3, 2, 4).reshape(b, h * 8, w * 8)
+    d = torch.nn.functional.normalize(dr, p=2, dim=1)
+    return p.numpy(), d.numpy()

@@ -19,15 +19,17 @@ import types
 
 sys.dont_write_bytecode = True
 sys.modules.setdefault("cv2", types.ModuleType("cv2"))  # imported at line_process.py:2, never called
-sys.path.insert(0, "/root/reference")
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))   # linetr_amd (seeded inputs / weights)
+sys.path.insert(0, "/root/reference")   # FIRST on the path: `models` must be the reference's package, not this repo's shim
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 torch.set_grad_enabled(False)
 
+import models as _ref_models  # noqa: E402
+assert _ref_models.__file__.startswith("/root/reference/"), _ref_models.__file__
 from models.line_transformer import LineTransformer  # noqa: E402  (reference)
 from models.nn_matcher import nn_matcher_distmat, nn_matcher  # noqa: E402  (reference)
 from models.line_process import get_dist_matrix  # noqa: E402  (reference)

@@ -1,0 +1,198 @@
+"""GPU: the fused SuperPoint-head producer through the C ABI, against the oracle, the fixture
+frozen from the real reference, and size-independent properties at the bench sizes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from linetr_amd import synth
+from oracle import linetr_oracle as O
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "superpoint_heads.npz")
+SCORE_TOL = 2e-7      # probabilities <= 1: exp / sum in fp32, summation order differs from torch's
+DESC_TOL = 2e-7       # unit vectors: 1/sqrt(sum of 256 squares), summation order differs
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from linetr_amd.engine import Engine
+    return Engine.heads_only("cuda:0")
+
+
+def run(eng, sl, dr, **kw):
+    s, a, b = eng.superpoint_heads(torch.from_numpy(sl).cuda() if sl is not None else None,
+                                   torch.from_numpy(dr).cuda() if dr is not None else None, **kw)
+    torch.cuda.synchronize()
+    return tuple(None if t is None else t.cpu().numpy() for t in (s, a, b))
+
+
+def test_golden_from_reference(eng):
+    g = np.load(GOLD)
+    score, nhwc, nchw = run(eng, g["score_logits"], g["desc_raw"], nhwc=True, nchw=True)
+    assert score.shape == (2, 64, 96) and nhwc.shape == (2, 8, 12, 256) and nchw.shape == (2, 256, 8, 12)
+    assert np.abs(score - g["dense_score"]).max() <= SCORE_TOL
+    assert np.abs(nchw - g["dense_descriptor"]).max() <= DESC_TOL
+    assert np.array_equal(nhwc, nchw.transpose(0, 2, 3, 1))          # the two layouts carry the same bits
+
+
+@pytest.mark.parametrize("B,Hc,Wc", [(3, 60, 80), (1, 7, 9), (2, 5, 13), (1, 1, 1), (2, 120, 160)])
+def test_vs_oracle_shapes(eng, B, Hc, Wc):
+    """cfg2/cfg3 (60x80) and cfg5 (120x160) map sizes, plus ragged ones: HW not a multiple of 4 or 64 (tail blocks,
+    scalar path), a single cell."""
+    rs = np.random.RandomState(B * 1000 + Hc * 10 + Wc)
+    sl = (rs.standard_normal((B, 65, Hc, Wc)) * 3).astype(np.float32)
+    dr = (rs.standard_normal((B, 256, Hc, Wc)) * rs.uniform(0.01, 30, size=(B, 1, Hc, Wc))).astype(np.float32)
+    want_s, want_d = O.superpoint_heads(sl, dr)
+    score, nhwc, nchw = run(eng, sl, dr, nhwc=True, nchw=True)
+    assert np.abs(score - want_s).max() <= SCORE_TOL
+    assert np.abs(nchw - want_d).max() <= DESC_TOL
+    assert np.array_equal(nhwc, nchw.transpose(0, 2, 3, 1))
+
+
+def test_edge_values(eng):
+    """all-zero descriptor (F.normalize's eps branch -> zeros, no NaN), huge logits (softmax must not overflow),
+    one dominant channel, dominant dustbin."""
+    sl = np.zeros((1, 65, 2, 4), np.float32)
+    sl[0, :, 0, 0] = 80.0                     # uniform but huge
+    sl[0, 5, 0, 1] = 90.0                     # one-hot at channel 5 -> pixel (dy=0, dx=5) of cell (0,1)
+    sl[0, 64, 0, 2] = 50.0                    # dustbin wins -> the whole patch ~0
+    sl[0, :, 1, :] = -1e4                     # uniform very negative
+    dr = np.zeros((1, 256, 2, 4), np.float32)
+    dr[0, 3, 0, 1] = 1e-20                    # below eps: x / 1e-12
+    dr[0, :, 1, 2] = 1e18                     # sum of squares 2.56e38, just inside fp32; exact answer 1/16
+    want_s, want_d = O.superpoint_heads(sl, dr)
+    score, nhwc, nchw = run(eng, sl, dr, nhwc=True, nchw=True)
+    assert np.isfinite(score).all() and np.isfinite(nchw).all()
+    assert np.abs(score - want_s).max() <= SCORE_TOL
+    assert np.allclose(nchw, want_d, rtol=5e-6, atol=0)      # torch's own norm is 1.1e-6 off the exact 1/16 here
+    assert abs(nchw[0, 0, 1, 2] - 0.0625) < 1e-7
+    assert abs(score[0, 0, 8 + 5] - 1.0) < 1e-6 and score[0, :8, 16:24].max() < 1e-20
+
+
+def test_partial_outputs_and_errors(eng):
+    rs = np.random.RandomState(3)
+    sl = rs.standard_normal((2, 65, 4, 8)).astype(np.float32)
+    dr = rs.standard_normal((2, 256, 4, 8)).astype(np.float32)
+    s, a, b = run(eng, sl, None)
+    assert s is not None and a is None and b is None
+    s, a, b = run(eng, None, dr, nhwc=False, nchw=True)
+    assert s is None and a is None and b.shape == (2, 256, 4, 8)
+    with pytest.raises(ValueError):
+        eng.superpoint_heads(torch.zeros(1, 64, 4, 8).cuda(), None)
+    with pytest.raises(ValueError):
+        eng.superpoint_heads(None, None)
+    s, a, b = eng.superpoint_heads(torch.zeros(0, 65, 4, 8).cuda(), torch.zeros(0, 256, 4, 8).cuda())   # empty batch
+    assert s.shape == (0, 32, 64) and a.shape == (0, 4, 8, 256)
+
+
+def test_properties_at_bench_size(eng):
+    """cfg3 batch (128 images of 480x640): patch sums + dustbin = 1, unit norms, layouts identical."""
+    B, Hc, Wc = 128, 60, 80
+    g = torch.Generator(device="cuda").manual_seed(5)
+    sl = torch.randn(B, 65, Hc, Wc, device="cuda", generator=g) * 2
+    dr = torch.randn(B, 256, Hc, Wc, device="cuda", generator=g)
+    score, nhwc, nchw = eng.superpoint_heads(sl, dr, nhwc=True, nchw=True)
+    p_dust = torch.softmax(sl, 1)[:, 64]
+    patch = score.reshape(B, Hc, 8, Wc, 8).sum(dim=(2, 4))
+    assert (patch + p_dust - 1).abs().max().item() < 5e-6
+    assert (nhwc.norm(dim=-1) - 1).abs().max().item() < 1e-6
+    assert torch.equal(nhwc, nchw.permute(0, 2, 3, 1))
+
+
+def test_describe_from_producer_layout_is_identical():
+    """The NHWC map handed straight to linetr_describe gives bit-identical line descriptors to the NCHW map that goes
+    through the library's own transposition pass."""
+    from linetr_amd.engine import Engine
+    eng = Engine(synth.calibrated_state_dict(), "cuda:0")
+    B = 4
+    lines = [synth.synth_lines(50 + i, 60) for i in range(B)]
+    offsets = np.cumsum([0] + [len(l) for l in lines]).astype(np.int32)
+    lines6 = np.concatenate(lines)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    dr = torch.randn(B, 256, 60, 80, device="cuda", generator=g)
+    sl = torch.randn(B, 65, 60, 80, device="cuda", generator=g)
+    score, nhwc, nchw = eng.superpoint_heads(sl, dr, nhwc=True, nchw=True)
+    kw = dict(remove_borders=8, min_length=16, max_keylines=-1, token_distance=8, max_tokens=21)
+    _, d_a = eng.describe_lines(lines6, offsets, nchw, score, **kw)
+    _, d_b = eng.describe_lines(lines6, offsets, nhwc, score, dense_layout="nhwc", **kw)
+    assert d_a.shape[0] > 0 and torch.equal(d_a, d_b)
+
+
+class _Helpers:
+    """Key-point helpers for the stand-in SuperPoint below, written from the published SuperPoint post-processing
+    (max-pool NMS, border removal, top-k, bilinear descriptor sampling): test scaffolding, not product code."""
+
+    @staticmethod
+    def simple_nms(scores, r):
+        mp = lambda x: torch.nn.functional.max_pool2d(x, kernel_size=r * 2 + 1, stride=1, padding=r)
+        zeros = torch.zeros_like(scores)
+        max_mask = scores == mp(scores)
+        for _ in range(2):
+            supp_mask = mp(max_mask.float()) > 0
+            supp_scores = torch.where(supp_mask, zeros, scores)
+            new_max_mask = supp_scores == mp(supp_scores)
+            max_mask = max_mask | (new_max_mask & (~supp_mask))
+        return torch.where(max_mask, scores, zeros)
+
+    @staticmethod
+    def remove_borders(k, s, b, h, w):
+        m = (k[:, 0] >= b) & (k[:, 0] < h - b) & (k[:, 1] >= b) & (k[:, 1] < w - b)
+        return k[m], s[m]
+
+    @staticmethod
+    def top_k_keypoints(k, s, n):
+        if n >= len(k):
+            return k, s
+        s, idx = torch.topk(s, n, dim=0)
+        return k[idx], s
+
+    @staticmethod
+    def sample_descriptors(kp, desc, s=8):
+        b, c, h, w = desc.shape
+        kp = kp - s / 2 + 0.5
+        kp = kp / torch.tensor([(w * s - s / 2 - 0.5), (h * s - s / 2 - 0.5)]).to(kp)[None]
+        kp = kp * 2 - 1
+        d = torch.nn.functional.grid_sample(desc, kp.view(b, 1, -1, 2), mode="bilinear", align_corners=True)
+        return torch.nn.functional.normalize(d.reshape(b, c, -1), p=2, dim=1)
+
+
+class _StandInSuperPoint(nn.Module):
+    """Same layer names / shapes as the reference's SuperPoint (synth.SUPERPOINT_LAYERS), so its state_dict loads."""
+
+    def __init__(self):
+        super().__init__()
+        self.config = {"descriptor_dim": 256, "nms_radius": 4, "keypoint_threshold": 0.005, "max_keypoints": -1,
+                       "remove_borders": 4}
+        self.relu = nn.ReLU(inplace=True)
+        self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
+        for name, co, ci, k in synth.SUPERPOINT_LAYERS:
+            setattr(self, name, nn.Conv2d(ci, co, kernel_size=k, stride=1, padding=k // 2))
+
+
+def test_wrapper_reproduces_reference_forward():
+    """FusedHeadSuperPoint around a SuperPoint with the fixture's seeded weights returns the reference's dict: dense
+    maps within conv-rounding distance of the CPU run frozen in the fixture, same key points."""
+    from linetr_amd.superpoint import FusedHeadSuperPoint
+    g = np.load(GOLD)
+    sp = _StandInSuperPoint()
+    sp.load_state_dict({k: torch.from_numpy(v) for k, v in synth.superpoint_state_dict(int(g["weights_seed"])).items()})
+    sp = sp.cuda().eval()
+    saved = (torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32)
+    m = FusedHeadSuperPoint(sp, helpers=_Helpers)
+    out = m({"image": torch.from_numpy(g["image"]).cuda()})
+    assert set(out) == {"keypoints", "scores", "descriptors", "dense_descriptor", "dense_score", "dense_descriptor_nhwc"}
+    # GPU convolutions (MIOpen) vs the CPU convolutions of the fixture: a few 1e-6 on O(1) activations
+    assert np.abs(out["dense_score"].cpu().numpy() - g["dense_score"]).max() < 2e-5
+    assert np.abs(out["dense_descriptor"].cpu().numpy() - g["dense_descriptor"]).max() < 2e-5
+    assert torch.equal(out["dense_descriptor_nhwc"], out["dense_descriptor"].permute(0, 2, 3, 1))
+    for b in range(2):
+        kp, want = out["keypoints"][b].cpu().numpy(), g[f"keypoints{b}"]
+        have = {tuple(r) for r in kp.tolist()}
+        ref = {tuple(r) for r in want.tolist()}
+        assert len(have ^ ref) <= max(2, len(ref) // 20), (len(have), len(ref))      # threshold-edge flips only
+        assert out["descriptors"][b].shape == (256, kp.shape[0])
+    assert saved == (torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32)

@@ -1,5 +1,7 @@
 """CPU: pin oracle/linetr_oracle.py against the fixtures frozen from the real reference
 (tests/golden/make_golden.py).  Tokeniser entries bit-exact, descriptors <= 2e-5, matches identical."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -109,3 +111,16 @@ def test_matcher_known_answers():
     M, D = O.point_nn(g["point_desc0"], g["point_desc1"], 0.7, True)
     assert np.array_equal(M, g["point_M"])
     assert np.abs(D - g["point_D"]).max() < 1e-6
+
+
+def test_superpoint_heads_oracle_matches_reference_fixture():
+    """8(f) row 2: the oracle's head post-processing vs the dense maps the real SuperPoint.forward returned."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "superpoint_heads.npz"))
+    score, desc = O.superpoint_heads(g["score_logits"], g["desc_raw"])
+    assert score.shape == g["dense_score"].shape == (2, 64, 96)
+    assert np.array_equal(score, g["dense_score"])
+    assert np.array_equal(desc, g["dense_descriptor"])
+    # what the maps mean: every 8x8 patch + its dustbin is a probability distribution; descriptors are unit vectors
+    patch = score.reshape(2, 8, 8, 12, 8).sum(axis=(2, 4))
+    assert (patch <= 1 + 1e-6).all() and (patch > 0).all()
+    assert np.abs(np.linalg.norm(desc, axis=1) - 1).max() < 1e-6
