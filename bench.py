@@ -174,6 +174,54 @@ PMC_KERNEL_NAMES = {   # profile class -> kernel symbol in profiles/r01_pmc_traf
 }
 
 
+def producer_section(eng, pipe, H, W, n_img, ms_per_step):
+    """linetr_superpoint_heads on raw head outputs of this batch's shape (synthetic logits / descriptors), HIP-event
+    timed; the same maths in stock PyTorch on the GPU for scale; and the descriptor step fed with the producer's
+    NHWC map (no transposition pass inside linetr_describe)."""
+    Hc, Wc = H // 8, W // 8
+    g = torch.Generator(device=eng.device).manual_seed(3)
+    sl = torch.randn(n_img, 65, Hc, Wc, device=eng.device, generator=g) * 2
+    dr = torch.randn(n_img, 256, Hc, Wc, device=eng.device, generator=g)
+
+    def timed(fn, reps=10):
+        for _ in range(3):
+            r = fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            r = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, r
+
+    ms, (score, nhwc, _) = timed(lambda: eng.superpoint_heads(sl, dr, nhwc=True, nchw=False))
+
+    def torch_heads():
+        p = torch.softmax(sl, 1)[:, :-1]
+        p = p.permute(0, 2, 3, 1).reshape(n_img, Hc, Wc, 8, 8).permute(0, 1, 3, 2, 4).reshape(n_img, Hc * 8, Wc * 8)
+        return p, torch.nn.functional.normalize(dr, p=2, dim=1)
+    ms_torch, _ = timed(torch_heads)
+    nbytes = n_img * Hc * Wc * (256 * 2 + 65 + 64) * 4
+    c = LINE_CFG
+
+    def step_nhwc():
+        return eng.describe_lines(pipe.cat, pipe.offsets, nhwc, score, remove_borders=c["remove_borders"],
+                                  min_length=c["min_length"], max_keylines=c["max_keylines"],
+                                  token_distance=c["token_distance"], max_tokens=pipe.T, dense_layout="nhwc")
+    for _ in range(5):
+        step_nhwc()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        step_nhwc()
+    torch.cuda.synchronize()
+    ms_nhwc = (time.perf_counter() - t0) / 10 * 1e3
+    return {"kernel": "sp_desc_head + sp_score_head (linetr_superpoint_heads)", "images": n_img, "ms": round(ms, 4),
+            "algorithmic_bytes": nbytes, "achieved_GBps": round(nbytes / ms / 1e6, 1), "hbm_peak_GBps": HBM_PEAK_GBS,
+            "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "torch_same_ops_ms": round(ms_torch, 4),
+            "ms_per_step_fed_nhwc": round(ms_nhwc, 4), "ms_per_step_fed_nchw": round(ms_per_step, 4)}
+
+
 def pmc_traffic(kernel_class):
     """HBM-side bytes per launch of `kernel_class` from the committed rocprofv3 PMC pass (FETCH_SIZE/WRITE_SIZE in
     KiB, separate --pmc runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads
@@ -376,6 +424,8 @@ def main():
         "gpu_ms_per_step_profiled": round(tot_ms / prof_steps, 3),
         "roofline": roofline, "kernels": breakdown,
     }
+    if rank == 0:   # the dense-map producer feeding this batch (reported beside the metric, never in it)
+        out["producer"] = producer_section(eng, pipe, H, W, n_img, ms_per_step)
     if not args.no_alt_precisions:   # the same step in the other MFMA modes (few steps each), for reference
         alt = {}
         for mode in ("bf16x3", "f16x3", "bf16x6", "f32"):

@@ -1150,7 +1150,9 @@ extern "C" int linetr_superpoint_heads(LinetrHandle* h, const float* d_score_log
   if (d_dense_desc_nhwc || d_dense_desc_nchw) {
     const double by = (double)B * HW * D * 4.0 * (1 + (d_dense_desc_nhwc ? 1 : 0) + (d_dense_desc_nchw ? 1 : 0));
     ProfScope ps(h, st, "sp_desc_head", 3.0 * B * HW * D, by);
-    hipLaunchKernelGGL(sp_desc_head_kernel, grid, dim3(256), 0, st, d_desc_raw, d_dense_desc_nhwc, d_dense_desc_nchw, HW);
+    static const int cells = getenv("LINETR_SP_CELLS") ? atoi(getenv("LINETR_SP_CELLS")) : 32;   // tuning aid
+    if (cells == 64) hipLaunchKernelGGL(sp_desc_head_kernel<64>, grid, dim3(256), 0, st, d_desc_raw, d_dense_desc_nhwc, d_dense_desc_nchw, HW);
+    else hipLaunchKernelGGL(sp_desc_head_kernel<32>, dim3((unsigned)cdiv(HW, 32), (unsigned)B), dim3(256), 0, st, d_desc_raw, d_dense_desc_nhwc, d_dense_desc_nchw, HW);
     LT_LAUNCH_CHECK();
   }
   if (d_dense_score) {
