@@ -111,7 +111,10 @@ class Matching(torch.nn.Module):
             lt.config["token_distance"] = max(8, max(shape) / 80)
         lt.config["image_shape"] = shape
         c = lt.config
-        dd = torch.cat([sp["dense_descriptor"] for sp in sp_out])
+        # a producer that already emits the tokeniser's layout (linetr_amd.superpoint.FusedHeadSuperPoint) saves the
+        # NCHW -> NHWC pass inside linetr_describe
+        layout = "nhwc" if all("dense_descriptor_nhwc" in sp for sp in sp_out) else "nchw"
+        dd = torch.cat([sp["dense_descriptor_nhwc" if layout == "nhwc" else "dense_descriptor"] for sp in sp_out])
         ds = torch.cat([sp["dense_score"] for sp in sp_out])
         eng = lt.engine(dd.device)
         off = np.concatenate([[0], np.cumsum([len(l) for l in lines])]).astype(np.int32)
@@ -119,7 +122,7 @@ class Matching(torch.nn.Module):
         align = int(torch.__version__[2]) > 2
         tb, ld = eng.describe_lines(cat, off, dd, ds, remove_borders=c["remove_borders"], min_length=c["min_length"],
                                     max_keylines=c["max_keylines"], token_distance=c["token_distance"],
-                                    max_tokens=c["max_tokens"], align_corners=align)
+                                    max_tokens=c["max_tokens"], align_corners=align, dense_layout=layout)
         cu_n, cu_k = tb.cu_n, tb.cu_k
         n, k = np.diff(cu_n), np.diff(cu_k)
         dev = ld.device

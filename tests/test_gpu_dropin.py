@@ -158,6 +158,33 @@ def test_matching_forward_batch_equals_per_pair():
             v[0]
 
 
+def test_forward_batch_uses_producer_layout():
+    """A SuperPoint that also hands out 'dense_descriptor_nhwc' (FusedHeadSuperPoint): forward_batch feeds that map to
+    linetr_describe (dense_layout='nhwc') and returns the same line descriptors and matches."""
+    from models.matching import Matching
+    seeds = [51, 52, 53, 54]
+    line_sets = [synth.synth_lines(s, 120 + 15 * i, 480, 640) for i, s in enumerate(seeds)]
+
+    class NhwcSuperPoint(FakeSuperPoint):
+        def forward(self, data):
+            out = super().forward(data)
+            out["dense_descriptor_nhwc"] = out["dense_descriptor"].permute(0, 2, 3, 1).contiguous()
+            return out
+
+    def build(cls):
+        mt = Matching({"auto_min_length": True, "linetransformer": {**LT_CFG}}, superpoint=cls(seeds), lsd=FakeLSD(line_sets))
+        mt.linetransformer.load_state_dict(synth.to_torch_state_dict(synth.calibrated_state_dict()))
+        return mt.eval().to("cuda")
+    img = torch.zeros(1, 1, 480, 640, device="cuda")
+    pairs = [{"image0": img, "image1": img.clone()} for _ in range(2)]
+    a = build(FakeSuperPoint).forward_batch(pairs)
+    b = build(NhwcSuperPoint).forward_batch(pairs)
+    for pa, pb in zip(a, b):
+        assert torch.equal(pa["line_desc0"], pb["line_desc0"]) and torch.equal(pa["line_desc1"], pb["line_desc1"])
+        assert torch.equal(pa["matches_l"], pb["matches_l"])
+        assert "dense_descriptor_nhwc0" in pb and "dense_descriptor_nhwc0" not in pa
+
+
 def test_nhwc_dense_layout_matches_nchw():
     from linetr_amd.engine import Engine
     eng = Engine(synth.calibrated_state_dict(), "cuda:0")
