@@ -754,6 +754,21 @@ struct TokenStage {            // how the token stage (word MLP + CLS pooling) i
   bool use_side = false;       // h->side carries the NHWC transpose (ev_nhwc) and may take the line-position MLP
 };
 
+bool fused_mlp_enabled(const LinetrModelConfig& c) {
+  static const bool off = getenv("LINETR_NO_FUSED_MLP") != nullptr;   // tuning aid: the three-launch chain
+  return !off && c.enc_channels[1] == 64 && c.enc_channels[2] == 128;
+}
+
+// rows handled by one wave of mlp123_kernel (multiples of the 32-row MFMA step).  The kernel holds 160 weights per lane,
+// so one wave fits a SIMD (1024 on the chip) and workgroup dispatch is slow for such fat blocks (~10 blocks/us
+// measured): give every wave one long run of rows -- a single round of <= 256 blocks -- rather than many short ones.
+int mlp123_rows_per_wave(int64_t rows) {
+  static const char* env = getenv("LINETR_MLP_RPW");   // tuning aid
+  if (env) return atoi(env);
+  const int64_t waves = 256 * 4;
+  return (int)std::max<int64_t>(cdiv((int)cdiv((int)rows, (int)waves), 32) * 32, 32);
+}
+
 int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const float* sublines, const float* resp,
                  const float* angle_sub, const int32_t* h_cu, const int* cu_dev, int n_images, int N, int T,
                  float* d_line_desc, FwdWs& w) {
@@ -766,25 +781,43 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   const float scale = (float)std::max(c.norm_width, c.norm_height) * 0.7f;
   int e;
   // ---- word positional encoder up to the last ReLU (a4); its final linear layer is applied after pooling
-  {
-    ProfScope ps(h, st, "mlp_first", 2.0 * rows * 3 * e0, (double)rows * (12 + 4 * e0));
-    hipLaunchKernelGGL(word_mlp1_kernel, dim3((unsigned)cdiv((int)(rows * 8), 256)), dim3(256), 0, st,
-                       ts.cpnt ? ts.cpnt : ts.pnt, ts.cpnt ? ts.cscore : ts.score, rows, cx, cy, scale, h->wW1, h->wb1, w.a1);
+  const bool fused_mlp = fused_mlp_enabled(c);
+  if (fused_mlp) {   // layers 1-3 in one exact-fp32 MFMA kernel (lt_model.h)
+    ProfScope ps(h, st, "mlp123", 2.0 * rows * (3 * e0 + e0 * e1 + e1 * e2), (double)rows * (12 + 4 * e2));
+    const int rpw = mlp123_rows_per_wave(rows);
+    hipLaunchKernelGGL(mlp123_kernel<true>, dim3((unsigned)cdiv((int)cdiv((int)rows, rpw), 4)), dim3(256), 0, st,
+                       ts.cpnt ? ts.cpnt : ts.pnt, ts.cpnt ? ts.cscore : ts.score, (const float*)nullptr, rows, rpw, cx, cy,
+                       scale, h->wW1, h->wb1, h->wW2, h->wb2, h->wW3, h->wb3, w.a3);
     LT_LAUNCH_CHECK();
+  } else {
+    {
+      ProfScope ps(h, st, "mlp_first", 2.0 * rows * 3 * e0, (double)rows * (12 + 4 * e0));
+      hipLaunchKernelGGL(word_mlp1_kernel, dim3((unsigned)cdiv((int)(rows * 8), 256)), dim3(256), 0, st,
+                         ts.cpnt ? ts.cpnt : ts.pnt, ts.cpnt ? ts.cscore : ts.score, rows, cx, cy, scale, h->wW1, h->wb1, w.a1);
+      LT_LAUNCH_CHECK();
+    }
+    if ((e = run_gemm(h, st, w.a1, e0, nullptr, 0, 0, h->wW2, h->wb2, nullptr, 0, w.a2, e1, (int)rows, e1, e0, ACT_RELU))) return e;
+    if ((e = run_gemm(h, st, w.a2, e1, nullptr, 0, 0, h->wW3, h->wb3, nullptr, 0, w.a3, e2, (int)rows, e2, e1, ACT_RELU))) return e;
   }
-  if ((e = run_gemm(h, st, w.a1, e0, nullptr, 0, 0, h->wW2, h->wb2, nullptr, 0, w.a2, e1, (int)rows, e1, e0, ACT_RELU))) return e;
-  if ((e = run_gemm(h, st, w.a2, e1, nullptr, 0, 0, h->wW3, h->wb3, nullptr, 0, w.a3, e2, (int)rows, e2, e1, ACT_RELU))) return e;
   if ((e = run_gemm(h, st, w.a3, e2, nullptr, 0, 0, h->wW4, h->wb4, nullptr, 0, w.a4, e3, (int)rows, e3, e2, ACT_RELU))) return e;
   // ---- line positional encoder: independent of everything above -> side stream when available
   hipStream_t ls = ts.use_side ? h->side : st;
-  {
-    ProfScope ps(h, ls, "mlp_first", 2.0 * N * 5 * e0, (double)N * (28 + 4 * e0));
-    hipLaunchKernelGGL(line_mlp1_kernel, dim3(cdiv(N * 8, 256)), dim3(256), 0, ls, sublines, resp, angle_sub, N, cx, cy,
-                       scale, h->lW1, h->lb1, w.l1);
+  if (fused_mlp) {
+    ProfScope ps(h, ls, "mlp123_line", 2.0 * N * (5 * e0 + e0 * e1 + e1 * e2), (double)N * (28 + 4 * e2));
+    const int rpw = mlp123_rows_per_wave(N);
+    hipLaunchKernelGGL(mlp123_kernel<false>, dim3((unsigned)cdiv(cdiv(N, rpw), 4)), dim3(256), 0, ls, sublines, resp, angle_sub,
+                       (int64_t)N, rpw, cx, cy, scale, h->lW1, h->lb1, h->lW2, h->lb2, h->lW3, h->lb3, w.l3);
     LT_LAUNCH_CHECK();
+  } else {
+    {
+      ProfScope ps(h, ls, "mlp_first", 2.0 * N * 5 * e0, (double)N * (28 + 4 * e0));
+      hipLaunchKernelGGL(line_mlp1_kernel, dim3(cdiv(N * 8, 256)), dim3(256), 0, ls, sublines, resp, angle_sub, N, cx, cy,
+                         scale, h->lW1, h->lb1, w.l1);
+      LT_LAUNCH_CHECK();
+    }
+    if ((e = run_gemm(h, ls, w.l1, e0, nullptr, 0, 0, h->lW2, h->lb2, nullptr, 0, w.l2, e1, N, e1, e0, ACT_RELU))) return e;
+    if ((e = run_gemm(h, ls, w.l2, e1, nullptr, 0, 0, h->lW3, h->lb3, nullptr, 0, w.l3, e2, N, e2, e1, ACT_RELU))) return e;
   }
-  if ((e = run_gemm(h, ls, w.l1, e0, nullptr, 0, 0, h->lW2, h->lb2, nullptr, 0, w.l2, e1, N, e1, e0, ACT_RELU))) return e;
-  if ((e = run_gemm(h, ls, w.l2, e1, nullptr, 0, 0, h->lW3, h->lb3, nullptr, 0, w.l3, e2, N, e2, e1, ACT_RELU))) return e;
   if ((e = run_gemm(h, ls, w.l3, e2, nullptr, 0, 0, h->lW4, h->lb4, nullptr, 0, w.l4, e3, N, e3, e2, ACT_RELU))) return e;
   if ((e = run_gemm(h, ls, w.l4, e3, nullptr, 0, 0, h->lW5, h->lb5, nullptr, 0, w.lpos, D, N, D, e3, ACT_NONE))) return e;
   if (ts.use_side) {
@@ -967,7 +1000,10 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
   float* angle_sub = out.angle_sub ? out.angle_sub : dw.angle_sub;
   const float* nhwc_map = dense_is_nhwc ? d_dense_desc : dw.nhwc;
   const bool use_side = side_stream_ready(h, N);
-  if (use_side && !dense_is_nhwc) {  // NHWC transpose on the side stream, concurrent with tokenise + token-MLP GEMMs
+  if (use_side && !dense_is_nhwc) {  // NHWC transpose on the side stream, concurrent with tokenise + token MLP
+    // (measured: while this grid drains, the fused word MLP -- one fat wave per SIMD -- gets most of its blocks placed
+    // 140-175 us late and ends about when the transposition does; deferring the transposition behind it, or making it
+    // persistent with <= 2 blocks per CU, moves the step by < 1 %, so the plain launch stays)
     LT_HIP(hipEventRecord(h->ev_fork, st));
     LT_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     ProfScope ps(h, h->side, "nchw_to_nhwc", 0, 2.0 * n_images * P * D * 4);
@@ -1225,6 +1261,14 @@ extern "C" int linetr_debug_gemm(LinetrHandle* h, const float* A, int32_t lda, c
   }
   return e;
 }
+
+#ifdef LT_MLP_STAMPS
+extern "C" int linetr_debug_mlp_stamps(unsigned long long* out) {   // debug build only (tools/mlp_stamps.py)
+  LT_HIP(hipDeviceSynchronize());
+  LT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(lt::lt_mlp_stamps), sizeof(unsigned long long) * 1024 * 16));
+  return LINETR_OK;
+}
+#endif
 
 // =============================================================================================
 // profiling

@@ -57,6 +57,206 @@ __global__ void line_mlp1_kernel(const float* __restrict__ sublines /*[N][2][2]*
   *reinterpret_cast<f32x4*>(out + (int64_t)row * 32 + c0) = o;
 }
 
+// ---- layers 1-3 of a positional-encoder MLP in ONE pass (in -> 32 -> 64 -> 128, BN folded, ReLU) ---------------
+// Exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) on the TRANSPOSED product: neurons are the MFMA rows (A = weights,
+// resident in VGPRs for the whole kernel), the 32 rows (tokens / sub-lines) of a step are the MFMA columns
+// (B = activations).  The C/D layout -- lane = column, registers = rows (r&3) + 8(r>>2) + 4(lane>>5) -- is then
+// exactly a B-operand layout of the next layer with the K index permuted, so bias + ReLU happen in registers and the
+// activations never leave them: no LDS, no broadcasts (a v_readlane version spent 2/3 of its time in readlanes, a
+// lane-per-row version with scalar-loaded weights thrashed the 16 KiB scalar cache).  Replaces mlp_first + the
+// K = 32 and K = 64 GEMM launches (all prologue/epilogue at 9-30 TF) and keeps a1 / a2 out of HBM.
+__device__ __forceinline__ void word_feat(const float* __restrict__ pnt, const float* __restrict__ score, int64_t row,
+                                          float cx, float cy, float scale, float (&in)[3]) {
+#pragma clang fp contract(off)
+  in[0] = (pnt[row * 2 + 0] - cx) / scale;
+  in[1] = (pnt[row * 2 + 1] - cy) / scale;
+  in[2] = score[row];
+}
+__device__ __forceinline__ void line_feat(const float* __restrict__ sublines, const float* __restrict__ resp,
+                                          const float* __restrict__ angle, int64_t row, float cx, float cy, float scale,
+                                          float (&in)[5]) {
+#pragma clang fp contract(off)
+  const float* sl = sublines + row * 4;
+  const float sx = (sl[0] - cx) / scale, sy = (sl[1] - cy) / scale;
+  const float ex = (sl[2] - cx) / scale, ey = (sl[3] - cy) / scale;
+  in[0] = (sx + ex) / 2.f; in[1] = (sy + ey) / 2.f; in[2] = resp[row]; in[3] = angle[row * 2]; in[4] = angle[row * 2 + 1];
+}
+#ifdef LT_MLP_STAMPS   // debug build: 100 MHz wall-clock stamps of one wave per block (tools/mlp_stamps.py)
+__device__ unsigned long long lt_mlp_stamps[1024 * 16];
+#define LT_MLP_STAMP(i) do { if (WORD && threadIdx.x == 0 && blockIdx.x < 1024) lt_mlp_stamps[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define LT_MLP_STAMP(i) do {} while (0)
+#endif
+// K index served by register r of an accumulator tile in lane half h (see above)
+__device__ __forceinline__ constexpr int cd_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <bool WORD>
+__global__ __launch_bounds__(256) void mlp123_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                     const float* __restrict__ p2, int64_t rows, int rows_per_wave,
+                                                     float cx, float cy, float scale,
+                                                     const float* __restrict__ W1 /*[32][IN]*/, const float* __restrict__ b1,
+                                                     const float* __restrict__ W2 /*[64][32]*/, const float* __restrict__ b2,
+                                                     const float* __restrict__ W3 /*[128][64]*/, const float* __restrict__ b3,
+                                                     float* __restrict__ out /*[rows][128]*/) {
+  constexpr int IN = WORD ? 3 : 5;
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t r_begin = wave * rows_per_wave;
+  const int64_t r_end = r_begin + rows_per_wave < rows ? r_begin + rows_per_wave : rows;
+  LT_MLP_STAMP(0);
+  // Stage W2 / W3 / biases in LDS once per block (coalesced float4 loads; row strides 33 / 65 floats so that the
+  // per-lane gathers below are bank-conflict-free) -- per-lane gathers straight from global touch 32 lines per load.
+  // LDS: the weight images are dead once every wave has gathered its registers; the per-wave output staging tiles
+  // (32 rows x 68 floats each) reuse that space, which keeps the block at 43 KiB so that it can share a CU with the
+  // blocks of a concurrent kernel (the NHWC transposition on the side stream) instead of waiting for them to drain.
+  __shared__ __attribute__((aligned(16))) float sAll[64 * 33 + 128 * 65];
+  __shared__ __attribute__((aligned(16))) float sW1[32 * 8];
+  __shared__ __attribute__((aligned(16))) float sB[64 + 128];
+  float* sW2 = sAll;
+  float* sW3 = sAll + 64 * 33;
+  float* stg = sAll + (threadIdx.x >> 6) * (32 * 68);
+  static_assert(4 * 32 * 68 <= 64 * 33 + 128 * 65, "staging tiles must fit into the dead weight images");
+  {  // all 10 loads of a thread are issued before the first LDS write (a load -> write loop pays the L2 latency 10x)
+    f32x4 v2[2], v3[8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) v2[u] = *reinterpret_cast<const f32x4*>(W2 + (threadIdx.x + 256 * u) * 4);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v3[u] = *reinterpret_cast<const f32x4*>(W3 + (threadIdx.x + 256 * u) * 4);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = threadIdx.x + 256 * u, r = idx / 8, c = (idx % 8) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sW2[r * 33 + c + q] = v2[u][q];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = threadIdx.x + 256 * u, r = idx / 16, c = (idx % 16) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sW3[r * 65 + c + q] = v3[u][q];
+    }
+  }
+  {  // layer-1 rows as [w0 .. w4, -, -, bias]
+    const int k = threadIdx.x >> 3, c = threadIdx.x & 7;
+    sW1[threadIdx.x] = c < IN ? W1[k * IN + c] : (c == 7 ? b1[k] : 0.f);
+  }
+  if (threadIdx.x < 64) sB[threadIdx.x] = b2[threadIdx.x];
+  else if (threadIdx.x < 192) sB[threadIdx.x] = b3[threadIdx.x - 64];
+  __syncthreads();
+  LT_MLP_STAMP(1);
+  // resident A operands.  Layer 2: K step s uses k = 2s + h (layer 1 is computed straight into that order).
+  // Layer 3: K step (i, r) uses k = 32 i + cd_row(r, h), the order layer 2's accumulators come out in.
+  float w2[2][16], w3[4][32];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) w2[i][s2] = sW2[(32 * i + col) * 33 + 2 * s2 + h];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) w3[j][i * 16 + r] = sW3[(32 * j + col) * 65 + 32 * i + cd_row(r, h)];
+  __syncthreads();                       // all waves hold their weights: sAll becomes the staging area
+  if (r_begin >= r_end) return;
+  float feat[IN], feat_next[IN];
+  {
+    int64_t row = r_begin + col;
+    row = row < r_end ? row : r_end - 1;            // tail columns recompute the last row; their stores are masked
+    if constexpr (WORD) word_feat(p0, p1, row, cx, cy, scale, feat);
+    else line_feat(p0, p1, p2, row, cx, cy, scale, feat);
+  }
+  LT_MLP_STAMP(2);
+  int it_ = 0;
+  for (int64_t base = r_begin; base < r_end; base += 32, ++it_) {
+    if (it_ == 0) LT_MLP_STAMP(3);
+    if (it_ == 1) LT_MLP_STAMP(8);
+    {  // next step's inputs are requested now and consumed after this step's 160 MFMAs
+      int64_t row = base + 32 + col;
+      row = row < r_end ? row : r_end - 1;
+      if constexpr (WORD) word_feat(p0, p1, row, cx, cy, scale, feat_next);
+      else line_feat(p0, p1, p2, row, cx, cy, scale, feat_next);
+    }
+    // layer 1 on the VALU, rounded like word_mlp1_kernel / line_mlp1_kernel; this lane's neurons are k = 2s + h, their
+    // weights come from LDS (kept as wave-uniform scalars they overflowed the SGPR file and were spilled lane by lane)
+    float a1[16];
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+      for (int s1 = 0; s1 < 16; ++s1) {
+        const float* wr = sW1 + (2 * s1 + h) * 8;
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(wr), wb = *reinterpret_cast<const f32x4*>(wr + 4);
+        const float wv[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
+        float t = wv[7];                       // bias
+#pragma unroll
+        for (int i = 0; i < IN; ++i) t += wv[i] * feat[i];
+        a1[s1] = fmaxf(t, 0.f);
+      }
+    }
+    if (it_ == 0) LT_MLP_STAMP(4);
+    // layer 2: a2^T[64 neurons][32 rows] = W2 a1^T + b2.  The two 32-neuron tiles are interleaved: a chain of
+    // dependent MFMAs on ONE accumulator runs at a fraction of the pipe rate (measured 4x slower per step).
+    f32x16 acc2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; r += 4) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(sB + 32 * i + cd_row(r, h));
+        acc2[i][r] = bv[0]; acc2[i][r + 1] = bv[1]; acc2[i][r + 2] = bv[2]; acc2[i][r + 3] = bv[3];
+      }
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[i][s2], a1[s2], acc2[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[i][r] = fmaxf(acc2[i][r], 0.f);
+    if (it_ == 0) LT_MLP_STAMP(5);
+    // layer 3, two 32-neuron tiles at a time (two independent accumulator chains); the 16 registers of a tile are
+    // 4 runs of 4 consecutive neurons
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      f32x16 acc3[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(sB + 64 + 32 * (2 * jp + q) + cd_row(r, h));
+          acc3[q][r] = bv[0]; acc3[q][r + 1] = bv[1]; acc3[q][r + 2] = bv[2]; acc3[q][r + 3] = bv[3];
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            acc3[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[2 * jp + q][i * 16 + r], acc2[i][r], acc3[q], 0, 0, 0);
+      // A lane owns one ROW in the accumulators, so storing from them would write 32-byte pieces 512 bytes apart.
+      // Through this wave's staging tile ([32 rows][64 neurons of this pass], stride 68 floats) every store instruction
+      // writes four complete 256-byte half rows.  LDS operations of one wave execute in order: no barrier needed.
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4)
+          *reinterpret_cast<f32x4*>(stg + col * 68 + 32 * q + cd_row(r, h)) =
+              f32x4{fmaxf(acc3[q][r], 0.f), fmaxf(acc3[q][r + 1], 0.f), fmaxf(acc3[q][r + 2], 0.f), fmaxf(acc3[q][r + 3], 0.f)};
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int t = 4 * i + (lane >> 4), pc = (lane & 15) * 4;
+        if (base + t < r_end)
+          *reinterpret_cast<f32x4*>(out + (base + t) * 128 + 64 * jp + pc) = *reinterpret_cast<const f32x4*>(stg + t * 68 + pc);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (it_ == 0) LT_MLP_STAMP(6);
+#pragma unroll
+    for (int i = 0; i < IN; ++i) feat[i] = feat_next[i];
+    if (it_ == 0) LT_MLP_STAMP(7);
+  }
+  LT_MLP_STAMP(9);
+}
+
 // ---------------------------------------------------------------------------------------------
 // CLS-row attention pooling of the line-descriptive layer (models/line_attention.py:6-75 restricted
 // to query row 0, the only row that reaches the output: models/line_transformer.py:128).
