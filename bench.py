@@ -167,6 +167,9 @@ def cpu_baseline(workload, budget_s=12.0, max_pairs=16):
 
 PMC_KERNEL_NAMES = {   # profile class -> kernel symbol in profiles/r01_pmc_traffic.json (rocprofv3 --pmc run)
     # matched as a prefix of the demangled name (trailing template arguments may grow)
+    "gemm_bf16x6_128x256": "void lt::gemm_split_kernel<128, 256, 2, 4, 3, true, 0",
+    "gemm_bf16x3_128x256": "void lt::gemm_split_kernel<128, 256, 2, 4, 2, true, 0",
+    "gemm_f16x3_128x256": "void lt::gemm_split_kernel<128, 256, 2, 4, 2, true, 1",
     "gemm_bf16x6_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 3, true, 0",
     "gemm_bf16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 0",
     "gemm_f16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 1",
