@@ -56,15 +56,52 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- device helpers -------------------------------------------------------------------------
 
+constexpr float LOG2E = 1.44269504088896340736f;
+
+// Wave-wide reductions on the VALU's DPP paths (no LDS crossbar): xor-1 / xor-2 inside quads, half-row and row
+// mirrors give every lane its 16-lane row total, row_bcast15 / row_bcast31 fold the four rows into row 3, and lane 63 is
+// broadcast through an SGPR.  7 dependent VALU steps instead of 6 dependent ds_bpermute round trips (__shfl_xor).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get(float v, float masked) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, masked), __builtin_bit_cast(int, v),
+                                                               CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_get<0xB1, 0xf>(v, 0.f);    // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E, 0xf>(v, 0.f);    // quad_perm [2,3,0,1]
+  v += dpp_get<0x141, 0xf>(v, 0.f);   // row_half_mirror
+  v += dpp_get<0x140, 0xf>(v, 0.f);   // row_mirror
+  v += dpp_get<0x142, 0xa>(v, 0.f);   // row_bcast15 into rows 1, 3
+  v += dpp_get<0x143, 0xc>(v, 0.f);   // row_bcast31 into rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// N independent sums at once: the N chains interleave, so the 2 wait states a DPP read needs after the VALU write of
+// its source are filled with useful work instead of s_nops.
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  for (int i = 0; i < N; ++i) v[i] += dpp_get<0xB1, 0xf>(v[i], 0.f);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x4E, 0xf>(v[i], 0.f);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x141, 0xf>(v[i], 0.f);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x140, 0xf>(v[i], 0.f);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x142, 0xa>(v[i], 0.f);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x143, 0xc>(v[i], 0.f);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_get<0xB1, 0xf>(v, v));
+  v = fmaxf(v, dpp_get<0x4E, 0xf>(v, v));
+  v = fmaxf(v, dpp_get<0x141, 0xf>(v, v));
+  v = fmaxf(v, dpp_get<0x140, 0xf>(v, v));
+  v = fmaxf(v, dpp_get<0x142, 0xa>(v, v));
+  v = fmaxf(v, dpp_get<0x143, 0xc>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 }  // namespace lt

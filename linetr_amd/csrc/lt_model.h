@@ -456,35 +456,59 @@ __global__ __launch_bounds__(256) void cls_pool_online_kernel(
   f32x4 db[4], ab[4];
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
-    m[h] = cc.s_cls[h]; l[h] = 1.f; w0[h] = 1.f;
+    m[h] = cc.s_cls[h] * LOG2E; l[h] = 1.f; w0[h] = 1.f;
     db[h] = f32x4{0.f, 0.f, 0.f, 0.f};
     ab[h] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   auto row_of = [&](int jj) -> int64_t { return jj < n_valid ? tok0 + jj : padrow; };
+  // The tap geometry of a token is wave-uniform and costs ~150 VALU instructions (two divisions, floor, clamps):
+  // lane i computes it once for token chunk + i, and the loop below fetches a token's 4 offsets + 4 weights with
+  // 8 v_readlane instead of recomputing them in all 64 lanes.
+  int t_off[4];
+  float t_w[4];
+  auto fill_taps = [&](int chunk) {
+    const int jj = chunk + lane;
+    const int64_t row = row_of(jj < ntk ? jj : ntk - 1);
+    tap_coords(cpnt[row * 2], cpnt[row * 2 + 1], Hc, Wc, align_corners, t_off, t_w);
+  };
+  auto issue = [&](int jj, TapSet& t, f32x4& a) {
+    int off[4];
+    float wt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      off[k] = __builtin_amdgcn_readlane(t_off[k], jj & 63);
+      wt[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_w[k]), jj & 63));
+    }
+    taps_load(nhwc_img, off, wt, lane, t);
+    a = *reinterpret_cast<const f32x4*>(a4 + row_of(jj) * D + lane * 4);
+  };
   TapSet cur, nxt;
   f32x4 a_cur, a_nxt;
-  {
-    const int64_t row = row_of(0);
-    taps_issue(cpnt[row * 2], cpnt[row * 2 + 1], nhwc_img, Hc, Wc, align_corners, lane, cur);
-    a_cur = *reinterpret_cast<const f32x4*>(a4 + row * D + lane * 4);
-  }
+  fill_taps(0);
+  issue(0, cur, a_cur);
   for (int jj = 0; jj < ntk; ++jj) {
     if (jj + 1 < ntk) {  // wave-uniform
-      const int64_t row = row_of(jj + 1);
-      taps_issue(cpnt[row * 2], cpnt[row * 2 + 1], nhwc_img, Hc, Wc, align_corners, lane, nxt);
-      a_nxt = *reinterpret_cast<const f32x4*>(a4 + row * D + lane * 4);
+      if (((jj + 1) & 63) == 0) fill_taps(jj + 1);
+      issue(jj + 1, nxt, a_nxt);
     }
-    const f32x4 dv = taps_finish(cur);
+    const f32x4 dv = taps_finish<true>(cur);
     const float mult = jj < n_valid ? 1.f : (float)n_pad;
+    float sc[4];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       float p = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) p += dv[c] * u[h][c] + a_cur[c] * u2[h][c];
-      const float sh = wave_sum(p) + cc.c_tok[h];
+      sc[h] = p;
+    }
+    wave_sum_n<4>(sc);                      // the four head scores reduce together
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      // running softmax in the log2 domain: one v_exp_f32 per exponential (m / l / w0 are only ever used as ratios)
+      const float sh = (sc[h] + cc.c_tok[h]) * LOG2E;
       const float m_new = fmaxf(m[h], sh);
-      const float alpha = expf(m[h] - m_new);
-      const float e = expf(sh - m_new) * mult;
+      const float alpha = __builtin_amdgcn_exp2f(m[h] - m_new);
+      const float e = __builtin_amdgcn_exp2f(sh - m_new) * mult;
       m[h] = m_new;
       l[h] = l[h] * alpha + e;
       w0[h] *= alpha;
@@ -687,7 +711,6 @@ __global__ __launch_bounds__(256) void sig_attn_kernel(const float* __restrict__
 //     V^T[d][kv] is two 4-element runs of one LDS row.
 //   * softmax stays fp32 and in-lane as in sig_attn_kernel.
 // ---------------------------------------------------------------------------------------------
-constexpr float LOG2E = 1.44269504088896340736f;
 constexpr int ATS_RK = 3 * 128 + 16;   // K plane row stride (bytes)
 constexpr int ATS_RV = 3 * 128 + 8;    // V^T plane row stride (bytes)
 

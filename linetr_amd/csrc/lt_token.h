@@ -171,8 +171,10 @@ __global__ __launch_bounds__(64) void tokenize_kernel(
 // token's loads in flight while it works on the current one -----------------------------------------------
 struct TapSet { f32x4 v[4]; float w[4]; };   // nw, ne, sw, se values and weights
 
-__device__ __forceinline__ void taps_issue(float px, float py, const float* __restrict__ nhwc_img, int Hc, int Wc,
-                                           int align_corners, int lane, TapSet& t) {
+// Bilinear tap geometry of one point (sample_descriptors' grid arithmetic, models/line_process.py:86-98, and
+// grid_sample's unnormalisation): 4 cell offsets (clamped, in cells) and weights (0 for taps outside the map: zero padding).
+__device__ __forceinline__ void tap_coords(float px, float py, int Hc, int Wc, int align_corners, int (&off)[4],
+                                           float (&wt)[4]) {
 #pragma clang fp contract(off)
   const float s = 8.f;
   float gx = ((px - s / 2) + 0.5f) / ((float)Wc * s - s / 2 - 0.5f);
@@ -189,20 +191,40 @@ __device__ __forceinline__ void taps_issue(float px, float py, const float* __re
   }
   const float x_w = floorf(ix), y_n = floorf(iy);
   const float w = ix - x_w, e = 1.f - w, nn = iy - y_n, ss = 1.f - nn;
-  t.w[0] = ss * e; t.w[1] = ss * w; t.w[2] = nn * e; t.w[3] = nn * w;
+  const float wv[4] = {ss * e, ss * w, nn * e, nn * w};
   const int x0 = (int)x_w, y0 = (int)y_n;
-  const float* base = nhwc_img + lane * 4;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
     const bool in = xx >= 0 && xx < Wc && yy >= 0 && yy < Hc;
-    // clamp the address, zero the weight-less value afterwards: keeps the load unconditional (no branch)
     const int yc = min(max(yy, 0), Hc - 1), xc = min(max(xx, 0), Wc - 1);
-    t.v[k] = *reinterpret_cast<const f32x4*>(base + ((int64_t)yc * Wc + xc) * D);
-    if (!in) t.v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    off[k] = yc * Wc + xc;
+    wt[k] = in ? wv[k] : 0.f;
   }
 }
 
+// loads of the 4 taps (this lane's 4 channels); the address is always valid, out-of-map taps carry weight 0
+__device__ __forceinline__ void taps_load(const float* __restrict__ nhwc_img, const int (&off)[4], const float (&wt)[4],
+                                          int lane, TapSet& t) {
+  const float* base = nhwc_img + lane * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    t.v[k] = *reinterpret_cast<const f32x4*>(base + (int64_t)off[k] * D);
+    t.w[k] = wt[k];
+  }
+}
+
+__device__ __forceinline__ void taps_issue(float px, float py, const float* __restrict__ nhwc_img, int Hc, int Wc,
+                                           int align_corners, int lane, TapSet& t) {
+  int off[4];
+  float wt[4];
+  tap_coords(px, py, Hc, Wc, align_corners, off, wt);
+  taps_load(nhwc_img, off, wt, lane, t);
+}
+
+// RCP = true: one division + 4 multiplies instead of 4 divisions (<= 1 ulp apart); only for consumers that never
+// expose the sampled descriptor itself (the pooling kernel), the reference's desc_sublines keeps the exact form.
+template <bool RCP = false>
 __device__ __forceinline__ f32x4 taps_finish(const TapSet& t) {
 #pragma clang fp contract(off)
   f32x4 o;
@@ -218,8 +240,14 @@ __device__ __forceinline__ f32x4 taps_finish(const TapSet& t) {
   }
   sq = wave_sum(sq);
   const float nrm = fmaxf(sqrtf(sq), 1e-12f);
+  if constexpr (RCP) {
+    const float inv = 1.f / nrm;
 #pragma unroll
-  for (int c = 0; c < 4; ++c) o[c] = o[c] / nrm;
+    for (int c = 0; c < 4; ++c) o[c] = o[c] * inv;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = o[c] / nrm;
+  }
   return o;
 }
 
