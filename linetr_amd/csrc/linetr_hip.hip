@@ -9,7 +9,6 @@
 #include "lt_common.h"
 #include "lt_gemm.h"
 #include "lt_gemm_split.h"
-#include "lt_gemm_dma.h"
 #include "lt_match.h"
 #include "lt_model.h"
 #include "lt_producer.h"
@@ -881,7 +880,12 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
         hipLaunchKernelGGL(sig_attn_kernel, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
       } else {
         ProfScope ps(h, st, "sig_attn_bf16x6", fl, (double)N * D * 16);
-        hipLaunchKernelGGL(sig_attn_split_kernel, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
+        static const bool attn4 = getenv("LINETR_ATTN_4WAVE") != nullptr;   // tuning aid: 128-query blocks
+        if (attn4 || max_n <= 128)
+          hipLaunchKernelGGL(sig_attn_split_kernel<4>, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
+        else
+          hipLaunchKernelGGL(sig_attn_split_kernel<8>, dim3(n_images, HEADS, cdiv(max_n, 256)), dim3(512), 0, st, w.qkv, cu_dev,
+                             w.msgp);
       }
       LT_LAUNCH_CHECK();
     }
@@ -1220,34 +1224,6 @@ extern "C" int linetr_debug_gemm(LinetrHandle* h, const float* A, int32_t lda, c
     hipLaunchKernelGGL((split_rows_kernel<2, 1>), dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, st, W, buf + b2 + b3, (int64_t)N, K);
     LT_LAUNCH_CHECK();
     if (cache_weights) h->debug_split[W] = buf;
-  }
-  static const bool use_dma = getenv("LINETR_GEMM_DMA") != nullptr;   // experiment: direct-to-LDS kernel on pre-split A
-  if (use_dma && N % 128 == 0 && lda == K) {
-    // debug only: one cached split copy of the last A (pointer, shape and mode must all match)
-    static const float* cA = nullptr; static int cM = 0, cK = 0, cP = -1; static unsigned char* abuf = nullptr;
-    const int pl = h->precision == LINETR_PREC_BF16X6 ? 3 : 2;
-    if (cA != A || cM != M || cK != K || cP != h->precision) {
-      LT_HIP(hipStreamSynchronize(st));
-      if (abuf) (void)hipFree(abuf);
-      LT_HIP(hipMalloc((void**)&abuf, (size_t)M * K * 2 * pl));
-      const int64_t n4 = (int64_t)M * K / 4;
-      const dim3 gr((unsigned)cdiv((int)n4, 256));
-      if (h->precision == LINETR_PREC_BF16X6) hipLaunchKernelGGL(split_rows_kernel<3>, gr, dim3(256), 0, st, A, abuf, (int64_t)M, K);
-      else if (h->precision == LINETR_PREC_BF16X3) hipLaunchKernelGGL(split_rows_kernel<2>, gr, dim3(256), 0, st, A, abuf, (int64_t)M, K);
-      else hipLaunchKernelGGL((split_rows_kernel<2, 1>), gr, dim3(256), 0, st, A, abuf, (int64_t)M, K);
-      LT_LAUNCH_CHECK();
-      cA = A; cM = M; cK = K; cP = h->precision;
-    }
-    DmaGemmArgs da{};
-    da.g.A = nullptr; da.g.bias = bias; da.g.R = R; da.g.ldr = ldy; da.g.Y = Y; da.g.ldy = ldy;
-    da.g.M = M; da.g.N = N; da.g.K = K; da.g.act = act;
-    da.Asp = abuf; da.Asp2 = nullptr;
-    int e;
-    if (h->precision == LINETR_PREC_BF16X6) { da.Wsp = buf + b2; e = gemm_dma_launch<3>(da, st); }
-    else if (h->precision == LINETR_PREC_BF16X3) { da.Wsp = buf; e = gemm_dma_launch<2>(da, st); }
-    else { da.Wsp = buf + b2 + b3; e = gemm_dma_launch<2, 1>(da, st); }
-    if (!cache_weights) { (void)hipStreamSynchronize(st); (void)hipFree(buf); }
-    return e;
   }
   h->split[W] = {0, (size_t)b2, N, K, (size_t)(b2 + b3)};
   unsigned char* keep = h->split_arena;

@@ -714,14 +714,17 @@ __global__ __launch_bounds__(256) void sig_attn_kernel(const float* __restrict__
 constexpr int ATS_RK = 3 * 128 + 16;   // K plane row stride (bytes)
 constexpr int ATS_RV = 3 * 128 + 8;    // V^T plane row stride (bytes)
 
-__global__ __launch_bounds__(256) void sig_attn_split_kernel(const float* __restrict__ qkv,
-                                                             const int* __restrict__ cu_sub,
-                                                             float* __restrict__ out /*[N][256] head-major*/) {
+// NW waves per block = 32 NW query rows per block.  With 8 waves the K / V tiles of an (image, head) are split and
+// staged once for up to 256 queries instead of once per 128.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void sig_attn_split_kernel(const float* __restrict__ qkv,
+                                                                 const int* __restrict__ cu_sub,
+                                                                 float* __restrict__ out /*[N][256] head-major*/) {
   __shared__ __attribute__((aligned(16))) unsigned char Ks[ATT_KT * ATS_RK];
   __shared__ __attribute__((aligned(16))) unsigned char Vt[DH * ATS_RV];
   const int img = blockIdx.x, head = blockIdx.y;
   const int n0 = cu_sub[img], Ni = cu_sub[img + 1] - n0;
-  const int q0 = blockIdx.z * ATT_QT;
+  const int q0 = blockIdx.z * (NW * 32);
   if (q0 >= Ni) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h2 = lane >> 5, lq = lane & 31;
@@ -755,12 +758,12 @@ __global__ __launch_bounds__(256) void sig_attn_split_kernel(const float* __rest
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m = -INFINITY, l = 0.f;
 
-  const int srow = tid >> 4, sc4 = (tid & 15) * 4;  // staging: 16 rows x 16 float4 per pass
+  const int srow = tid >> 4, sc4 = (tid & 15) * 4;  // staging: 4 NW rows x 16 float4 per pass
   for (int t0 = 0; t0 < Ni; t0 += ATT_KT) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = srow + i * 16;
+    for (int i = 0; i < ATT_KT / (4 * NW); ++i) {
+      const int r = srow + i * (4 * NW);
       const int kv = t0 + r;
       f32x4 kx = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
       if (kv < Ni) {
