@@ -153,7 +153,7 @@ inline int gemm_launch_t(const GemmArgs& g, int groups, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * (BM + BN) * GEMM_LDS_STRIDE * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<BM, BN, WM, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<BM, BN, WM, WN>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }

@@ -232,7 +232,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
       constexpr int N_TERM = PL * (PL + 1) / 2;
       constexpr int N_MMA = MI * NI * N_TERM;                // MFMAs per 16-wide K step
       constexpr int N_FRAG = (MI + NI) * PL;                 // ds_read_b128 per K step
-      constexpr int N_GLD = A_F4 + B_PCS;                    // global loads per tile
       constexpr int E1 = 2 * A_F4 + B_PCS;                   // first-half store / refill steps
       // fragment read order = order of first use by the MFMAs (plane PL-1 of A and plane 0 of B first)
 #define FRAG_ORDER(k) (((k) / (MI + NI)) == 0 ? (((k) % (MI + NI)) < MI ? ((k) % (MI + NI)) * PL + (PL - 1) : MI * PL + (((k) % (MI + NI)) - MI) * PL) \
