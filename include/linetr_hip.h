@@ -246,6 +246,14 @@ int linetr_get_precision(const LinetrHandle* h);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 
+/* Runs layers 1-3 of a positional encoder (MLP of models/line_transformer.py:9-20, BN folded, ReLU) alone, for the
+ * unit tests: which = 0 WordPositionalEncoder (line_transformer.py:52-73; d_in0 = token points [rows,2] in pixels,
+ * d_in1 = token scores [rows], d_in2 unused), which = 1 LinePositionalEncoder (:40-50; d_in0 = sub-lines [rows,2,2] in
+ * pixels, d_in1 = resp [rows], d_in2 = angles [rows,2]).  d_out [rows,128] = activations after the third ReLU.
+ * Coordinates are normalised with the handle's image_shape as in normalize_keylines (:22-38). */
+int linetr_debug_posenc(LinetrHandle* h, int32_t which, const float* d_in0, const float* d_in1, const float* d_in2,
+                           int64_t rows, float* d_out, void* stream);
+
 /* Runs the library's fp32-MFMA GEMM  Y[M,N] = act(A[M,K] W[N,K]^T + bias) (+ R)  on device buffers; used
  * by the unit tests (vs a plain PyTorch fp32 reference) and by the kernel micro-benchmarks.  act: 0 none,
  * 1 ReLU, 2 erf-GELU, 3 max(2-2x,0).  d_bias / d_residual may be NULL.  N % 64 == 0, K % 32 == 0.

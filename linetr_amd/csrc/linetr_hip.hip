@@ -1203,6 +1203,29 @@ extern "C" int linetr_superpoint_heads(LinetrHandle* h, const float* d_score_log
   return LINETR_OK;
 }
 
+extern "C" int linetr_debug_posenc(LinetrHandle* h, int32_t which, const float* d_in0, const float* d_in1,
+                                      const float* d_in2, int64_t rows, float* d_out, void* stream) {
+  if (!h || !d_in0 || !d_in1 || !d_out || (which == 1 && !d_in2) || which < 0 || which > 1)
+    return fail(LINETR_E_ARG, "debug_posenc: bad argument");
+  if (!fused_mlp_enabled(h->cfg)) return fail(LINETR_E_ARG, "debug_posenc: needs keyline_encoder [32,64,128,256]");
+  if (rows <= 0) return LINETR_OK;
+  LT_HIP(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const LinetrModelConfig& c = h->cfg;
+  const float cx = c.norm_width / 2.f, cy = c.norm_height / 2.f;
+  const float scale = (float)std::max(c.norm_width, c.norm_height) * 0.7f;
+  const int rpw = mlp123_rows_per_wave(rows);
+  const dim3 grid((unsigned)cdiv((int)cdiv((int)rows, rpw), 4));
+  if (which == 0)
+    hipLaunchKernelGGL(mlp123_kernel<true>, grid, dim3(256), 0, st, d_in0, d_in1, (const float*)nullptr, rows, rpw, cx, cy, scale,
+                       h->wW1, h->wb1, h->wW2, h->wb2, h->wW3, h->wb3, d_out);
+  else
+    hipLaunchKernelGGL(mlp123_kernel<false>, grid, dim3(256), 0, st, d_in0, d_in1, d_in2, rows, rpw, cx, cy, scale, h->lW1, h->lb1,
+                       h->lW2, h->lb2, h->lW3, h->lb3, d_out);
+  LT_LAUNCH_CHECK();
+  return LINETR_OK;
+}
+
 extern "C" int linetr_debug_gemm(LinetrHandle* h, const float* A, int32_t lda, const float* W, const float* bias,
                                  const float* R, float* Y, int32_t ldy, int32_t M, int32_t N, int32_t K, int32_t act,
                                  int32_t cache_weights, void* stream) {

@@ -494,6 +494,18 @@ class Engine:
         code = self._L.linetr_get_precision(self._h)
         return {v: k for k, v in self.PRECISIONS.items()}[code]
 
+    def debug_posenc(self, which: str, in0, in1, in2=None):
+        """Layers 1-3 of the word ('word': points [rows,2], scores [rows]) or line ('line': sub-lines [rows,2,2],
+        resp [rows], angles [rows,2]) positional encoder alone -> [rows,128] (unit tests of the fused MLP kernel)."""
+        a, b = self._f32(in0), self._f32(in1)
+        c = self._f32(in2) if in2 is not None else None
+        rows = int(b.shape[0])
+        out = torch.empty((rows, 128), dtype=torch.float32, device=self.device)
+        nat.check(self._L.linetr_debug_posenc(self._h, {"word": 0, "line": 1}[which], a.data_ptr(), b.data_ptr(),
+                                                 c.data_ptr() if c is not None else None, rows, out.data_ptr(),
+                                                 self._stream()))
+        return out
+
     def debug_gemm(self, A, W, bias=None, residual=None, act=0, cache_weights=False, out=None):
         """Y = act(A @ W.T + bias) (+ residual) on the library's MFMA GEMM (diagnostics / unit tests).
         A / out / residual may be row-strided views (stride(0) multiple of 4, stride(1) == 1)."""

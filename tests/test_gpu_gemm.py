@@ -52,3 +52,47 @@ def test_gemm_epilogues(eng, act):
     x = A @ W.t() + b
     x = [x, torch.relu(x), torch.nn.functional.gelu(x), (2 - 2 * x).clamp(min=0)][act] + R
     assert (Y - x).abs().max().item() < 5e-5
+
+
+def _folded_mlp_reference(sd, prefix, x, n_layers=3):
+    """Plain PyTorch fp32 reference of the first `n_layers` Conv1d(k=1) + BatchNorm(eval) + ReLU blocks."""
+    import torch.nn.functional as F
+    for i in range(n_layers):
+        w = torch.from_numpy(sd[f"{prefix}.{3 * i}.weight"])[:, :, 0]
+        x = F.linear(x, w, torch.from_numpy(sd[f"{prefix}.{3 * i}.bias"]))
+        x = F.batch_norm(x, torch.from_numpy(sd[f"{prefix}.{3 * i + 1}.running_mean"]),
+                         torch.from_numpy(sd[f"{prefix}.{3 * i + 1}.running_var"]),
+                         torch.from_numpy(sd[f"{prefix}.{3 * i + 1}.weight"]),
+                         torch.from_numpy(sd[f"{prefix}.{3 * i + 1}.bias"]), False, 0.0, 1e-5)
+        x = F.relu(x)
+    return x
+
+
+@pytest.mark.parametrize("rows", [1, 31, 32, 33, 1000, 70001])
+def test_fused_posenc_layers_vs_torch(rows):
+    """mlp123_kernel (exact-fp32 MFMA, layers 1-3 of both positional encoders) against stock PyTorch fp32 on the same
+    rows: ragged row counts around the 32-row MFMA step and the per-wave row split."""
+    from linetr_amd import synth
+    from linetr_amd.engine import Engine
+    sd = synth.calibrated_state_dict()
+    eng = Engine(sd, "cuda:0")
+    g = torch.Generator().manual_seed(rows)
+    H, W = 480, 640
+    cx, cy, scale = W / 2.0, H / 2.0, 0.7 * max(H, W)
+    # word encoder: [x, y, score]
+    pnt = torch.rand(rows, 2, generator=g) * torch.tensor([W - 1.0, H - 1.0])
+    score = torch.rand(rows, generator=g)
+    got = eng.debug_posenc("word", pnt.cuda(), score.cuda()).cpu()
+    xin = torch.cat([(pnt - torch.tensor([cx, cy])) / scale, score[:, None]], dim=1)
+    want = _folded_mlp_reference(sd, "klenc.word_position_enc.encoder", xin)
+    assert got.shape == (rows, 128)
+    assert (got - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
+    # line encoder: [mid_x, mid_y, resp, cos2t, sin2t]
+    sl = torch.rand(rows, 2, 2, generator=g) * torch.tensor([W - 1.0, H - 1.0])
+    resp = torch.rand(rows, generator=g)
+    ang = torch.rand(rows, 2, generator=g) * 2 - 1
+    got = eng.debug_posenc("line", sl.cuda(), resp.cuda(), ang.cuda()).cpu()
+    sn = (sl - torch.tensor([cx, cy])) / scale
+    xin = torch.cat([(sn[:, 0] + sn[:, 1]) / 2, resp[:, None], ang], dim=1)
+    want = _folded_mlp_reference(sd, "klenc.line_position_enc.encoder", xin)
+    assert (got - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
