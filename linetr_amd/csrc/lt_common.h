@@ -75,6 +75,21 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_get<0x143, 0xc>(v, 0.f);   // row_bcast31 into rows 2, 3
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Exchange between the two 32-lane halves of a wave on gfx950's v_permlane32_swap (no LDS round trip): after the swap one
+// register holds the lower half's values in both halves and the other the upper half's, so max / sum of the pair is
+// the xor-32 butterfly step, identical in both halves.
+// (Inline asm on purpose: with this toolchain __builtin_amdgcn_permlane32_swap hands back the same register for both
+// results -- tools/ubench/permlane_test.hip.  The s_nops cover the VALU-write -> permlane-read wait states the
+// compiler would otherwise insert itself.)
+__device__ __forceinline__ void halves_of(float x, float& lo, float& hi) {
+  unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  lo = __builtin_bit_cast(float, a);
+  hi = __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float xor32_max(float x) { float a, b; halves_of(x, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xor32_sum(float x) { float a, b; halves_of(x, a, b); return a + b; }
+
 // N independent sums at once: the N chains interleave, so the 2 wait states a DPP read needs after the VALU write of
 // its source are filled with useful work instead of s_nops.
 template <int N>

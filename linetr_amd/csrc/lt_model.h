@@ -655,20 +655,21 @@ __global__ __launch_bounds__(256) void sig_attn_kernel(const float* __restrict__
         for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], qf[kk][s], st, 0, 0, 0);
       }
       // online softmax over this lane's 16 kv rows (+ the other half-wave's 16)
-      float mx = -INFINITY;
+      if (kv0 + 32 > Ni) {   // wave-uniform: only the image's last chunk has keys past the end
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-        if (kv >= Ni) st[r] = -INFINITY;
-        mx = fmaxf(mx, st[r]);
+        for (int r = 0; r < 16; ++r)
+          if (kv0 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= Ni) st[r] = -INFINITY;
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float mx = st[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
+      mx = xor32_max(mx);
       const float m_new = fmaxf(m, mx);
       const float alpha = expf(m - m_new);  // m = -inf on the first chunk -> 0
       float ps = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { st[r] = expf(st[r] - m_new); ps += st[r]; }
-      ps += __shfl_xor(ps, 32, 64);
+      ps = xor32_sum(ps);
       l = l * alpha + ps;
       m = m_new;
 #pragma unroll
@@ -759,18 +760,30 @@ __global__ __launch_bounds__(NW * 64) void sig_attn_split_kernel(const float* __
   float m = -INFINITY, l = 0.f;
 
   const int srow = tid >> 4, sc4 = (tid & 15) * 4;  // staging: 4 NW rows x 16 float4 per pass
+  constexpr int NPASS = ATT_KT / (4 * NW);
+  // K / V rows of the NEXT tile travel in registers while the current tile is being consumed: the global-load latency
+  // (1-2 us per tile, 4 tiles per block at N = 199) is off the critical path
+  f32x4 kreg[NPASS], vreg[NPASS];
+  auto fetch = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      const int kv = t0 + srow + i * (4 * NW);
+      kreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kv < Ni) {
+        const float* p = base + (int64_t)kv * 768 + head * DH + sc4;
+        kreg[i] = *reinterpret_cast<const f32x4*>(p + 256);
+        vreg[i] = *reinterpret_cast<const f32x4*>(p + 512);
+      }
+    }
+  };
+  fetch(0);
   for (int t0 = 0; t0 < Ni; t0 += ATT_KT) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < ATT_KT / (4 * NW); ++i) {
+    for (int i = 0; i < NPASS; ++i) {
       const int r = srow + i * (4 * NW);
-      const int kv = t0 + r;
-      f32x4 kx = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
-      if (kv < Ni) {
-        const float* p = base + (int64_t)kv * 768 + head * DH + sc4;
-        kx = *reinterpret_cast<const f32x4*>(p + 256);
-        vx = *reinterpret_cast<const f32x4*>(p + 512);
-      }
+      const f32x4 kx = kreg[i], vx = vreg[i];
       unsigned a[3], b[3];
       split_pair<3>(kx[0], kx[1], a);
       split_pair<3>(kx[2], kx[3], b);
@@ -787,6 +800,7 @@ __global__ __launch_bounds__(NW * 64) void sig_attn_split_kernel(const float* __
         col[(sc4 + 3) * (ATS_RV / 2)] = (unsigned short)(b[p] >> 16);
       }
     }
+    if (t0 + ATT_KT < Ni) fetch(t0 + ATT_KT);   // block-uniform
     __syncthreads();
     if (!wave_active) continue;
 #pragma unroll
@@ -810,19 +824,20 @@ __global__ __launch_bounds__(NW * 64) void sig_attn_split_kernel(const float* __
         st = mfma_split<0>(ka[0], qf[s][1], st);
         st = mfma_split<0>(ka[0], qf[s][0], st);
       }
-      float mx = -INFINITY;
+      if (kv0 + 32 > Ni) {   // wave-uniform: only the image's last chunk has keys past the end
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-        if (kv >= Ni) st[r] = -INFINITY;
-        mx = fmaxf(mx, st[r]);
+        for (int r = 0; r < 16; ++r)
+          if (kv0 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= Ni) st[r] = -INFINITY;
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float mx = st[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
+      mx = xor32_max(mx);
       const float m_new = fmaxf(m, mx);
       float ps = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - m_new); ps += st[r]; }
-      ps += __shfl_xor(ps, 32, 64);
+      ps = xor32_sum(ps);
       if (__any(m_new != m)) {      // wave-uniform: once the running max has settled the accumulators need no rescale
         const float alpha = __builtin_amdgcn_exp2f(m - m_new);   // m = -inf on the first chunk -> 0
         l *= alpha;
