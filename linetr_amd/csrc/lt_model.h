@@ -506,16 +506,20 @@ __global__ __launch_bounds__(256) void cls_pool_online_kernel(
     for (int h = 0; h < 4; ++h) {
       // running softmax in the log2 domain: one v_exp_f32 per exponential (m / l / w0 are only ever used as ratios)
       const float sh = (sc[h] + cc.c_tok[h]) * LOG2E;
-      const float m_new = fmaxf(m[h], sh);
-      const float alpha = __builtin_amdgcn_exp2f(m[h] - m_new);
-      const float e = __builtin_amdgcn_exp2f(sh - m_new) * mult;
-      m[h] = m_new;
-      l[h] = l[h] * alpha + e;
-      w0[h] *= alpha;
+      if (__any(sh > m[h])) {   // wave-uniform (sh and m are): the running maximum moves on few tokens only
+        const float alpha = __builtin_amdgcn_exp2f(m[h] - sh);
+        m[h] = sh;
+        l[h] *= alpha;
+        w0[h] *= alpha;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { db[h][c] *= alpha; ab[h][c] *= alpha; }
+      }
+      const float e = __builtin_amdgcn_exp2f(sh - m[h]) * mult;
+      l[h] += e;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        db[h][c] = db[h][c] * alpha + e * dv[c];
-        ab[h][c] = ab[h][c] * alpha + e * a_cur[c];
+        db[h][c] += e * dv[c];
+        ab[h][c] += e * a_cur[c];
       }
     }
     cur = nxt;
