@@ -48,22 +48,30 @@ class FusedHeadSuperPoint(nn.Module):
         return sp.convPb(relu(sp.convPa(x))), sp.convDb(relu(sp.convDa(x)))
 
     def forward(self, data):
-        fn, cfg = self._fn, self.config
         score_logits, desc_raw = self.encode(data["image"])
         dense_score, d_nhwc, d_nchw = self.engine().superpoint_heads(score_logits, desc_raw, nhwc=True,
                                                                      nchw=self.want_nchw)
         if d_nchw is None:                       # a view with the reference's shape (not contiguous)
             d_nchw = d_nhwc.permute(0, 3, 1, 2)
-        b, hc, wc = score_logits.shape[0], score_logits.shape[2], score_logits.shape[3]
-        scores = fn.simple_nms(dense_score, cfg["nms_radius"])
-        keypoints = [torch.nonzero(s > cfg["keypoint_threshold"]) for s in scores]
-        scores = [s[tuple(k.t())] for s, k in zip(scores, keypoints)]
-        keypoints, scores = list(zip(*[fn.remove_borders(k, s, cfg["remove_borders"], hc * 8, wc * 8)
-                                       for k, s in zip(keypoints, scores)]))
-        if cfg["max_keypoints"] >= 0:
-            keypoints, scores = list(zip(*[fn.top_k_keypoints(k, s, cfg["max_keypoints"])
-                                           for k, s in zip(keypoints, scores)]))
-        keypoints = [torch.flip(k, [1]).float() for k in keypoints]
-        descriptors = [fn.sample_descriptors(k[None], d[None], 8)[0] for k, d in zip(keypoints, d_nchw)]
+        hc, wc = int(score_logits.shape[2]), int(score_logits.shape[3])
+        keypoints, scores, descriptors = self._keypoints(dense_score, d_nchw, hc * 8, wc * 8)
         return {"keypoints": keypoints, "scores": scores, "descriptors": descriptors, "dense_descriptor": d_nchw,
                 "dense_score": dense_score, "dense_descriptor_nhwc": d_nhwc}
+
+    def _keypoints(self, dense_score, dense_desc, height, width):
+        """Key-point branch of the wrapped implementation (superpoint.py:168-187, 195-197), image by image, through its
+        own helpers: NMS, threshold, border removal, optional top-k, (row, col) -> (x, y), descriptor sampling."""
+        fn, cfg = self._fn, self.config
+        nms = fn.simple_nms(dense_score, cfg["nms_radius"])
+        kps, scs, descs = [], [], []
+        for b in range(nms.shape[0]):
+            rc = torch.nonzero(nms[b] > cfg["keypoint_threshold"])
+            val = nms[b][rc[:, 0], rc[:, 1]]
+            rc, val = fn.remove_borders(rc, val, cfg["remove_borders"], height, width)
+            if cfg["max_keypoints"] >= 0:
+                rc, val = fn.top_k_keypoints(rc, val, cfg["max_keypoints"])
+            xy = rc.flip(1).float()
+            kps.append(xy)
+            scs.append(val)
+            descs.append(fn.sample_descriptors(xy[None], dense_desc[b][None], 8)[0])
+        return kps, tuple(scs), descs

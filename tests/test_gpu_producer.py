@@ -129,41 +129,40 @@ def test_describe_from_producer_layout_is_identical():
 
 
 class _Helpers:
-    """Key-point helpers for the stand-in SuperPoint below, written from the published SuperPoint post-processing
-    (max-pool NMS, border removal, top-k, bilinear descriptor sampling): test scaffolding, not product code."""
+    """Key-point helpers for the stand-in SuperPoint below (test scaffolding, not product code), written from the
+    published description of SuperPoint's post-processing: iterated max-pool non-maximum suppression, a border filter,
+    top-k by score, and bilinear descriptor lookup at key-point centres with a final L2 normalisation."""
 
     @staticmethod
     def simple_nms(scores, r):
-        mp = lambda x: torch.nn.functional.max_pool2d(x, kernel_size=r * 2 + 1, stride=1, padding=r)
-        zeros = torch.zeros_like(scores)
-        max_mask = scores == mp(scores)
-        for _ in range(2):
-            supp_mask = mp(max_mask.float()) > 0
-            supp_scores = torch.where(supp_mask, zeros, scores)
-            new_max_mask = supp_scores == mp(supp_scores)
-            max_mask = max_mask | (new_max_mask & (~supp_mask))
-        return torch.where(max_mask, scores, zeros)
+        pool = lambda t: torch.nn.functional.max_pool2d(t, 2 * r + 1, 1, r)
+        keep = scores == pool(scores)
+        for _ in range(2):                      # re-admit maxima that were only shadowed by already-kept points
+            near = pool(keep.float()) > 0
+            rest = scores.masked_fill(near, 0.0)
+            keep = keep | ((rest == pool(rest)) & ~near)
+        return scores * keep
 
     @staticmethod
-    def remove_borders(k, s, b, h, w):
-        m = (k[:, 0] >= b) & (k[:, 0] < h - b) & (k[:, 1] >= b) & (k[:, 1] < w - b)
-        return k[m], s[m]
+    def remove_borders(rc, val, b, h, w):
+        r, c = rc[:, 0], rc[:, 1]
+        ok = (r >= b) & (r < h - b) & (c >= b) & (c < w - b)
+        return rc[ok], val[ok]
 
     @staticmethod
-    def top_k_keypoints(k, s, n):
-        if n >= len(k):
-            return k, s
-        s, idx = torch.topk(s, n, dim=0)
-        return k[idx], s
+    def top_k_keypoints(rc, val, n):
+        if n >= rc.shape[0]:
+            return rc, val
+        best = torch.topk(val, n).indices
+        return rc[best], val[best]
 
     @staticmethod
-    def sample_descriptors(kp, desc, s=8):
-        b, c, h, w = desc.shape
-        kp = kp - s / 2 + 0.5
-        kp = kp / torch.tensor([(w * s - s / 2 - 0.5), (h * s - s / 2 - 0.5)]).to(kp)[None]
-        kp = kp * 2 - 1
-        d = torch.nn.functional.grid_sample(desc, kp.view(b, 1, -1, 2), mode="bilinear", align_corners=True)
-        return torch.nn.functional.normalize(d.reshape(b, c, -1), p=2, dim=1)
+    def sample_descriptors(xy, dense, cell=8):
+        bsz, ch, hc, wc = dense.shape
+        span = torch.tensor([wc * cell - cell / 2 - 0.5, hc * cell - cell / 2 - 0.5], device=xy.device, dtype=xy.dtype)
+        grid = ((xy - cell / 2 + 0.5) / span) * 2 - 1
+        got = torch.nn.functional.grid_sample(dense, grid.view(bsz, 1, -1, 2), mode="bilinear", align_corners=True)
+        return torch.nn.functional.normalize(got.reshape(bsz, ch, -1), p=2, dim=1)
 
 
 class _StandInSuperPoint(nn.Module):
