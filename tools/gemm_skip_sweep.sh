@@ -14,6 +14,6 @@ if [ "$1" = build ]; then
   done; wait
 else
   for shape in ${SHAPES:-8192x4096x4096}; do for m in ${MODES:-bf16x6 bf16x3}; do for n in "${masks[@]}"; do
-    LABEL="$m $shape skip-mask $n" LINETR_LIB=$PWD/tools/liblinetr_skip$n.so timeout 100 python tools/gemm_phase_timing.py $m ${shape//x/ } 2>&1 | grep TF
+    LABEL="$m $shape skip-mask $n" LINETR_LIB=$PWD/tools/liblinetr_skip$n.so timeout 100 python tools/gemm_time_one.py $m ${shape//x/ } 2>&1 | grep TF
   done; done; done
 fi
