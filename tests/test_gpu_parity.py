@@ -68,6 +68,31 @@ def check_tokens(tb, g, prefix="", img=0, keys=TOK_KEYS):
             assert np.array_equal(have, want), (k, np.abs(have - want).max())
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x3"])
+def test_cfg2_pair_golden_other_precisions(engine, mode):
+    """The stated contract (descriptors within 1e-4 of the reference, line matches identical by index) holds in every
+    arithmetic mode, not only in the fp32-faithful default."""
+    g = load("cfg2_pair")
+    hw = (480, 640)
+    maps = [synth.synth_dense_maps(int(g[f"{t}_seed"]), *hw) for t in "ab"]
+    dd = torch.cat([m[0] for m in maps]).cuda()
+    ds = torch.cat([m[1] for m in maps]).cuda()
+    engine.set_precision(mode)
+    try:
+        tb, ld = run_native(engine, [g["a_lines"], g["b_lines"]], dd, ds, hw, BASE_CFG)
+        dk, off, m01 = engine.match(ld[:199], np.array([0, 199]), tb.sub2line[:199], np.array([0, 199]), ld[199:],
+                                    np.array([0, 199]), tb.sub2line[199:], np.array([0, 199]), 0.8, True)
+        ld = ld.cpu().numpy()
+    finally:
+        engine.set_precision("bf16x6")
+    for i, t in enumerate("ab"):
+        assert np.abs(ld[199 * i:199 * (i + 1)].T - g[f"{t}_line_desc"][0]).max() < 1e-4
+    M = np.zeros((199, 199))
+    m = m01.cpu().numpy()
+    M[np.nonzero(m >= 0)[0], m[m >= 0]] = 1
+    assert np.array_equal(M, g["pair_M"][0])
+
+
 def test_cfg2_pair_golden(engine):
     g = load("cfg2_pair")
     hw = (480, 640)
