@@ -9,6 +9,7 @@
 #include "lt_common.h"
 #include "lt_gemm.h"
 #include "lt_gemm_split.h"
+#include "lt_gemm_split16.h"
 #include "lt_match.h"
 #include "lt_model.h"
 #include "lt_producer.h"
@@ -123,7 +124,7 @@ const char* gemm_class_name(const GemmArgs& g, int groups, const char* kind) {
   const char* tile;
   if (strcmp(kind, "gemm_f32") != 0) {
     static const char* tile_env = getenv("LINETR_GEMM_TILE");
-    tile = tile_env ? tile_env : split_tile_name(g, groups);
+    tile = tile_env ? tile_env : split_tile_name(g, groups, strcmp(kind, "gemm_bf16x6") == 0 ? 3 : 2);
   } else if (g.N % 128 != 0) tile = "128x64";
   else {
     int64_t big = (int64_t)cdiv(g.M, 128) * (g.N / 128) * groups;

@@ -447,12 +447,18 @@ inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t
   hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT, PFD, PIPE>), grid, dim3(WM * WN * 64), lds, st, sa);
 }
 
+template <int PL, int FMT>
+inline void gemm_split16_launch(const SplitGemmArgs& sa, hipStream_t st);   // lt_gemm_split16.h (112-row tiles)
+inline bool split16_wins(const GemmArgs& g, int groups);
+
 // Tile choice: 8-wave 256x128 blocks (2 waves/SIMD inside one block, half the LDS staging per MFMA) once
 // there are enough of them to occupy most CUs; smaller tiles for small M so the grid still fills the chip.
-inline const char* split_tile_name(const GemmArgs& g, int groups) {
+inline const char* split_tile_name(const GemmArgs& g, int groups, int pl = 3) {
   if (g.N % 128 != 0) return "128x64";
   const int64_t t256 = (int64_t)cdiv(g.M, 256) * (g.N / 128) * groups;
   // same block size either way; 128x256 halves the A rows a block has to split per MFMA (+2-4 % measured)
+  static const bool no112 = getenv("LINETR_NO_TILE112") != nullptr;   // tuning aid
+  if (!no112 && pl == 2 && split16_wins(g, groups)) return "112x256";   // saves a round of blocks (lt_gemm_split16.h)
   if (t256 >= 192) return g.N % 256 == 0 ? "128x256" : "256x128";
   const int64_t t128 = (int64_t)cdiv(g.M, 128) * (g.N / 128) * groups;
   if (t128 >= 256) return "128x128";
@@ -468,8 +474,9 @@ inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st
   if (g.N % 64 != 0 || g.K % 32 != 0 || (g.A2 && g.K1 % 32 != 0))
     return fail(LINETR_E_ARG, "gemm_split: unsupported shape M=%d N=%d K=%d", g.M, g.N, g.K);
   static const char* tile_env = getenv("LINETR_GEMM_TILE");  // tuning aid: force a tile
-  const char* tile = tile_env ? tile_env : split_tile_name(g, groups);
-  if (g.N % 128 != 0 || !strcmp(tile, "128x64")) gemm_split_launch_t<128, 64, 4, 1, PL, true, FMT>(sa, groups, st);
+  const char* tile = tile_env ? tile_env : split_tile_name(g, groups, PL);
+  if (!strcmp(tile, "112x256")) gemm_split16_launch<PL, FMT>(sa, st);
+  else if (g.N % 128 != 0 || !strcmp(tile, "128x64")) gemm_split_launch_t<128, 64, 4, 1, PL, true, FMT>(sa, groups, st);
   else if (!strcmp(tile, "256x128")) {
     static const bool nopipe = getenv("LINETR_GEMM_NOPIPE") != nullptr;   // tuning aid: the pre-pipelining main loop
     if (nopipe) gemm_split_launch_t<256, 128, 4, 2, PL, true, FMT>(sa, groups, st);

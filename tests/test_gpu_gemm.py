@@ -41,6 +41,27 @@ def test_gemm_precision_modes(eng, mode, tol):
     assert ((Y - ref).abs().max() / ref.abs().max()).item() < tol
 
 
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 3e-5), ("f16x3", 4e-6)])
+@pytest.mark.parametrize("M,N,K,act", [(25472, 512, 512, 1), (25473, 256, 256, 2), (25361, 768, 256, 0)])
+def test_gemm_112_row_tiles(eng, mode, tol, M, N, K, act):
+    """Shapes for which the dispatcher picks the 112 x 256 kernel (v_mfma_f32_16x16x32, lt_gemm_split16.h) in the
+    3-product modes: full tiles, a ragged last tile (25 473 = 227 x 112 + 49), every epilogue piece (bias, activation,
+    residual) against float64."""
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    R = torch.randn(M, N, device="cuda", generator=g)
+    eng.set_precision(mode)
+    try:
+        Y = eng.debug_gemm(A, W, b, R, act)
+    finally:
+        eng.set_precision("bf16x6")
+    x = A.double() @ W.double().t() + b.double()
+    x = [x, torch.relu(x), torch.nn.functional.gelu(x)][act] + R.double()
+    assert ((Y.double() - x).abs().max() / x.abs().max()).item() < tol
+
+
 @pytest.mark.parametrize("act", [0, 1, 2, 3])
 def test_gemm_epilogues(eng, act):
     g = torch.Generator(device="cuda").manual_seed(act)
