@@ -29,9 +29,12 @@ def run(label, fn):
     dt = (time.perf_counter() - t0) / n
     stop = True; th.join()
     clk = [c for c, _ in samples[1:] if c]; pw = [p for _, p in samples[1:] if p]
-    print(f"{label}: {dt*1e6:.1f} us, {2*M*N*K/dt/1e12:.1f} TF | sclk samples {clk} MHz | power {pw} W", flush=True)
-for md in ([mode] if mode != 'all' else ['f32', 'bf16x6', 'bf16x3']):
+    import statistics
+    tail_c = clk[len(clk)//2:] or [0]; tail_p = pw[len(pw)//2:] or [0]
+    print(f"{os.environ.get('LABEL', label)}: {dt*1e6:.1f} us, {2*M*N*K/dt/1e12:.1f} TF | sclk {statistics.median(tail_c):.0f} MHz | power {statistics.median(tail_p):.0f} W (settled half of {len(clk)} samples)", flush=True)
+for md in ([mode] if mode != "all" else ["f32", "bf16x6", "bf16x3"]):
     eng.set_precision(md)
     eng.debug_gemm(A, W, cache_weights=True)
     run(f"{md} {M}x{N}x{K}", lambda: eng.debug_gemm(A, W, cache_weights=True))
-run("torch.mm bf16", (lambda a, w: (lambda: torch.mm(a, w.t())))(A.bfloat16(), W.bfloat16()))
+if not os.environ.get("NO_TORCH_MM"):
+    run("torch.mm bf16", (lambda a, w: (lambda: torch.mm(a, w.t())))(A.bfloat16(), W.bfloat16()))
