@@ -204,7 +204,11 @@ int linetr_match(LinetrHandle* h, int32_t n_pairs, const int32_t* h_dims, const 
 
 /* nn_matcher_distmat (models/nn_matcher.py:3-31) on a distance matrix that already lives on the device:
  * d_dist [n0,n1] float32 -> d_match01 [n0] (index into side 1 or -1).  `h` may be NULL for the three
- * matcher entry points (they need no weights); the current HIP device is used then. */
+ * matcher entry points (they need no weights); the current HIP device is used then.
+ * Contract: distances are float32 and NaN-free (the reference's cosine distances are clipped to [0,4]); a NaN entry
+ * is skipped by the argmin here, whereas np.argmin would return it.  All three matcher entry points are fully
+ * asynchronous on `stream` (host tables are staged in a library-owned pinned ring). */
+int64_t linetr_match_distmat_workspace_bytes(int32_t n0, int32_t n1);
 int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_t n0, int32_t n1, float nn_thresh,
                          int32_t mutual, int32_t* d_match01, void* d_workspace, int64_t workspace_bytes,
                          void* stream);

@@ -86,6 +86,8 @@ def lib():
     L.linetr_match.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, i64, vp]
     L.linetr_match_points.argtypes = [vp, vp, i32, vp, i32, f32, i32, vp, vp, vp, i64, vp]
     L.linetr_match_distmat.argtypes = [vp, vp, i32, i32, f32, i32, vp, vp, i64, vp]
+    L.linetr_match_distmat_workspace_bytes.argtypes = [i32, i32]
+    L.linetr_match_distmat_workspace_bytes.restype = i64
     L.linetr_superpoint_heads.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L.linetr_set_precision.argtypes = [vp, i32]
     L.linetr_get_precision.argtypes = [vp]
@@ -102,7 +104,7 @@ def lib():
 EXPORTS = ["linetr_abi_version", "linetr_last_error", "linetr_create", "linetr_destroy", "linetr_prefilter",
            "linetr_prefilter_batch", "linetr_pack_lines", "linetr_tokenize_workspace_bytes", "linetr_tokenize", "linetr_forward_workspace_bytes",
            "linetr_forward", "linetr_describe_workspace_bytes", "linetr_describe", "linetr_match_workspace_bytes", "linetr_match", "linetr_match_points",
-           "linetr_match_distmat", "linetr_superpoint_heads", "linetr_set_precision", "linetr_get_precision", "linetr_debug_posenc", "linetr_debug_gemm", "linetr_set_profiling", "linetr_get_profile"]
+           "linetr_match_distmat", "linetr_match_distmat_workspace_bytes", "linetr_superpoint_heads", "linetr_set_precision", "linetr_get_precision", "linetr_debug_posenc", "linetr_debug_gemm", "linetr_set_profiling", "linetr_get_profile"]
 
 
 class NativeError(RuntimeError):

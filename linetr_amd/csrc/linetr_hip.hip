@@ -1,8 +1,11 @@
 // liblinetr_hip.so -- host side of the C ABI declared in include/linetr_hip.h.
 // Weight preparation (float64 on the host), host pre-filter, launch sequencing, profiling.
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <thread>
 
@@ -10,6 +13,7 @@
 #include "lt_gemm.h"
 #include "lt_gemm_split.h"
 #include "lt_gemm_split16.h"
+#include "lt_gemm_small.h"
 #include "lt_match.h"
 #include "lt_model.h"
 #include "lt_producer.h"
@@ -53,6 +57,7 @@ struct LinetrHandle {
   // side stream: work that is independent of the token-MLP GEMMs (NHWC transpose, line-position MLP) runs here and
   // is joined back with events; created lazily, disabled with LINETR_NO_SIDE_STREAM=1
   hipStream_t side = nullptr;
+  bool side_failed = false;
   hipEvent_t ev_fork = nullptr, ev_tok = nullptr, ev_nhwc = nullptr, ev_lpos = nullptr;
   // profiling
   bool profiling = false;
@@ -71,11 +76,88 @@ bool side_stream_ready(LinetrHandle* h, int n_sublines) {
   static const bool off = getenv("LINETR_NO_SIDE_STREAM") != nullptr;
   if (off || n_sublines < 8192) return false;
   if (h->side) return true;
-  if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; return false; }
-  for (hipEvent_t* e : {&h->ev_fork, &h->ev_tok, &h->ev_nhwc, &h->ev_lpos})
-    if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return false;
+  if (h->side_failed) return false;
+  // create into locals and publish only when all five objects exist: a half-built set must never be used
+  hipStream_t s = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ok = hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; ok && i < 4; ++i) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    if (s) (void)hipStreamDestroy(s);
+    (void)hipGetLastError();
+    h->side_failed = true;
+    return false;
+  }
+  h->side = s;
+  h->ev_fork = ev[0]; h->ev_tok = ev[1]; h->ev_nhwc = ev[2]; h->ev_lpos = ev[3];
   return true;
 }
+
+// Persistent host worker pool (the batched pre-filter used to create and join 7 std::threads per call).
+// Leaked on purpose: the workers are detached and live until process exit, so there is no static-destruction order
+// problem when the library is unloaded from an interpreter that is shutting down.
+class WorkPool {
+ public:
+  static WorkPool& get() {
+    static WorkPool* p = new WorkPool();
+    return *p;
+  }
+  int size() const { return n_workers_ + 1; }
+  // runs fn(0..n-1), the calling thread takes part; one parallel region at a time
+  void run(int n, const std::function<void(int)>& fn) {
+    if (n <= 0) return;
+    if (n == 1 || n_workers_ == 0) { for (int i = 0; i < n; ++i) fn(i); return; }
+    std::lock_guard<std::mutex> region(region_);
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = &fn; n_jobs_ = n; next_ = 0; pending_ = n; ++gen_;
+    }
+    cv_work_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> lk(m_);
+    cv_done_.wait(lk, [&] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  WorkPool() {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    n_workers_ = (int)std::min(15u, hw > 1 ? hw / 2 : 0u);
+    for (int i = 0; i < n_workers_; ++i) std::thread([this] { loop(); }).detach();
+  }
+  void drain() {
+    for (;;) {
+      int i;
+      const std::function<void(int)>* f;
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (!job_ || next_ >= n_jobs_) return;
+        i = next_++;
+        f = job_;
+      }
+      (*f)(i);
+      std::lock_guard<std::mutex> lk(m_);
+      if (--pending_ == 0) cv_done_.notify_all();
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_work_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+      }
+      drain();
+    }
+  }
+  std::mutex m_, region_;
+  std::condition_variable cv_work_, cv_done_;
+  const std::function<void(int)>* job_ = nullptr;
+  int n_jobs_ = 0, next_ = 0, pending_ = 0, n_workers_ = 0;
+  uint64_t gen_ = 0;
+};
 
 int prof_class(LinetrHandle* h, const char* name) {
   for (size_t i = 0; i < h->classes.size(); ++i)
@@ -618,20 +700,19 @@ extern "C" int linetr_prefilter_batch(const double* L, const int32_t* off, int32
                                       LinetrLineRec* h_recs, int32_t capacity, int32_t* cu_k, int32_t* cu_n) {
   if (B < 0 || !off || !cu_k || !cu_n || (B > 0 && off[B] > 0 && !L)) return fail(LINETR_E_ARG, "null argument");
   std::vector<std::vector<LinetrLineRec>> sel(B);
-  int nt = n_threads > 0 ? n_threads : std::min<int>(8, std::max(1u, std::thread::hardware_concurrency()));
-  nt = std::max(1, std::min(nt, B / 8));  // not worth a thread for fewer than 8 images each
-  auto work = [&](int t) {
-    for (int i = t; i < B; i += nt)
+  WorkPool& pool = WorkPool::get();
+  int nt = n_threads > 0 ? n_threads : pool.size();
+  nt = std::max(1, std::min(nt, B / 4));  // not worth a hand-off for fewer than 4 images per chunk
+  // contiguous chunks of images, a few per thread so that uneven images balance out
+  const int chunks = nt == 1 ? 1 : std::min(B, nt * 2);
+  auto work = [&](int c) {
+    const int i0 = (int)((int64_t)B * c / chunks), i1 = (int)((int64_t)B * (c + 1) / chunks);
+    for (int i = i0; i < i1; ++i)
       prefilter_core(L + (size_t)off[i] * 6, off[i + 1] - off[i], height, width, border, min_length, max_keylines,
                      vms ? vms[i] : nullptr, sel[i]);
   };
-  if (nt == 1) work(0);
-  else {
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto& x : th) x.join();
-  }
+  if (chunks == 1) work(0);
+  else pool.run(chunks, work);
   cu_k[0] = cu_n[0] = 0;
   int cur = 0, tcur = 0;
   int64_t k = 0;
@@ -882,7 +963,11 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
       } else {
         ProfScope ps(h, st, "sig_attn_bf16x6", fl, (double)N * D * 16);
         static const bool attn4 = getenv("LINETR_ATTN_4WAVE") != nullptr;   // tuning aid: 128-query blocks
-        if (attn4 || max_n <= 128)
+        // few (image, head) pairs: 64-query blocks, so that a single pair still spreads over 32 CUs instead of 8
+        if (!attn4 && (int64_t)n_images * HEADS * cdiv(max_n, 256) < 64)
+          hipLaunchKernelGGL(sig_attn_split_kernel<2>, dim3(n_images, HEADS, cdiv(max_n, 64)), dim3(128), 0, st, w.qkv, cu_dev,
+                             w.msgp);
+        else if (attn4 || max_n <= 128)
           hipLaunchKernelGGL(sig_attn_split_kernel<4>, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
         else
           hipLaunchKernelGGL(sig_attn_split_kernel<8>, dim3(n_images, HEADS, cdiv(max_n, 256)), dim3(512), 0, st, w.qkv, cu_dev,
@@ -902,6 +987,13 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     LT_LAUNCH_CHECK();
   }
   return LINETR_OK;
+}
+
+// an error return between fork and join must not leave work on the side stream un-ordered with the caller's stream
+void join_side_after_error(LinetrHandle* h, hipStream_t st) {
+  if (!h->side) return;
+  if (hipEventRecord(h->ev_lpos, h->side) == hipSuccess) (void)hipStreamWaitEvent(st, h->ev_lpos, 0);
+  else (void)hipStreamSynchronize(h->side);
 }
 
 int check_cu(const int32_t* h_cu, int n_images) {
@@ -939,7 +1031,9 @@ extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const in
     LT_HIP(hipEventRecord(h->ev_fork, st));
     LT_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
   }
-  return forward_core(h, st, ts, tok->sublines, tok->resp, tok->angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);
+  const int e = forward_core(h, st, ts, tok->sublines, tok->resp, tok->angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);
+  if (e && ts.use_side) join_side_after_error(h, st);
+  return e;
 }
 
 // =============================================================================================
@@ -986,6 +1080,7 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
   if (!d_recs || !d_dense_desc || !d_dense_score || !d_line_desc || !d_ws) return fail(LINETR_E_ARG, "describe: null pointer");
   if (T < 1 || T > 4096 || height % 8 || width % 8) return fail(LINETR_E_ARG, "describe: bad max_tokens / image size");
   if (n_real < N || n_real > (int64_t)N * T) return fail(LINETR_E_ARG, "describe: implausible real-token count");
+  if (out.desc && !out.pnt) return fail(LINETR_E_ARG, "describe: out.desc requires out.pnt");
   if (ws_bytes < linetr_describe_workspace_bytes(h, n_images, height, width, N, n_real))
     return fail(LINETR_E_WORKSPACE, "describe: workspace too small");
   const int64_t rows = n_real + n_images;
@@ -1046,7 +1141,6 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
   }
   if (out.desc) {  // the reference's dense tensor was asked for as well
     if (use_side) LT_HIP(hipStreamWaitEvent(st, h->ev_nhwc, 0));
-    if (!out.pnt) return fail(LINETR_E_ARG, "describe: out.desc requires out.pnt");
     const int64_t ntok = (int64_t)N * T;
     ProfScope ps(h, st, "sample_desc", 0, (double)ntok * D * 4 * 2);
     hipLaunchKernelGGL(sample_desc_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, st, out.pnt, dw.s2l_g, d_recs,
@@ -1057,17 +1151,62 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
   ts.cpnt = dw.cpnt; ts.cscore = dw.cscore; ts.nhwc = nhwc_map; ts.recs = d_recs; ts.sub2line_g = dw.s2l_g;
   ts.rows = rows; ts.first_pad = n_real; ts.Hc = Hc; ts.Wc = Wc; ts.align_corners = align_corners;
   ts.use_side = use_side;
-  return forward_core(h, st, ts, sublines, resp, angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);
+  const int e = forward_core(h, st, ts, sublines, resp, angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);
+  if (e && use_side) join_side_after_error(h, st);
+  return e;
 }
 
 // =============================================================================================
 // matcher
 // =============================================================================================
 
+namespace {
+// Pinned staging ring for the small host tables the matcher uploads (PairDesc array, identity maps).  A slot is
+// reused only after the copy that read it has completed (event), so no entry point has to synchronise the stream.
+struct PinnedRing {
+  struct Slot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; };
+  Slot slots[8];
+  int next = 0;
+  std::mutex m;
+  // returns a host pointer of >= bytes, or nullptr; *slot_out identifies the slot for commit()
+  void* acquire(size_t bytes, int* slot_out) {
+    std::lock_guard<std::mutex> lk(m);
+    Slot& s = slots[next];
+    *slot_out = next;
+    next = (next + 1) % 8;
+    if (s.busy) { (void)hipEventSynchronize(s.ev); s.busy = false; }
+    if (s.cap < bytes) {
+      if (s.p) (void)hipHostFree(s.p);
+      s.p = nullptr; s.cap = 0;
+      const size_t cap = std::max<size_t>(align_up((int64_t)bytes * 2, 4096), 16384);
+      if (hipHostMalloc(&s.p, cap, hipHostMallocDefault) != hipSuccess) { s.p = nullptr; return nullptr; }
+      s.cap = cap;
+    }
+    if (!s.ev && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { s.ev = nullptr; return nullptr; }
+    return s.p;
+  }
+  int commit(int slot, hipStream_t st) {   // call after the last async copy out of the slot has been enqueued
+    std::lock_guard<std::mutex> lk(m);
+    LT_HIP(hipEventRecord(slots[slot].ev, st));
+    slots[slot].busy = true;
+    return 0;
+  }
+};
+PinnedRing& staging_ring() {   // leaked: see WorkPool
+  static PinnedRing* r = new PinnedRing();
+  return *r;
+}
+
+// ints of argmin scratch one pair needs (layout in lt_match.h)
+int64_t pair_scratch_ints(int k0, int k1) { return 2 * (int64_t)k0 + k1 + 2 * (int64_t)cdiv(std::max(k0, 1), PM_ROWS) * k1 + 8; }
+}  // namespace
+
 extern "C" int64_t linetr_match_workspace_bytes(int32_t n_pairs, int64_t sum_n0n1, int64_t sum_k0k1, int64_t sum_k) {
   (void)sum_k0k1;
-  return align_up((int64_t)n_pairs * sizeof(PairDesc), 256) + align_up(sum_n0n1 * 4, 256) +
-         align_up((3 * sum_k + 4 * (int64_t)n_pairs) * 4, 256) + 256;
+  // scratch bound: sum over pairs of pair_scratch_ints(k0,k1) <= 3 sum_k + 2 (sum_k0k1 / PM_ROWS + sum_k) + 8 P, and
+  // k0 k1 <= n0 n1
+  const int64_t scratch = 5 * sum_k + 2 * (sum_n0n1 / PM_ROWS + 1) + 8 * (int64_t)n_pairs;
+  return align_up((int64_t)n_pairs * sizeof(PairDesc), 256) + align_up(sum_n0n1 * 4, 256) + align_up(scratch * 4, 256) + 256;
 }
 
 extern "C" int linetr_match(LinetrHandle* h, int32_t P, const int32_t* dims, const float* d_desc0, const int64_t* off_n0,
@@ -1079,9 +1218,11 @@ extern "C" int linetr_match(LinetrHandle* h, int32_t P, const int32_t* dims, con
   if (!dims || !off_n0 || !off_n1 || !off_dk || !off_k0 || !d_ws) return fail(LINETR_E_ARG, "match: null argument");
   hipStream_t st = (hipStream_t)stream;
   if (h) LT_HIP(hipSetDevice(h->device));
-  std::vector<PairDesc> pd(P);
+  int slot = 0;
+  PairDesc* pd = (PairDesc*)staging_ring().acquire((size_t)P * sizeof(PairDesc), &slot);
+  if (!pd) return fail(LINETR_E_HIP, "match: pinned staging allocation failed");
   int64_t od = 0, os = 0, sum_k = 0;
-  int max_n0 = 0, max_n1 = 0;
+  int max_n0 = 0, max_n1 = 0, max_k1 = 0, max_chunks = 0;
   double flops = 0;
   for (int p = 0; p < P; ++p) {
     PairDesc& d = pd[p];
@@ -1090,17 +1231,22 @@ extern "C" int linetr_match(LinetrHandle* h, int32_t P, const int32_t* dims, con
       return fail(LINETR_E_ARG, "match: bad dims for pair %d", p);
     d.off_n0 = off_n0[p]; d.off_n1 = off_n1[p]; d.off_dk = off_dk[p]; d.off_k0 = off_k0[p];
     d.off_d = od; od += (int64_t)d.n0 * d.n1;
-    d.off_seg = os; os += 3 * (int64_t)(d.k0 + d.k1) / 1 + 4;  // seg0,seg1,row_arg,col_arg,row_min (<= 3*(k0+k1)+2)
+    d.chunks = cdiv(std::max(d.k0, 1), PM_ROWS);
+    d.pad_ = 0;
+    d.off_seg = os; os += pair_scratch_ints(d.k0, d.k1);
     sum_k += d.k0 + d.k1;
     max_n0 = std::max(max_n0, d.n0); max_n1 = std::max(max_n1, d.n1);
+    max_k1 = std::max(max_k1, d.k1); max_chunks = std::max(max_chunks, d.chunks);
     flops += 2.0 * d.n0 * d.n1 * D;
   }
+  if (max_k1 > PM_MAX_K1) return fail(LINETR_E_ARG, "match: more than %d key-lines in one image", PM_MAX_K1);
   if (ws_bytes < linetr_match_workspace_bytes(P, od, 0, sum_k)) return fail(LINETR_E_WORKSPACE, "match: workspace too small");
   char* base = (char*)d_ws;
   PairDesc* d_pd = (PairDesc*)base;
   float* d_dist = (float*)(base + align_up((int64_t)P * sizeof(PairDesc), 256));
   int* d_scr = (int*)((char*)d_dist + align_up(od * 4, 256));
-  LT_HIP(hipMemcpyAsync(d_pd, pd.data(), P * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+  LT_HIP(hipMemcpyAsync(d_pd, pd, P * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+  if (int e = staging_ring().commit(slot, st)) return e;
   if (max_n0 > 0 && max_n1 > 0) {
     if (!d_desc0 || !d_desc1 || !d_s2l0 || !d_s2l1 || !d_dk) return fail(LINETR_E_ARG, "match: null tensor");
     ProfScope ps(h, st, "pair_dist", flops, 0);
@@ -1110,13 +1256,15 @@ extern "C" int linetr_match(LinetrHandle* h, int32_t P, const int32_t* dims, con
   }
   {
     ProfScope ps(h, st, "pair_match", 0, 0);
-    hipLaunchKernelGGL(pair_match_kernel, dim3(P), dim3(256), 0, st, d_pd, d_s2l0, d_s2l1, d_dist, thr, mutual, d_dk,
-                       d_match01, d_scr);
+    if (max_k1 > 0) {
+      hipLaunchKernelGGL(pair_pool_kernel, dim3(max_chunks, P), dim3(256), (size_t)(max_k1 + PM_ROWS + 2) * sizeof(int), st,
+                         d_pd, d_s2l0, d_s2l1, d_dist, d_dk, d_scr);
+      LT_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(pair_final_kernel, dim3(P), dim3(256), 0, st, d_pd, thr, mutual, d_match01, d_scr);
     LT_LAUNCH_CHECK();
   }
-  // the PairDesc table was copied from a stack-owned vector: make sure the copy has been consumed
-  LT_HIP(hipStreamSynchronize(st));
-  return LINETR_OK;
+  return LINETR_OK;   // fully asynchronous: the PairDesc table was staged in pinned memory owned by the ring
 }
 
 extern "C" int linetr_match_points(LinetrHandle* h, const float* d0_cn, int32_t n0, const float* d1_cn, int32_t n1,
@@ -1136,10 +1284,16 @@ extern "C" int linetr_match_points(LinetrHandle* h, const float* d0_cn, int32_t 
   float* r1 = (float*)base; base += align_up((int64_t)std::max(n1, 1) * D * 4, 256);
   int* id0 = (int*)base; base += align_up((int64_t)n0 * 4, 256);
   int* id1 = (int*)base; base += align_up((int64_t)std::max(n1, 1) * 4, 256);
-  std::vector<int> iota(std::max(n0, n1));
-  std::iota(iota.begin(), iota.end(), 0);
-  LT_HIP(hipMemcpyAsync(id0, iota.data(), n0 * 4, hipMemcpyHostToDevice, st));
-  if (n1 > 0) LT_HIP(hipMemcpyAsync(id1, iota.data(), n1 * 4, hipMemcpyHostToDevice, st));
+  {
+    int slot = 0;
+    const int m = std::max(n0, n1);
+    int* iota = (int*)staging_ring().acquire((size_t)m * sizeof(int), &slot);
+    if (!iota) return fail(LINETR_E_HIP, "match_points: pinned staging allocation failed");
+    std::iota(iota, iota + m, 0);
+    LT_HIP(hipMemcpyAsync(id0, iota, n0 * 4, hipMemcpyHostToDevice, st));
+    if (n1 > 0) LT_HIP(hipMemcpyAsync(id1, iota, n1 * 4, hipMemcpyHostToDevice, st));
+    if (int e = staging_ring().commit(slot, st)) return e;
+  }
   hipLaunchKernelGGL(transpose_cn_kernel, dim3(cdiv(n0, 32), D / 32), dim3(32, 8), 0, st, d0_cn, r0, D, n0);
   if (n1 > 0) hipLaunchKernelGGL(transpose_cn_kernel, dim3(cdiv(n1, 32), D / 32), dim3(32, 8), 0, st, d1_cn, r1, D, n1);
   LT_LAUNCH_CHECK();
@@ -1149,30 +1303,49 @@ extern "C" int linetr_match_points(LinetrHandle* h, const float* d0_cn, int32_t 
                       ws_bytes - need_t, stream);
 }
 
+extern "C" int64_t linetr_match_distmat_workspace_bytes(int32_t n0, int32_t n1) {
+  n0 = std::max(n0, 0); n1 = std::max(n1, 0);
+  return 256 + align_up((int64_t)n0 * 4, 256) + align_up((int64_t)std::max(n1, 1) * 4, 256) +
+         align_up((int64_t)n0 * std::max(n1, 1) * 4, 256) + align_up(pair_scratch_ints(n0, n1) * 4, 256);
+}
+
 extern "C" int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_t n0, int32_t n1, float thr,
                                     int32_t mutual, int32_t* d_match01, void* d_ws, int64_t ws_bytes, void* stream) {
   if (n0 < 0 || n1 < 0) return fail(LINETR_E_ARG, "match_distmat: bad argument");
   if (n0 == 0) return LINETR_OK;
+  if (n1 > PM_MAX_K1) return fail(LINETR_E_ARG, "match_distmat: more than %d columns", PM_MAX_K1);
   hipStream_t st = (hipStream_t)stream;
   if (h) LT_HIP(hipSetDevice(h->device));
-  // scratch: PairDesc | identity maps | Dk copy | segment/argmin ints
+  // scratch: PairDesc | identity maps | Dk copy | argmin ints
   const int64_t o_id0 = 256, o_id1 = o_id0 + align_up((int64_t)n0 * 4, 256);
   const int64_t o_dk = o_id1 + align_up((int64_t)std::max(n1, 1) * 4, 256);
   const int64_t o_scr = o_dk + align_up((int64_t)n0 * std::max(n1, 1) * 4, 256);
-  const int64_t need = o_scr + align_up((3 * (int64_t)(n0 + n1) + 4) * 4, 256);
+  const int64_t need = linetr_match_distmat_workspace_bytes(n0, n1);
   if (!d_ws || ws_bytes < need) return fail(LINETR_E_WORKSPACE, "match_distmat: workspace too small (need %lld)", (long long)need);
   char* base = (char*)d_ws;
-  PairDesc pd{};
-  pd.n0 = pd.k0 = n0; pd.n1 = pd.k1 = n1;
-  std::vector<int> iota(std::max(n0, n1));
-  std::iota(iota.begin(), iota.end(), 0);
-  LT_HIP(hipMemcpyAsync(base, &pd, sizeof pd, hipMemcpyHostToDevice, st));
-  LT_HIP(hipMemcpyAsync(base + o_id0, iota.data(), n0 * 4, hipMemcpyHostToDevice, st));
-  if (n1 > 0) LT_HIP(hipMemcpyAsync(base + o_id1, iota.data(), n1 * 4, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(pair_match_kernel, dim3(1), dim3(256), 0, st, (const PairDesc*)base, (const int*)(base + o_id0),
-                     (const int*)(base + o_id1), d_dist, thr, mutual, (float*)(base + o_dk), d_match01, (int*)(base + o_scr));
+  const int m = std::max(n0, n1);
+  int slot = 0;
+  char* host = (char*)staging_ring().acquire(256 + (size_t)m * sizeof(int), &slot);
+  if (!host) return fail(LINETR_E_HIP, "match_distmat: pinned staging allocation failed");
+  PairDesc* pd = (PairDesc*)host;
+  *pd = PairDesc{};
+  pd->n0 = pd->k0 = n0; pd->n1 = pd->k1 = n1;
+  pd->chunks = cdiv(n0, PM_ROWS);
+  int* iota = (int*)(host + 256);
+  std::iota(iota, iota + m, 0);
+  LT_HIP(hipMemcpyAsync(base, pd, sizeof(PairDesc), hipMemcpyHostToDevice, st));
+  LT_HIP(hipMemcpyAsync(base + o_id0, iota, n0 * 4, hipMemcpyHostToDevice, st));
+  if (n1 > 0) LT_HIP(hipMemcpyAsync(base + o_id1, iota, n1 * 4, hipMemcpyHostToDevice, st));
+  if (int e = staging_ring().commit(slot, st)) return e;
+  if (n1 > 0) {
+    hipLaunchKernelGGL(pair_pool_kernel, dim3(pd->chunks, 1), dim3(256), (size_t)(n1 + PM_ROWS + 2) * sizeof(int), st,
+                       (const PairDesc*)base, (const int*)(base + o_id0), (const int*)(base + o_id1), d_dist,
+                       (float*)(base + o_dk), (int*)(base + o_scr));
+    LT_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(pair_final_kernel, dim3(1), dim3(256), 0, st, (const PairDesc*)base, thr, mutual, d_match01,
+                     (int*)(base + o_scr));
   LT_LAUNCH_CHECK();
-  LT_HIP(hipStreamSynchronize(st));
   return LINETR_OK;
 }
 

@@ -52,6 +52,12 @@ inline int fail(int code, const char* fmt, ...) {
   } while (0)
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+// bit of the calling thread's current HIP device (function attributes such as the dynamic-LDS opt-in are per device)
+inline unsigned long long current_device_bit() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return 1ull << (dev & 63);
+}
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- device helpers -------------------------------------------------------------------------

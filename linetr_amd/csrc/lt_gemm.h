@@ -151,11 +151,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 template <int BM, int BN, int WM, int WN>
 inline int gemm_launch_t(const GemmArgs& g, int groups, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * (BM + BN) * GEMM_LDS_STRIDE * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;   // one bit per device: the opt-in is a per-device function attribute
+  const unsigned long long dev_bit = current_device_bit();
+  if (!(attr_done & dev_bit)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<BM, BN, WM, WN>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+    attr_done |= dev_bit;
   }
   dim3 grid(g.N / BN, cdiv(g.M, BM), groups);
   hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, st, g);

@@ -437,11 +437,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
 template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0, int PFD = 1, bool PIPE = false>
 inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t st) {
   constexpr size_t lds = (size_t)(DB ? 2 : 1) * (BM + BN) * (PL * 64 + 16);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;   // one bit per device: the opt-in is a per-device function attribute
+  const unsigned long long dev_bit = current_device_bit();
+  if (!(attr_done & dev_bit)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT, PFD, PIPE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+    attr_done |= dev_bit;
   }
   dim3 grid((sa.g.N / BN) * cdiv(sa.g.M, BM), groups);
   hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT, PFD, PIPE>), grid, dim3(WM * WN * 64), lds, st, sa);
@@ -450,10 +451,14 @@ inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t
 template <int PL, int FMT>
 inline void gemm_split16_launch(const SplitGemmArgs& sa, hipStream_t st);   // lt_gemm_split16.h (112-row tiles)
 inline bool split16_wins(const GemmArgs& g, int groups);
+template <int PL, int FMT>
+inline void gemm_split_small_launch(const SplitGemmArgs& sa, int groups, hipStream_t st);   // lt_gemm_small.h (single-pair sizes)
+inline bool small_gemm_wins(const GemmArgs& g, int groups);
 
 // Tile choice: 8-wave 256x128 blocks (2 waves/SIMD inside one block, half the LDS staging per MFMA) once
 // there are enough of them to occupy most CUs; smaller tiles for small M so the grid still fills the chip.
 inline const char* split_tile_name(const GemmArgs& g, int groups, int pl = 3) {
+  if (small_gemm_wins(g, groups)) return "32x32k4";   // latency-bound sizes: barrier-free K-split kernel
   if (g.N % 128 != 0) return "128x64";
   const int64_t t256 = (int64_t)cdiv(g.M, 256) * (g.N / 128) * groups;
   // same block size either way; 128x256 halves the A rows a block has to split per MFMA (+2-4 % measured)
@@ -475,7 +480,8 @@ inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st
     return fail(LINETR_E_ARG, "gemm_split: unsupported shape M=%d N=%d K=%d", g.M, g.N, g.K);
   static const char* tile_env = getenv("LINETR_GEMM_TILE");  // tuning aid: force a tile
   const char* tile = tile_env ? tile_env : split_tile_name(g, groups, PL);
-  if (!strcmp(tile, "112x256")) gemm_split16_launch<PL, FMT>(sa, st);
+  if (!strcmp(tile, "32x32k4")) gemm_split_small_launch<PL, FMT>(sa, groups, st);
+  else if (!strcmp(tile, "112x256")) gemm_split16_launch<PL, FMT>(sa, st);
   else if (g.N % 128 != 0 || !strcmp(tile, "128x64")) gemm_split_launch_t<128, 64, 4, 1, PL, true, FMT>(sa, groups, st);
   else if (!strcmp(tile, "256x128")) {
     static const bool nopipe = getenv("LINETR_GEMM_NOPIPE") != nullptr;   // tuning aid: the pre-pipelining main loop

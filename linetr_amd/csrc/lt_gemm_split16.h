@@ -212,11 +212,12 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(SplitGemmArgs sa) {
 template <int PL, int FMT = 0>
 inline void gemm_split16_launch(const SplitGemmArgs& sa, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * (112 + 256) * (PL * 64 + 16);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;   // one bit per device: the opt-in is a per-device function attribute
+  const unsigned long long dev_bit = current_device_bit();
+  if (!(attr_done & dev_bit)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split16_kernel<PL, FMT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+    attr_done |= dev_bit;
   }
   dim3 grid((sa.g.N / 256) * cdiv(sa.g.M, 112));
   hipLaunchKernelGGL((gemm_split16_kernel<PL, FMT>), grid, dim3(512), lds, st, sa);

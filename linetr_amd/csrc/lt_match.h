@@ -13,7 +13,12 @@ struct PairDesc {          // one image pair (device copy lives in the workspace
   int64_t off_dk;          // offset of Dk [k0,k1] in the output
   int64_t off_k0;          // offset of match01 [k0]
   int64_t off_seg;         // offset of the segment tables / argmin scratch (ints) in the workspace
+  int32_t chunks;          // row chunks of pair_pool_kernel (cdiv(k0, PM_ROWS))
+  int32_t pad_;
 };
+
+constexpr int PM_ROWS = 8;          // key-line rows of Dk per block of pair_pool_kernel
+constexpr int PM_MAX_K1 = 12000;    // seg1 table of a pair must fit the block's LDS (48 KB)
 
 // D[a][b] = max(2 - 2 * <d0[a], d1[b]>, 0), fp32 MFMA, 64x64 tile per block, K = 256.
 // grid (tiles_b, tiles_a, pair)
@@ -65,36 +70,47 @@ __global__ __launch_bounds__(256) void pair_dist_kernel(const PairDesc* __restri
   }
 }
 
-// One block per pair: key-line pooling (mean of sub-line distances), row/column first-index argmin,
-// strict threshold and mutual check.  Deterministic (fixed summation order, no atomics).
-// Scratch ints at off_seg: seg0[k0+1], seg1[k1+1], row_arg[k0], col_arg[k1]; row_min floats alias.
-__global__ __launch_bounds__(256) void pair_match_kernel(const PairDesc* __restrict__ pairs,
-                                                         const int* __restrict__ s2l0, const int* __restrict__ s2l1,
-                                                         const float* __restrict__ dist, float thr, int mutual,
-                                                         float* __restrict__ dk_out, int* __restrict__ match01,
-                                                         int* __restrict__ scratch) {
-  const PairDesc pd = pairs[blockIdx.x];
+// ---------------------------------------------------------------------------------------------
+// Key-line pooling + mutual nearest neighbour (subline2keyline + nn_matcher_distmat), two launches (a single block per
+// pair took 150 us for one 200 x 200 pair):
+//   pair_pool_kernel   grid (row chunks, pairs): PM_ROWS key-line rows of Dk each -- segmented mean, row argmin, and the
+//                      chunk's partial column argmin;
+//   pair_final_kernel  grid (pairs): column partials combined in chunk order (first index wins), threshold + mutual check.
+// Deterministic: fixed summation order, no atomics; np.argmin's first-minimum rule on rows and columns.
+// Sub-lines of a key-line are contiguous and key-line ids are non-decreasing, so a segment start is a lower bound.
+// Scratch ints of a pair at off_seg: row_arg[k0] | row_min[k0] | col_arg[k1] | part_val[chunks][k1] | part_arg[chunks][k1]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int seg_lower_bound(const int* __restrict__ m, int n, int key) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (m[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void pair_pool_kernel(const PairDesc* __restrict__ pairs, const int* __restrict__ s2l0,
+                                                        const int* __restrict__ s2l1, const float* __restrict__ dist,
+                                                        float* __restrict__ dk_out, int* __restrict__ scratch) {
+  extern __shared__ int pm_lds[];                    // seg1[k1+1] | seg0[PM_ROWS+1]
+  const PairDesc pd = pairs[blockIdx.y];
+  const int chunk = blockIdx.x;
+  if (chunk >= pd.chunks || pd.k1 <= 0) return;
   const int tid = threadIdx.x;
-  int* seg0 = scratch + pd.off_seg;
-  int* seg1 = seg0 + pd.k0 + 1;
-  int* row_arg = seg1 + pd.k1 + 1;
-  int* col_arg = row_arg + pd.k0;
-  float* row_min = reinterpret_cast<float*>(col_arg + pd.k1);
+  const int i0 = chunk * PM_ROWS, rows = min(PM_ROWS, pd.k0 - i0);
+  int* seg1 = pm_lds;
+  int* seg0 = pm_lds + pd.k1 + 1;
   const int* m0 = s2l0 + pd.off_n0;
   const int* m1 = s2l1 + pd.off_n1;
-  // segment starts: sub-lines of a key-line are contiguous and key-line ids non-decreasing
-  for (int n = tid; n < pd.n0; n += 256)
-    if (n == 0 || m0[n] != m0[n - 1]) seg0[m0[n]] = n;
-  for (int n = tid; n < pd.n1; n += 256)
-    if (n == 0 || m1[n] != m1[n - 1]) seg1[m1[n]] = n;
-  if (tid == 0) { seg0[pd.k0] = pd.n0; seg1[pd.k1] = pd.n1; }
+  for (int j = tid; j <= pd.k1; j += 256) seg1[j] = j == pd.k1 ? pd.n1 : seg_lower_bound(m1, pd.n1, j);
+  if (tid <= rows) seg0[tid] = i0 + tid == pd.k0 ? pd.n0 : seg_lower_bound(m0, pd.n0, i0 + tid);
   __syncthreads();
   const float* Dp = dist + pd.off_d;
-  float* Dk = dk_out + pd.off_dk;
-  const int total = pd.k0 * pd.k1;
+  float* Dk = dk_out + pd.off_dk + (int64_t)i0 * pd.k1;
+  const int total = rows * pd.k1;
   for (int e = tid; e < total; e += 256) {
-    const int i = e / pd.k1, j = e % pd.k1;
-    const int a0 = seg0[i], a1 = seg0[i + 1], b0 = seg1[j], b1 = seg1[j + 1];
+    const int r = e / pd.k1, j = e - r * pd.k1;
+    const int a0 = seg0[r], a1 = seg0[r + 1], b0 = seg1[j], b1 = seg1[j + 1];
     float v;
     if (a1 - a0 == 1 && b1 - b0 == 1) {
       v = Dp[(int64_t)a0 * pd.n1 + b0];
@@ -110,15 +126,16 @@ __global__ __launch_bounds__(256) void pair_match_kernel(const PairDesc* __restr
     Dk[e] = v;
   }
   __syncthreads();
-  // argmin over clip(min=0) values; np.argmin returns the first minimum.
-  // Rows: one wave per row, lanes stride over the columns (coalesced), (value, index) butterfly reduction that
-  // keeps the smaller index on ties.  Columns: one thread per column, coalesced across threads.
+  int* row_arg = scratch + pd.off_seg;
+  float* row_min = reinterpret_cast<float*>(row_arg + pd.k0);
+  float* part_val = reinterpret_cast<float*>(row_arg + 2 * pd.k0 + pd.k1) + (int64_t)chunk * pd.k1;
+  int* part_arg = row_arg + 2 * pd.k0 + pd.k1 + (int64_t)pd.chunks * pd.k1 + (int64_t)chunk * pd.k1;
   {
     const int lane = tid & 63, wave = tid >> 6;
-    for (int i = wave; i < pd.k0; i += 4) {
+    for (int r = wave; r < rows; r += 4) {
       float best = INFINITY; int arg = 0x7fffffff;
       for (int j = lane; j < pd.k1; j += 64) {
-        const float v = fmaxf(Dk[(int64_t)i * pd.k1 + j], 0.f);
+        const float v = fmaxf(Dk[(int64_t)r * pd.k1 + j], 0.f);
         if (v < best) { best = v; arg = j; }       // ascending j per lane: strict < keeps the first
       }
 #pragma unroll
@@ -127,14 +144,34 @@ __global__ __launch_bounds__(256) void pair_match_kernel(const PairDesc* __restr
         const int oa = __shfl_xor(arg, o, 64);
         if (ov < best || (ov == best && oa < arg)) { best = ov; arg = oa; }
       }
-      if (lane == 0) { row_arg[i] = arg; row_min[i] = best; }
+      if (lane == 0) { row_arg[i0 + r] = arg == 0x7fffffff ? 0 : arg; row_min[i0 + r] = best; }   // all-inf / NaN row: index 0
     }
   }
   for (int j = tid; j < pd.k1; j += 256) {
     float best = INFINITY; int arg = 0;
-    for (int i = 0; i < pd.k0; ++i) {
-      const float v = fmaxf(Dk[(int64_t)i * pd.k1 + j], 0.f);
-      if (v < best) { best = v; arg = i; }
+    for (int r = 0; r < rows; ++r) {
+      const float v = fmaxf(Dk[(int64_t)r * pd.k1 + j], 0.f);
+      if (v < best) { best = v; arg = i0 + r; }
+    }
+    part_val[j] = best;
+    part_arg[j] = arg;
+  }
+}
+
+__global__ __launch_bounds__(256) void pair_final_kernel(const PairDesc* __restrict__ pairs, float thr, int mutual,
+                                                         int* __restrict__ match01, int* __restrict__ scratch) {
+  const PairDesc pd = pairs[blockIdx.x];
+  const int tid = threadIdx.x;
+  int* row_arg = scratch + pd.off_seg;
+  const float* row_min = reinterpret_cast<const float*>(row_arg + pd.k0);
+  int* col_arg = row_arg + 2 * pd.k0;
+  const float* part_val = reinterpret_cast<const float*>(col_arg + pd.k1);
+  const int* part_arg = col_arg + pd.k1 + (int64_t)pd.chunks * pd.k1;
+  for (int j = tid; j < pd.k1; j += 256) {
+    float best = INFINITY; int arg = 0;
+    for (int c = 0; c < pd.chunks; ++c) {            // ascending rows: strict < keeps the first minimum
+      const float v = part_val[(int64_t)c * pd.k1 + j];
+      if (v < best) { best = v; arg = part_arg[(int64_t)c * pd.k1 + j]; }
     }
     col_arg[j] = arg;
   }

@@ -41,15 +41,22 @@ def match01_to_matrix(m01: np.ndarray, n1: int) -> np.ndarray:
 
 
 def nn_matcher_distmat(dist_mat, nn_thresh, is_mutual_NN=True):
-    """Nearest-neighbour matching on a [1,n0,n1] distance matrix (reference: nn_matcher.py:3-31)."""
+    """Nearest-neighbour matching on a [1,n0,n1] distance matrix (reference: nn_matcher.py:3-31).
+
+    Contract of the device matcher: the argmin / threshold run in float32 (the dtype `Matching` passes; a float64
+    matrix is rounded to float32 first, so values within one float32 ulp of each other or of `nn_thresh` may match
+    differently from the reference's float64 comparison) and the matrix must be NaN-free: np.argmin returns the first
+    NaN, the kernel would skip it, so a NaN raises ValueError here instead of silently diverging."""
     dist_mat = np.asarray(dist_mat)
     n0, n1 = dist_mat.shape[1], dist_mat.shape[2]
     if n0 == 0 or n1 == 0:
         return np.zeros((1, n0, n1))
+    if np.isnan(dist_mat).any():
+        raise ValueError("nn_matcher_distmat: the distance matrix contains NaN")
     dev = _device()
     d = torch.from_numpy(np.ascontiguousarray(dist_mat[0], dtype=np.float32)).to(dev)
     m01 = torch.empty((n0,), dtype=torch.int32, device=dev)
-    need = 4 * (n0 * n1 + 4 * (n0 + n1)) + 4096
+    need = nat.lib().linetr_match_distmat_workspace_bytes(n0, n1)
     ws = _workspace(dev, need)
     nat.check(nat.lib().linetr_match_distmat(None, d.data_ptr(), n0, n1, float(np.float32(nn_thresh)),
                                              int(bool(is_mutual_NN)), m01.data_ptr(), ws.data_ptr(), ws.numel(),
