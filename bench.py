@@ -7,13 +7,21 @@
 
 Metric (BASELINE.json / SURVEY.md section 8d): line-descriptors/sec = sub-line descriptors written to
 `line_desc` / wall time of tokenise + forward (host pre-filter, H2D of the line records, tokeniser,
-descriptor network; for N>1 also the single RCCL all-gather of the descriptors).  SuperPoint dense
-maps are already resident in HBM, detected lines are resident on the host.  A "step" is one pass of
+descriptor network; for N>1 also the single RCCL all-gather of the descriptors).  The dense maps are
+already resident in HBM in the layout the repo's own producer (linetr_superpoint_heads: score map +
+channel-last descriptor map) emits, detected lines are resident on the host.  A "step" is one pass of
 that path over one batch of P synthetic image pairs per GPU (weak scaling: every rank gets its own P
 pairs).  Default workload = cfg3 of BASELINE.json (64 pairs of 640x480, 200 lines -> 199 sub-lines x
-21 tokens per image), the configuration the roofline is defined on; --workload cfg2 / cfg5 select the
-single-pair and the long-line configurations.  pair-match ms and the single-pair latency are reported
-in the same JSON line.  One JSON line is printed by rank 0.
+21 tokens per image), the configuration the roofline is defined on.  The same JSON line carries
+`cfg2` (single pair: latency) and `cfg5` (1280x960, 600 lines x 41 tokens) sub-objects, pair-match ms,
+the step fed with the reference's NCHW map, and the CPU baseline.
+
+--workload cfg4 runs BASELINE.json's fourth configuration instead: 1024 homography-augmented pairs,
+STRONG-sharded round-robin over the ranks (pair p -> rank p mod R), ONE all-gather of the descriptor
+slabs, then global matching of every local query image against candidates taken from the gathered set;
+a step is the whole job and the JSON carries compute_ms / gather_ms / global_match_ms.
+
+One JSON line is printed by rank 0.
 """
 from __future__ import annotations
 
@@ -33,13 +41,15 @@ from linetr_amd import parallel, synth  # noqa: E402
 from linetr_amd.engine import Engine  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA
 HBM_PEAK_GBS = 8000.0
-SETTLE_STEPS = 25      # untimed steps run once before the W warm-up steps (see main)
+PROFILE_TAG = "r02"             # profiles/<tag>_pmc_traffic.json, profiles/<tag>_gemm_pmc.json
 
 WORKLOADS = {
     # name: (H, W, lines/image, len_lo, len_hi, max_tokens, default pairs per GPU)
     "cfg2": (480, 640, 200, 17.0, 167.0, 21, 1),
     "cfg3": (480, 640, 200, 17.0, 167.0, 21, 64),
+    "cfg4": (480, 640, 200, 17.0, 167.0, 21, 64),     # pairs per describe call; the job is --pairs-total pairs
     "cfg5": (960, 1280, 600, 40.0, 327.0, 41, 8),
 }
 LINE_CFG = dict(min_length=16, token_distance=8, remove_borders=8, max_keylines=-1, nn_threshold=0.8)
@@ -53,7 +63,10 @@ def algorithmic_flops_per_image(N, T, K=None):
                   + 7 * (N * 655360 + 512 * N * N) + N * 65536)
 
 
-def make_inputs(workload, pairs, rank, device):
+def make_inputs(workload, pairs, rank, device, eng):
+    """Synthetic detector output + dense maps of `pairs` image pairs.  The dense maps are generated in the reference's
+    NCHW layout and passed once (outside any timed region) through the repo's producer layout, so that the default
+    step is fed what FusedHeadSuperPoint feeds it; the NCHW map is kept for the secondary measurement."""
     H, W, n_lines, lo, hi, T, _ = WORKLOADS[workload]
     lines, dds, dss = [], [], []
     for p in range(pairs):
@@ -66,14 +79,16 @@ def make_inputs(workload, pairs, rank, device):
             dss.append(ds)
     dd = torch.cat(dds).to(device)
     ds = torch.cat(dss).to(device)
-    return lines, dd, ds, (H, W), T
+    nhwc = dd.permute(0, 2, 3, 1).contiguous()     # layout change only: values identical to the NCHW map
+    return lines, dd, nhwc, ds, (H, W), T
 
 
 class Pipeline:
-    def __init__(self, eng, lines, dd, ds, hw, T, world, pairs, n_streams=1):
+    def __init__(self, eng, lines, dd, ds, hw, T, world, pairs, n_streams=1, layout="nhwc"):
         self.eng, self.lines, self.dd, self.ds, self.hw, self.T = eng, lines, dd, ds, hw, T
         self.world, self.pairs = world, pairs
         self.n_streams = n_streams
+        self.layout = layout
         self.n_img_cap = 2 * pairs
         self.rows_cap = sum(len(l) for l in lines)
         self.packed = [None, None]      # double-buffered: the all-gather of step i overlaps the compute of step i+1
@@ -84,11 +99,22 @@ class Pipeline:
         np.cumsum([len(l) for l in lines], out=self.offsets[1:])
         self.cat = np.ascontiguousarray(np.concatenate(lines), dtype=np.float64)
 
-    def describe(self):
+    def prefilter_only(self):
         e, c = self.eng, LINE_CFG
-        return e.describe_lines(self.cat, self.offsets, self.dd, self.ds, remove_borders=c["remove_borders"],
-                                min_length=c["min_length"], max_keylines=c["max_keylines"],
-                                token_distance=c["token_distance"], max_tokens=self.T, n_streams=self.n_streams)
+        return e.prefilter(self.cat, self.hw[0], self.hw[1], remove_borders=c["remove_borders"], min_length=c["min_length"],
+                           max_keylines=c["max_keylines"], token_distance=c["token_distance"], max_tokens=self.T,
+                           offsets=self.offsets)
+
+    def describe(self, dd=None, layout=None):
+        e, c = self.eng, LINE_CFG
+        return e.describe_lines(self.cat, self.offsets, self.dd if dd is None else dd, self.ds,
+                                remove_borders=c["remove_borders"], min_length=c["min_length"],
+                                max_keylines=c["max_keylines"], token_distance=c["token_distance"], max_tokens=self.T,
+                                n_streams=self.n_streams, dense_layout=layout or self.layout)
+
+    def pack(self, tb, ld, out=None):
+        return parallel.pack_descriptors(ld, tb.cu_n, self.n_img_cap, self.rows_cap, out, cu_k=tb.cu_k,
+                                         sub2line=tb.sub2line, d_cu_n=tb.extra.get("d_cu_n"), d_cu_k=tb.extra.get("d_cu_k"))
 
     def step(self):
         tb, ld = self.describe()
@@ -97,7 +123,7 @@ class Pipeline:
             s = self.slot
             if self.pending[s] is not None:            # the buffer we are about to overwrite: its gather must be done
                 self.pending[s][0].wait()
-            self.packed[s] = parallel.pack_descriptors(ld, tb.cu_n, self.n_img_cap, self.rows_cap, self.packed[s])
+            self.packed[s] = self.pack(tb, ld, self.packed[s])
             work, gathered = parallel.allgather_descriptors(self.packed[s], async_op=True)
             self.pending[s] = (work, gathered)
             self.slot ^= 1
@@ -110,78 +136,54 @@ class Pipeline:
                 p[0].wait()
                 self.pending[i] = None
 
-    def match(self, tb, ld):
-        """image 2p vs image 2p+1 for every local pair."""
-        cu_n, cu_k = tb.cu_n, tb.cu_k
-        # de-interleave the two sides: side 0 = even images, side 1 = odd images (row ranges are contiguous per image)
-        ev, od = slice(0, None, 2), slice(1, None, 2)
-        n = np.diff(cu_n); k = np.diff(cu_k)
-        idx0 = torch.cat([torch.arange(cu_n[i], cu_n[i + 1]) for i in range(0, len(n), 2)]).to(ld.device)
-        idx1 = torch.cat([torch.arange(cu_n[i], cu_n[i + 1]) for i in range(1, len(n), 2)]).to(ld.device)
-        d0, d1 = ld[idx0], ld[idx1]
-        s0, s1 = tb.sub2line[idx0], tb.sub2line[idx1]
-        c = lambda v: np.concatenate([[0], np.cumsum(v)]).astype(np.int32)
-        args = (d0, c(n[ev]), s0, c(k[ev]), d1, c(n[od]), s1, c(k[od]))
-        return args
+    def match_args(self, tb, ld):
+        """image 2p vs image 2p+1 for every local pair, addressed in place (no gather of rows)."""
+        cu_n, cu_k = tb.cu_n.astype(np.int64), tb.cu_k.astype(np.int64)
+        n, k = np.diff(cu_n), np.diff(cu_k)
+        dims = np.stack([n[0::2], k[0::2], n[1::2], k[1::2]], axis=1).astype(np.int32)
+        return (ld, tb.sub2line, dims, cu_n[0:-1:2], cu_n[0:-1:2], cu_n[1::2], cu_n[1::2])
 
 
-def cpu_baseline(workload, budget_s=12.0, max_pairs=16):
-    """The CPU oracle (a faithful port of the reference's as-executed PyTorch-CPU/NumPy path, incl. the
-    per-line Python tokeniser loop and the full 22-token descriptive layer) timed on this box."""
-    from oracle import linetr_oracle as O
-    H, W, n_lines, lo, hi, T, _ = WORKLOADS[workload]
-    sd = synth.to_torch_state_dict(synth.calibrated_state_dict())
-    cfg = dict(LINE_CFG, max_tokens=T)
-    n_desc, t_tok, t_fwd, t_match, pairs = 0, 0.0, 0.0, 0.0, 0
+def settle(step_fn, sync_fn, min_s, max_s=8.0, window=5, tol=0.03, agree=None):
+    """Steady state before anything is timed: at least `min_s` seconds of load AND the last three `window`-step
+    averages within `tol` of each other (a fresh lease ramps its clocks for more than a second; r01's 0.15 s of
+    warm-up left the driver's 0.11 s timed window inside that ramp).  With several ranks the steps contain
+    collectives, so the stop decision is taken together (`agree`: every rank must be done).
+    Returns the window history (ms per step)."""
+    hist = []
     t_start = time.perf_counter()
-    with torch.no_grad():
-        while pairs < max_pairs and (pairs < 2 or time.perf_counter() - t_start < budget_s):
-            outs = []
-            for side in (0, 1):
-                seed = 5000 + 2 * pairs + side
-                rows = synth.synth_lines(seed, n_lines, H, W, lo, hi)
-                dd, ds = synth.synth_dense_maps(seed, H, W)
-                kl = synth.array_to_keylines(rows)
-                t0 = time.perf_counter()
-                out = O.preprocess(kl, (1, 1, H, W), dd, ds, cfg)
-                t1 = time.perf_counter()
-                out = O.forward(sd, out, (H, W))
-                t2 = time.perf_counter()
-                t_tok += t1 - t0
-                t_fwd += t2 - t1
-                n_desc += out["line_desc"].shape[2]
-                outs.append(out)
-            t0 = time.perf_counter()
-            O.match_lines(outs[0]["line_desc"], outs[1]["line_desc"], outs[0]["mat_klines2sublines"][0],
-                          outs[1]["mat_klines2sublines"][0], 0.8)
-            t_match += time.perf_counter() - t0
-            pairs += 1
-    return {
-        "value": n_desc / (t_tok + t_fwd), "unit": "line-descriptors/s", "cores": torch.get_num_threads(),
-        "kind": "port",
-        "sample": f"{pairs} {workload}-shaped pairs ({n_desc} descriptors), oracle tokenise {t_tok / pairs * 1e3:.1f} ms + "
-                  f"forward {t_fwd / pairs * 1e3:.1f} ms + match {t_match / pairs * 1e3:.2f} ms per pair, "
-                  f"torch {torch.__version__} CPU, {os.cpu_count()} logical cpus",
-        "pair_match_ms": t_match / pairs * 1e3,
-    }
+    while True:
+        sync_fn()
+        t0 = time.perf_counter()
+        for _ in range(window):
+            step_fn()
+        sync_fn()
+        hist.append((time.perf_counter() - t0) / window * 1e3)
+        el = time.perf_counter() - t_start
+        done = el >= max_s or (el >= min_s and len(hist) >= 3 and
+                               (max(hist[-3:]) - min(hist[-3:])) <= tol * min(hist[-3:]))
+        if agree is not None:
+            done = agree(done)
+        if done:
+            break
+    return hist
 
 
-PMC_KERNEL_NAMES = {   # profile class -> kernel symbol in profiles/r01_pmc_traffic.json (rocprofv3 --pmc run)
-    # matched as a prefix of the demangled name (trailing template arguments may grow)
-    "gemm_bf16x6_128x256": "void lt::gemm_split_kernel<128, 256, 2, 4, 3, true, 0",
-    "gemm_bf16x3_128x256": "void lt::gemm_split_kernel<128, 256, 2, 4, 2, true, 0",
-    "gemm_f16x3_128x256": "void lt::gemm_split_kernel<128, 256, 2, 4, 2, true, 1",
-    "gemm_bf16x6_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 3, true, 0",
-    "gemm_bf16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 0",
-    "gemm_f16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 1",
-    "gemm_f32_128x128": "void lt::gemm_kernel<128, 128, 2, 2>",
-}
+def make_agree(dist, world, device):
+    """all ranks stop settling in the same iteration: done only if every rank says so (one tiny all-reduce per window)."""
+    if world <= 1:
+        return None
+
+    def agree(done):
+        t = torch.tensor([1.0 if done else 0.0], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+    return agree
 
 
-def producer_section(eng, pipe, H, W, n_img, ms_per_step):
-    """linetr_superpoint_heads on raw head outputs of this batch's shape (synthetic logits / descriptors), HIP-event
-    timed; the same maths in stock PyTorch on the GPU for scale; and the descriptor step fed with the producer's
-    NHWC map (no transposition pass inside linetr_describe)."""
+def producer_section(eng, H, W, n_img):
+    """linetr_superpoint_heads (the dense-map producer) on raw head outputs of this batch's shape,
+    HIP-event timed, beside the same maths in stock PyTorch on the GPU."""
     Hc, Wc = H // 8, W // 8
     g = torch.Generator(device=eng.device).manual_seed(3)
     sl = torch.randn(n_img, 65, Hc, Wc, device=eng.device, generator=g) * 2
@@ -189,58 +191,160 @@ def producer_section(eng, pipe, H, W, n_img, ms_per_step):
 
     def timed(fn, reps=10):
         for _ in range(3):
-            r = fn()
+            fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            r = fn()
+            fn()
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps, r
+        return e0.elapsed_time(e1) / reps
 
-    ms, (score, nhwc, _) = timed(lambda: eng.superpoint_heads(sl, dr, nhwc=True, nchw=False))
+    ms = timed(lambda: eng.superpoint_heads(sl, dr, nhwc=True, nchw=False))
 
     def torch_heads():
         p = torch.softmax(sl, 1)[:, :-1]
         p = p.permute(0, 2, 3, 1).reshape(n_img, Hc, Wc, 8, 8).permute(0, 1, 3, 2, 4).reshape(n_img, Hc * 8, Wc * 8)
         return p, torch.nn.functional.normalize(dr, p=2, dim=1)
-    ms_torch, _ = timed(torch_heads)
+    ms_torch = timed(torch_heads)
     nbytes = n_img * Hc * Wc * (256 * 2 + 65 + 64) * 4
-    c = LINE_CFG
-
-    def step_nhwc():
-        return eng.describe_lines(pipe.cat, pipe.offsets, nhwc, score, remove_borders=c["remove_borders"],
-                                  min_length=c["min_length"], max_keylines=c["max_keylines"],
-                                  token_distance=c["token_distance"], max_tokens=pipe.T, dense_layout="nhwc")
-    for _ in range(5):
-        step_nhwc()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(10):
-        step_nhwc()
-    torch.cuda.synchronize()
-    ms_nhwc = (time.perf_counter() - t0) / 10 * 1e3
     return {"kernel": "sp_desc_head + sp_score_head (linetr_superpoint_heads)", "images": n_img, "ms": round(ms, 4),
             "algorithmic_bytes": nbytes, "achieved_GBps": round(nbytes / ms / 1e6, 1), "hbm_peak_GBps": HBM_PEAK_GBS,
-            "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "torch_same_ops_ms": round(ms_torch, 4),
-            "ms_per_step_fed_nhwc": round(ms_nhwc, 4), "ms_per_step_fed_nchw": round(ms_per_step, 4)}
+            "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "torch_same_ops_ms": round(ms_torch, 4)}
+
+
+def timed_steps(step_fn, barrier_fn, steps, device):
+    """EXACTLY `steps` steps between two barriers (+ device synchronisation) -- the contract's timed region -- with a
+    HIP event behind every step (per-step device times without any host synchronisation inside the region) and the
+    host time spent inside each step call."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    host = np.zeros(steps)
+    barrier_fn()
+    evs[0].record()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(steps):
+        h0 = time.perf_counter()
+        last = step_fn()
+        host[i] = time.perf_counter() - h0
+        evs[i + 1].record()
+    barrier_fn()
+    elapsed = time.perf_counter() - t0
+    per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
+    return elapsed, per_step, host * 1e3, last
+
+
+def cpu_baseline(workload, budget_s=14.0):
+    """The CPU oracle (a faithful port of the reference's as-executed PyTorch-CPU/NumPy path, incl. the per-line Python
+    tokeniser loop and the full 22-token descriptive layer) timed on this box over a sweep of torch thread counts
+    (1 thread and the physical cores; default-128-thread runs oversubscribe and were 3-4x slower).
+    `value` is the best setting's descriptors / (tokenise + forward) seconds."""
+    from oracle import linetr_oracle as O
+    H, W, n_lines, lo, hi, T, _ = WORKLOADS[workload]
+    sd = synth.to_torch_state_dict(synth.calibrated_state_dict())
+    cfg = dict(LINE_CFG, max_tokens=T)
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        phys = max(1, (os.cpu_count() or 2) // 2)
+    default_threads = torch.get_num_threads()
+    sweep = sorted({t for t in (1, 8, 16, 32, phys) if t <= max(phys, 1)})
+    per_setting_budget = budget_s / len(sweep)
+    rows, inputs = [], []
+    for side in (0, 1):
+        seed = 5000 + side
+        rows_ = synth.synth_lines(seed, n_lines, H, W, lo, hi)
+        dd, ds = synth.synth_dense_maps(seed, H, W)
+        inputs.append((synth.array_to_keylines(rows_), dd, ds))
+    with torch.no_grad():
+        for nt in sweep:
+            torch.set_num_threads(nt)
+            n_desc, t_tok, t_fwd, t_match, pairs = 0, 0.0, 0.0, 0.0, 0
+            t_start = time.perf_counter()
+            while pairs < 1 or (time.perf_counter() - t_start < per_setting_budget and pairs < 6):
+                outs = []
+                for kl, dd, ds in inputs:
+                    t0 = time.perf_counter()
+                    out = O.preprocess(kl, (1, 1, H, W), dd, ds, cfg)
+                    t1 = time.perf_counter()
+                    out = O.forward(sd, out, (H, W))
+                    t2 = time.perf_counter()
+                    t_tok += t1 - t0
+                    t_fwd += t2 - t1
+                    n_desc += out["line_desc"].shape[2]
+                    outs.append(out)
+                t0 = time.perf_counter()
+                O.match_lines(outs[0]["line_desc"], outs[1]["line_desc"], outs[0]["mat_klines2sublines"][0],
+                              outs[1]["mat_klines2sublines"][0], 0.8)
+                t_match += time.perf_counter() - t0
+                pairs += 1
+            rows.append({"threads": nt, "pairs": pairs, "desc_per_s": round(n_desc / (t_tok + t_fwd), 1),
+                         "forward_only_desc_per_s": round(n_desc / t_fwd, 1),
+                         "tokenise_ms_per_pair": round(t_tok / pairs * 1e3, 1), "forward_ms_per_pair": round(t_fwd / pairs * 1e3, 1),
+                         "match_ms_per_pair": round(t_match / pairs * 1e3, 2)})
+    torch.set_num_threads(default_threads)
+    best = max(rows, key=lambda r: r["desc_per_s"])
+    one = next(r for r in rows if r["threads"] == 1)
+    return {
+        "value": best["desc_per_s"], "unit": "line-descriptors/s", "cores": best["threads"], "kind": "port",
+        "sample": f"thread sweep {sweep} x >=1 {workload}-shaped pair each (2 x {n_lines} lines), oracle tokenise (Python loop, "
+                  f"1 thread) + forward; best = {best['threads']} threads; torch {torch.__version__} CPU, "
+                  f"{phys} physical / {os.cpu_count()} logical cpus",
+        "one_thread_value": one["desc_per_s"], "physical_cores": phys, "sweep": rows,
+        "pair_match_ms": best["match_ms_per_pair"],
+    }
+
+
+PMC_KERNEL_NAMES = {   # profile class -> kernel symbol prefix in profiles/<tag>_pmc_traffic.json (rocprofv3 --pmc run)
+    "gemm_bf16x6_128x256": "void lt::gemm_split_kernel<128, 256, 2, 4, 3, true, 0",
+    "gemm_bf16x3_128x256": "void lt::gemm_split_kernel<128, 256, 2, 4, 2, true, 0",
+    "gemm_f16x3_128x256": "void lt::gemm_split_kernel<128, 256, 2, 4, 2, true, 1",
+    "gemm_bf16x6_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 3, true, 0",
+    "gemm_bf16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 0",
+    "gemm_f16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 1",
+    "gemm_bf16x6_32x32k4": "void lt::gemm_split_small_kernel<3, 0>",
+    "gemm_f32_128x128": "void lt::gemm_kernel<128, 128, 2, 2>",
+    "sig_attn_bf16x6": "void lt::sig_attn_split_kernel<8>",
+}
+
+
+def _profile_json(name):
+    for tag in (PROFILE_TAG, "r01"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_{name}.json")
+        if os.path.exists(path):
+            return json.load(open(path)), tag
+    return None, None
 
 
 def pmc_traffic(kernel_class):
     """HBM-side bytes per launch of `kernel_class` from the committed rocprofv3 PMC pass (FETCH_SIZE/WRITE_SIZE in
     KiB, separate --pmc runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads
     on gfx950).  None if no PMC data is committed for this kernel."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    data, _ = _profile_json("pmc_traffic")
     name = PMC_KERNEL_NAMES.get(kernel_class)
-    if not name or not os.path.exists(path):
+    if not name or not data:
         return None
-    rec = next((v for k, v in json.load(open(path)).items() if k.startswith(name)), None)
+    rec = next((v for k, v in data.items() if k.startswith(name)), None)
     if not rec or "FETCH_SIZE_KiB_avg" not in rec or "WRITE_SIZE_KiB_avg" not in rec:
         return None
     return (2.0 * rec["FETCH_SIZE_KiB_avg"] + rec["WRITE_SIZE_KiB_avg"]) * 1024.0
 
 
-def roofline_of(dom, prof_steps, tot_ms, precision):
+def pmc_mfma_busy(kernel_class):
+    """SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE) of the dominant kernel from the committed PMC
+    pass (profiles/<tag>_gemm_pmc.json, written by tools/pmc_kernels.sh), or None."""
+    data, tag = _profile_json("gemm_pmc")
+    name = PMC_KERNEL_NAMES.get(kernel_class)
+    if not name or not data:
+        return None
+    rec = next((v for k, v in data.get("kernels", {}).items() if k.startswith(name)), None)
+    if not rec or "mfma_busy" not in rec:
+        return None
+    return {"mfma_busy": rec["mfma_busy"], "source": f"profiles/{tag}_gemm_pmc.json"}
+
+
+def roofline_of(dom, prof_steps, tot_ms):
     """roofline object of the dominant kernel (largest summed HIP-event time over the profiled steps)."""
     common = {"kernel": dom["name"], "avg_launch_us": round(dom["ms"] / dom["calls"] * 1e3, 2),
               "launches_per_step": dom["calls"] // prof_steps, "share_of_gpu_time": round(dom["ms"] / tot_ms, 3)}
@@ -254,14 +358,242 @@ def roofline_of(dom, prof_steps, tot_ms, precision):
         if "bf16x" in dom["name"] or "f16x3" in dom["name"]:
             terms = 6 if "bf16x6" in dom["name"] else 3
             r.update({"mfma_flops_per_algorithmic_flop": terms,
-                      "bf16_pipe_frac": round(ach * terms / 2500.0, 4),
+                      "bf16_pipe_frac": round(ach * terms / BF16_MFMA_PEAK_TFLOPS, 4),
                       "pipe_note": f"each fp32 product = {terms} bf16 MFMA products; {terms}*achieved / 2.5 PF dense bf16 peak"})
+        busy = pmc_mfma_busy(dom["name"])
+        if busy:
+            r.update(busy)
     else:
         ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
         r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic}
     return {**common, **r}
 
+
+def profile_steps(eng, fn, prof_steps=3):
+    """per-kernel-class HIP-event profile of `prof_steps` calls of fn; returns (entries sorted by time, total ms)."""
+    eng.set_profiling(True)
+    for _ in range(prof_steps):
+        fn()
+    torch.cuda.synchronize()
+    prof = eng.get_profile()
+    eng.set_profiling(False)
+    prof.sort(key=lambda e: -e["ms"])
+    return prof, sum(e["ms"] for e in prof)
+
+
+def breakdown_of(prof, prof_steps):
+    return {e["name"]: {"calls": e["calls"] // prof_steps, "ms": round(e["ms"] / prof_steps, 4),
+                        "tflops": round(e["flops"] / max(e["ms"], 1e-9) / 1e9, 1) if e["flops"] else None} for e in prof}
+
+
+def sub_workload(eng, name, device, settle_s):
+    """cfg2 / cfg5 sub-object of the N = 1 line: the same step on another BASELINE.json configuration (own inputs,
+    own short settle), with its dominant kernel."""
+    H, W, n_lines, lo, hi, T, pairs = WORKLOADS[name]
+    lines, _dd, nhwc, ds, hw, T = make_inputs(name, pairs, 0, device, eng)
+    pipe = Pipeline(eng, lines, nhwc, ds, hw, T, 1, pairs)
+    sync = torch.cuda.synchronize
+    settle(pipe.step, sync, min_s=settle_s, max_s=max(settle_s * 3, 1.0))
+    steps = 20
+    elapsed, per_step, host_ms, (tb, ld, _g) = timed_steps(pipe.step, sync, steps, device)
+    prof, tot = profile_steps(eng, pipe.describe)
+    out = {"workload": f"{name}: {pairs} pair(s) of {W}x{H}, {n_lines} lines/image -> {int(tb.N / (2 * pairs))} sub-lines x {T} tokens",
+           "descriptors_per_step": int(tb.N), "value": round(tb.N * steps / elapsed, 1), "unit": "line-descriptors/s",
+           "ms_per_step": round(elapsed / steps * 1e3, 4), "ms_per_step_median": round(float(np.median(per_step)), 4),
+           "host_ms_per_step": round(float(np.mean(host_ms)), 4), "gpu_ms_per_step_profiled": round(tot / 3, 4),
+           "launches_per_step": int(sum(e["calls"] for e in prof) // 3),
+           "roofline": roofline_of(prof[0], 3, tot), "kernels": breakdown_of(prof, 3)}
+    if pairs == 1:      # single pair: strict latency (submit, wait, repeat) of describe and of describe + match
+        margs = pipe.match_args(tb, ld)
+        lat, lat_m = [], []
+        for _ in range(5):
+            pipe.describe(); eng.match_offsets(*margs, LINE_CFG["nn_threshold"], True)
+        sync()
+        for _ in range(20):
+            t1 = time.perf_counter()
+            tb1, ld1 = pipe.describe()
+            sync()
+            t2 = time.perf_counter()
+            eng.match_offsets(*pipe.match_args(tb1, ld1), LINE_CFG["nn_threshold"], True)
+            sync()
+            t3 = time.perf_counter()
+            lat.append(t2 - t1)
+            lat_m.append(t3 - t2)
+        out["pair_latency_sync_ms"] = round(float(np.median(lat)) * 1e3, 4)
+        out["pair_match_latency_ms"] = round(float(np.median(lat_m)) * 1e3, 4)
+    del pipe, lines, nhwc, ds
+    return out
+
+
+# =====================================================================================================================
+# cfg4: 1024 homography-augmented pairs, strong-sharded, one all-gather, global matching
+# =====================================================================================================================
+
+class Cfg4Job:
+    """BASELINE.json cfg4 on this rank: the pairs p = rank (mod world) of a P-pair job.
+
+    step() = describe all local pairs in batches -> one slab (descriptors + counts + key-line maps) -> ONE all-gather
+    -> every local query image (side 0 of a local pair p) is matched against the side-1 images of pairs
+    p, p+1, .. p+S-1 (mod P) taken from the GATHERED set (for world > 1 all but one in world of them live on other
+    ranks; s = 0 is the query's own partner, whose matches can be checked against the known homography)."""
+
+    def __init__(self, eng, device, rank, world, pairs_total, batch_pairs, candidates, strength, dist=None):
+        self.eng, self.device, self.rank, self.world, self.dist = eng, device, rank, world, dist
+        self.P, self.S = pairs_total, candidates
+        H, W, n_lines, lo, hi, T, _ = WORKLOADS["cfg4"]
+        self.hw, self.T = (H, W), T
+        self.mine = parallel.shard_pairs(pairs_total, rank, world)
+        self.batch_pairs = batch_pairs
+        lines, nhwc, ds, self.gt = [], [], [], {}
+        g = torch.Generator(device=device)
+        for p in self.mine:
+            l0, l1, m, gt = synth.homography_pair(40000 + p, n_lines, H, W, lo, hi, strength=strength)
+            g.manual_seed(40000 + p)
+            dd0 = torch.nn.functional.normalize(torch.randn(1, 256, H // 8, W // 8, device=device, generator=g), p=2, dim=1)
+            ds0 = torch.rand(1, H, W, device=device, generator=g)
+            dd1, ds1 = synth.warp_dense_maps(dd0, ds0, m, seed=p)
+            lines += [l0, l1]
+            nhwc += [dd0.permute(0, 2, 3, 1).contiguous(), dd1.permute(0, 2, 3, 1).contiguous()]
+            ds += [ds0, ds1]
+            self.gt[p] = (l0, l1, m, gt)
+        self.batches = []
+        for b0 in range(0, len(self.mine), batch_pairs):
+            i0, i1 = 2 * b0, 2 * min(b0 + batch_pairs, len(self.mine))
+            pipe = Pipeline(eng, lines[i0:i1], torch.cat(nhwc[i0:i1]), torch.cat(ds[i0:i1]), self.hw, T, 1, (i1 - i0) // 2)
+            self.batches.append(pipe)
+        per_rank = (pairs_total + world - 1) // world
+        self.n_img_cap = 2 * per_rank
+        self.rows_cap = max(sum(p.rows_cap for p in self.batches), 1)
+        if world > 1:     # every rank's slab must have the same height
+            t = torch.tensor([self.rows_cap], dtype=torch.int64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            self.rows_cap = int(t.item())
+        self.slab = torch.zeros((parallel.slab_rows(self.n_img_cap, self.rows_cap), 256), dtype=torch.float32, device=device)
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        self.last = None
+
+    def step(self):
+        e0, e1, e2, e3 = self.ev
+        e0.record()
+        # ---- compute: describe every local batch, results appended into the slab's regions -----------------------------------
+        lds, cu_n, cu_k, s2l = [], [0], [0], []
+        for pipe in self.batches:
+            tb, ld = pipe.describe()
+            lds.append(ld); s2l.append(tb.sub2line)
+            cu_n += list(np.asarray(tb.cu_n[1:], dtype=np.int64) + cu_n[-1])
+            cu_k += list(np.asarray(tb.cu_k[1:], dtype=np.int64) + cu_k[-1])
+        cu_n, cu_k = np.asarray(cu_n, dtype=np.int32), np.asarray(cu_k, dtype=np.int32)
+        ld = torch.cat(lds) if len(lds) > 1 else lds[0]
+        s2l = torch.cat(s2l) if len(s2l) > 1 else s2l[0]
+        parallel.pack_descriptors(ld, cu_n, self.n_img_cap, self.rows_cap, self.slab, cu_k=cu_k, sub2line=s2l)
+        e1.record()
+        # ---- the single collective ---------------------------------------------------------------------------------------------
+        if self.world > 1:
+            gathered = parallel.allgather_descriptors(self.slab)
+        else:
+            gathered = self.slab[None]
+        e2.record()
+        # ---- global matching on the gathered set --------------------------------------------------------------------------------
+        gs = parallel.GatheredSet(gathered, self.n_img_cap, self.rows_cap)
+        queries, cands = [], []
+        for p in self.mine:
+            for s in range(self.S):
+                c = (p + s) % self.P
+                queries.append((self.rank, 2 * (p // self.world)))
+                rc, lc = parallel.owner_of(c, self.world)
+                cands.append((rc, 2 * lc + 1))
+        res = []
+        CH = 2048          # pair-matches per linetr_match call (bounds the distance-matrix workspace)
+        for i in range(0, len(queries), CH):
+            res.append(parallel.global_match(self.eng, gs, queries[i:i + CH], cands[i:i + CH], LINE_CFG["nn_threshold"], True))
+        e3.record()
+        self.last = (gs, ld, cu_n, cu_k, res, queries, cands)
+        return int(cu_n[-1])
+
+    def phase_ms(self):
+        torch.cuda.synchronize()
+        e0, e1, e2, e3 = self.ev
+        return e0.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e3)
+
+    def recall(self, max_pairs=16):
+        """matches of (query p, candidate p) -- a pair's own two views -- against the known homography: a key-line of view
+        0 whose warped end points coincide with a key-line of view 1 (0.5 px) is a ground-truth match."""
+        gs, ld, cu_n, cu_k, res, queries, cands = self.last
+        dk, off_dk, m01, off_k0 = res[0]
+        m01 = m01.cpu().numpy()
+        hit = tot = matched = 0
+        for qi in range(0, min(len(queries), 2048), self.S):
+            p = self.mine[qi // self.S]
+            if qi // self.S >= max_pairs:
+                break
+            loc = p // self.world
+            pipe = self.batches[loc // self.batch_pairs]
+            j = 2 * (loc % self.batch_pairs)
+            tb, _ = pipe.describe()
+            k0 = tb.klines[tb.cu_k[j]:tb.cu_k[j + 1]].cpu().numpy().astype(np.float64)
+            k1 = tb.klines[tb.cu_k[j + 1]:tb.cu_k[j + 2]].cpu().numpy().astype(np.float64)
+            m = self.gt[p][2]
+            w = synth.warp_points(m, k0.reshape(-1, 2)).reshape(-1, 2, 2)
+            mm = m01[off_k0[qi]:off_k0[qi + 1]]
+            for i in range(len(k0)):
+                d = np.minimum(np.abs(k1 - w[i][None]).reshape(len(k1), -1).max(1),
+                               np.abs(k1 - w[i][::-1][None]).reshape(len(k1), -1).max(1))
+                jj = int(d.argmin()) if len(d) else -1
+                if jj >= 0 and d[jj] < 0.5:
+                    tot += 1
+                    hit += int(mm[i] == jj)
+            matched += int((mm >= 0).sum())
+        return {"gt_pairs": tot, "recovered": hit, "recall": round(hit / max(tot, 1), 4), "matches": matched}
+
+
+def run_cfg4(args, eng, device, rank, world, dist):
+    job = Cfg4Job(eng, device, rank, world, args.pairs_total, args.pairs or WORKLOADS["cfg4"][6], args.candidates,
+                  args.homography_strength, dist)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    settle(job.step, torch.cuda.synchronize, min_s=args.settle_s, max_s=max(3 * args.settle_s, 1.0), window=2,
+           agree=make_agree(dist, world, device))
+    for _ in range(args.warmup):
+        job.step()
+    elapsed, per_step, host_ms, n_local = timed_steps(job.step, barrier, args.steps, device)
+    phases = np.array(job.phase_ms())
+    if world > 1:
+        t = torch.tensor([elapsed, float(n_local), *phases], dtype=torch.float64, device=device)
+        mx = t.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = t.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, n_total, phases = float(mx[0]), float(sm[1]), mx[2:].cpu().numpy()
+    else:
+        n_total = float(n_local)
+    rec = job.recall()
+    H, W, n_lines, _, _, T, _ = WORKLOADS["cfg4"]
+    out = {
+        "metric": "line_descriptors_per_sec", "value": round(n_total * args.steps / elapsed, 1), "unit": "line-descriptors/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32 in/out; GEMMs as 6 bf16-split MFMA products, fp32 accumulate (fp32-faithful)", "data": "synthetic",
+        "config": {"workload": f"cfg4: {args.pairs_total} homography-augmented pairs of {W}x{H} ({n_lines} lines/image, recipe "
+                               f"dataloaders/confs/homography.yaml, strength {args.homography_strength}), pair p -> rank p mod {world}, "
+                               f"one all-gather, {args.candidates} gathered candidates per query",
+                   "pairs_total": args.pairs_total, "pairs_per_describe_call": job.batch_pairs,
+                   "descriptors_per_step": int(n_total), "collective": "all_gather(slab)" if world > 1 else "none (one rank)",
+                   "pair_matches_per_step": args.pairs_total * args.candidates},
+        "compute_ms": round(float(phases[0]), 3), "gather_ms": round(float(phases[1]), 3),
+        "global_match_ms": round(float(phases[2]), 3),
+        "ms_per_step_median": round(float(np.median(per_step)), 3), "host_ms_per_step": round(float(np.mean(host_ms)), 3),
+        "recall_vs_homography_rank0": rec,
+        "recall_note": "seeded, untrained weights are not viewpoint-invariant: recall is only meaningful for mild views "
+                       "(--homography-strength 0.05 gives > 0.8; tests/test_gpu_cfg4.py)",
+    }
+    return out
+
+
+# =====================================================================================================================
 
 def main():
     ap = argparse.ArgumentParser()
@@ -273,9 +605,16 @@ def main():
     ap.add_argument("--precision", default="bf16x6", choices=["f32", "bf16x6", "bf16x3", "f16x3"],
                     help="MFMA path of the dense contractions (bf16x6 = fp32-faithful split, the default)")
     ap.add_argument("--streams", type=int, default=1, help="independent sub-batches run on this many HIP streams")
+    ap.add_argument("--dense-layout", default="nhwc", choices=["nhwc", "nchw"],
+                    help="layout of the resident dense descriptor map (nhwc = what the repo's producer emits)")
+    ap.add_argument("--settle-s", type=float, default=2.0, help="minimum seconds of load before anything is timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-precisions", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--no-sub-workloads", action="store_true", help="skip the cfg2 / cfg5 sub-objects")
+    ap.add_argument("--cpu-budget", type=float, default=14.0)
+    ap.add_argument("--pairs-total", type=int, default=1024, help="cfg4: pairs of the whole job")
+    ap.add_argument("--candidates", type=int, default=4, help="cfg4: gathered candidate images matched per query image")
+    ap.add_argument("--homography-strength", type=float, default=1.0, help="cfg4: 1 = the yaml's recipe, <1 milder views")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -305,8 +644,19 @@ def main():
     pairs = args.pairs or def_pairs
     eng = Engine(synth.calibrated_state_dict(), device, image_shape=[H, W])
     eng.set_precision(args.precision)
-    lines, dd, ds, hw, T = make_inputs(args.workload, pairs, rank, device)
-    pipe = Pipeline(eng, lines, dd, ds, hw, T, world, pairs, args.streams)
+
+    if args.workload == "cfg4":
+        out = run_cfg4(args, eng, device, rank, world, dist)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    lines, dd_nchw, dd_nhwc, ds, hw, T = make_inputs(args.workload, pairs, rank, device, eng)
+    feed = dd_nhwc if args.dense_layout == "nhwc" else dd_nchw
+    pipe = Pipeline(eng, lines, feed, ds, hw, T, world, pairs, args.streams, args.dense_layout)
 
     def barrier():
         pipe.drain()
@@ -315,19 +665,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # one-time settling before the contract's W warm-up steps: first-touch of workspaces / pinned staging, and ~0.1 s of
-    # load so that the power manager has left its idle state (a cold start was measured up to 15 % slower per step)
-    for _ in range(SETTLE_STEPS):
-        pipe.step()
-    barrier()
+    # ---- steady state, then the contract: W untimed warm-up steps, EXACTLY K timed steps between barriers ----------
+    settle_hist = settle(pipe.step, barrier, min_s=args.settle_s, agree=make_agree(dist, world, device))
     for _ in range(args.warmup):
-        tb, ld, _g = pipe.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tb, ld, _g = pipe.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+        pipe.step()
+    elapsed, per_step, host_ms, (tb, ld, _g) = timed_steps(pipe.step, barrier, args.steps, device)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -339,122 +681,139 @@ def main():
         n_desc_step = float(tb.N)
     ms_per_step = elapsed / args.steps * 1e3
     value = n_desc_step * args.steps / elapsed
-    gathered_ok = None
-    if world > 1 and _g is not None:     # every rank's slab of the last all-gather carries that rank's descriptors
+    # host side of a step alone (C++ pre-filter on the worker pool; the rest of host_ms_per_step is Python + launches)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        pipe.prefilter_only()
+    host_prefilter_ms = (time.perf_counter() - t0) / 10 * 1e3
+
+    gathered_ok, global_match = None, None
+    if world > 1 and _g is not None:
+        # every rank's slab of the last all-gather carries that rank's descriptors; then GLOBAL matching on the gathered set:
+        # this rank's side-0 images against the side-1 images of the NEXT rank's pairs (descriptors this rank never computed)
+        gs = parallel.GatheredSet(_g, pipe.n_img_cap, pipe.rows_cap)
         gathered_ok = True
         for r in range(world):
-            d_r, cu_r = parallel.unpack_descriptors(_g[r], pipe.n_img_cap)
+            d_r, cu_r = parallel.unpack_descriptors(_g[r], pipe.n_img_cap, pipe.rows_cap)
             gathered_ok &= bool(len(cu_r) == 2 * pairs + 1 and d_r.shape[0] == cu_r[-1])
             if r == rank:
                 gathered_ok &= bool(torch.equal(d_r, ld))
             gathered_ok &= bool(((d_r.norm(dim=1) - 1).abs() < 1e-4).all().item())
+        nxt = (rank + 1) % world
+        q = [(rank, 2 * p) for p in range(pairs)]
+        c = [(nxt, 2 * p + 1) for p in range(pairs)]
+        for _ in range(2):
+            parallel.global_match(eng, gs, q, c, LINE_CFG["nn_threshold"], True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            _dk, _odk, m01g, _ok0 = parallel.global_match(eng, gs, q, c, LINE_CFG["nn_threshold"], True)
+        torch.cuda.synchronize()
+        global_match = {"ms_per_batch": round((time.perf_counter() - t0) / 5 * 1e3, 4), "pair_matches": pairs,
+                        "against": f"side-1 images of rank {nxt} (gathered)", "matches": int((m01g >= 0).sum().item())}
 
     # ---- pair-match ms (a19-a21) on the descriptors just produced --------------------------------------------
-    margs = pipe.match(tb, ld)
+    margs = pipe.match_args(tb, ld)
     for _ in range(2):
-        eng.match(*margs, LINE_CFG["nn_threshold"], True)
+        eng.match_offsets(*margs, LINE_CFG["nn_threshold"], True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     reps = 10
     for _ in range(reps):
-        dk, off_dk, m01 = eng.match(*margs, LINE_CFG["nn_threshold"], True)
+        dk, off_dk, m01, _ok0 = eng.match_offsets(*margs, LINE_CFG["nn_threshold"], True)
     torch.cuda.synchronize()
     pair_match_ms = (time.perf_counter() - t0) / reps / pairs * 1e3
     n_matches = int((m01 >= 0).sum().item())
     # ... and for ONE pair at a time (latency of get_dist_matrix + subline2keyline + nn_matcher_distmat)
-    n0, n1 = int(tb.cu_n[1]), int(tb.cu_n[2] - tb.cu_n[1])
-    k0, k1 = int(tb.cu_k[1]), int(tb.cu_k[2] - tb.cu_k[1])
-    one_args = (ld[:n0], np.array([0, n0]), tb.sub2line[:n0], np.array([0, k0]), ld[n0:n0 + n1], np.array([0, n1]),
-                tb.sub2line[n0:n0 + n1], np.array([0, k1]))
+    one_args = (margs[0], margs[1], margs[2][:1], margs[3][:1], margs[4][:1], margs[5][:1], margs[6][:1])
     for _ in range(3):
-        eng.match(*one_args, LINE_CFG["nn_threshold"], True)
+        eng.match_offsets(*one_args, LINE_CFG["nn_threshold"], True)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        eng.match(*one_args, LINE_CFG["nn_threshold"], True)
-    torch.cuda.synchronize()
-    pair_match_latency_ms = (time.perf_counter() - t0) / 20 * 1e3
-
-    # ---- single-pair latency (cfg2 shape, tokenise + forward + match) -----------------------------------------
-    one = Pipeline(eng, lines[:2], dd[:2], ds[:2], hw, T, 1, 1)
-    for _ in range(3):
-        pipe.step()                       # bring the clocks back up after the light matcher section
-    for _ in range(20):
-        tb1, ld1 = one.describe()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(30):
-        tb1, ld1 = one.describe()
-    torch.cuda.synchronize()
-    pair_latency_ms = (time.perf_counter() - t0) / 30 * 1e3   # back-to-back single pairs (throughput-latency)
     lat = []
-    for _ in range(10):                   # and strictly one at a time: submit, wait, repeat
+    for _ in range(20):
         t1 = time.perf_counter()
-        one.describe()
+        eng.match_offsets(*one_args, LINE_CFG["nn_threshold"], True)
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t1)
-    pair_latency_sync_ms = float(np.median(lat)) * 1e3
+    pair_match_latency_ms = float(np.median(lat)) * 1e3
 
     # ---- per-kernel HIP-event profile of the same step (roofline of the dominant kernel) ----------------------
+    for _ in range(3):
+        pipe.step()                       # bring the clocks back up after the light matcher section
     prof_steps = 3
-    eng.set_profiling(True)
-    for _ in range(prof_steps):
-        pipe.describe()
-    torch.cuda.synchronize()
-    prof = eng.get_profile()
-    eng.set_profiling(False)
-    prof.sort(key=lambda e: -e["ms"])
-    dom = prof[0]
-    tot_ms = sum(e["ms"] for e in prof)
-    roofline = roofline_of(dom, prof_steps, tot_ms, args.precision)
+    prof, tot_ms = profile_steps(eng, pipe.describe, prof_steps)
+    roofline = roofline_of(prof[0], prof_steps, tot_ms)
     n_img = 2 * pairs
     alg_flops_step = sum(algorithmic_flops_per_image(int(n), T) for n in np.diff(tb.cu_n))
-    breakdown = {e["name"]: {"calls": e["calls"] // prof_steps, "ms": round(e["ms"] / prof_steps, 4),
-                             "tflops": round(e["flops"] / max(e["ms"], 1e-9) / 1e9, 1) if e["flops"] else None}
-                 for e in prof}
 
     out = {
         "metric": "line_descriptors_per_sec", "value": round(value, 1), "unit": "line-descriptors/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": SETTLE_STEPS,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"f32": "f32 (v_mfma_f32_32x32x2_f32)", "bf16x6": "f32 in/out; GEMMs as 6 bf16-split MFMA products, fp32 accumulate (fp32-faithful)",
                   "bf16x3": "f32 in/out; GEMMs as 3 bf16-split MFMA products, fp32 accumulate (~1e-5)",
                   "f16x3": "f32 in/out; GEMMs as 3 fp16-split MFMA products, fp32 accumulate (~1e-6)"}[args.precision],
         "precision": args.precision, "data": "synthetic",
-        "gathered_rows_checked": gathered_ok,
         "config": {"workload": f"{args.workload}: {pairs} pairs/GPU of {W}x{H}, {n_lines} lines/image -> "
                                f"{int(tb.N / n_img)} sub-lines x {T} tokens, d_model=256, seeded weights",
                    "pairs_per_gpu": pairs, "descriptors_per_step": int(n_desc_step),
-                   "collective": "all_gather(line_desc)" if world > 1 else "none"},
+                   "dense_layout": args.dense_layout,
+                   "collective": "all_gather(line_desc + counts + key-line maps)" if world > 1 else "none"},
+        "ms_per_step_median": round(float(np.median(per_step)), 4), "ms_per_step_p10": round(float(np.percentile(per_step, 10)), 4),
+        "ms_per_step_p90": round(float(np.percentile(per_step, 90)), 4),
+        "host_ms_per_step": round(float(np.mean(host_ms)), 4), "host_prefilter_ms": round(host_prefilter_ms, 4),
+        "settle": {"seconds_min": args.settle_s, "windows": len(settle_hist), "first_ms": round(settle_hist[0], 4),
+                   "last3_ms": [round(v, 4) for v in settle_hist[-3:]]},
+        "gathered_rows_checked": gathered_ok, "global_match": global_match,
         "pair_match_ms": round(pair_match_ms, 4), "pair_match_latency_ms": round(pair_match_latency_ms, 4),
-        "pair_latency_ms": round(pair_latency_ms, 3), "pair_latency_sync_ms": round(pair_latency_sync_ms, 3),
         "matches_per_step": n_matches,
-        "whole_step_algorithmic_tflops": round(alg_flops_step / (ms_per_step * 1e-3) / 1e12 * (world if world > 1 else 1) / max(world, 1), 2),
+        "whole_step_algorithmic_tflops": round(alg_flops_step / (ms_per_step * 1e-3) / 1e12, 2),
         "gpu_ms_per_step_profiled": round(tot_ms / prof_steps, 3),
-        "roofline": roofline, "kernels": breakdown,
+        "roofline": roofline, "kernels": breakdown_of(prof, prof_steps),
     }
-    if world == 1:  # the dense-map producer feeding this batch (reported beside the metric, never in it)
-        out["producer"] = producer_section(eng, pipe, H, W, n_img, ms_per_step)
+    if world == 1:
+        # the same step fed with the reference's NCHW 'dense_descriptor' (one extra layout pass inside linetr_describe)
+        other = "nchw" if args.dense_layout == "nhwc" else "nhwc"
+        odd = dd_nchw if other == "nchw" else dd_nhwc
+        for _ in range(8):
+            pipe.describe(odd, other)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            pipe.describe(odd, other)
+        torch.cuda.synchronize()
+        out[f"ms_per_step_fed_{other}"] = round((time.perf_counter() - t0) / 10 * 1e3, 4)
+        out["producer"] = producer_section(eng, H, W, n_img)
     if world == 1 and not args.no_alt_precisions:   # the same step in the other MFMA modes (few steps each), for reference
         alt = {}
         for mode in ("bf16x3", "f16x3", "bf16x6", "f32"):
             if mode == args.precision:
                 continue
             eng.set_precision(mode)
-            for _ in range(8):     # re-warm: clocks drop during the light single-pair / profiling sections above
+            for _ in range(10):
                 pipe.step()
             barrier()
             t0 = time.perf_counter()
-            for _ in range(8):
-                tb_a, _ld, _g = pipe.step()
+            for _ in range(10):
+                tb_a, _ld, _gg = pipe.step()
             barrier()
-            alt[mode] = round(tb_a.N * 8 / (time.perf_counter() - t0) * world, 1)
+            alt[mode] = round(tb_a.N * 10 / (time.perf_counter() - t0), 1)
         eng.set_precision(args.precision)
         out["alt_precisions_desc_per_s"] = alt
+    if world == 1 and not args.no_sub_workloads:
+        del pipe, dd_nchw, dd_nhwc, ds, feed
+        torch.cuda.empty_cache()
+        for name in ("cfg2", "cfg5"):
+            if name != args.workload:
+                out[name] = sub_workload(eng, name, device, min(args.settle_s, 0.6))
+        if "cfg2" in out:      # the single-pair figures of the metric, also at top level
+            out["pair_latency_ms"] = out["cfg2"]["ms_per_step"]
+            out["pair_latency_sync_ms"] = out["cfg2"]["pair_latency_sync_ms"]
+            out["pair_match_latency_ms"] = out["cfg2"]["pair_match_latency_ms"]
     if world == 1 and not args.no_cpu_baseline:   # reported at N = 1 only (the contract), so scaling runs stay short
         cb = cpu_baseline(args.workload, args.cpu_budget)
-        out["cpu_baseline"] = {k: (round(v, 1) if isinstance(v, float) else v) for k, v in cb.items()}
+        out["cpu_baseline"] = cb
         out["speedup_vs_cpu"] = round(value / cb["value"], 1)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LINETR_ABI_VERSION 1
+#define LINETR_ABI_VERSION 2
 
 enum {
   LINETR_OK = 0,
@@ -137,16 +137,17 @@ int64_t linetr_tokenize_workspace_bytes(int32_t n_images, int32_t height, int32_
 
 /* line_tokenizer + sample_descriptors + score gather (models/line_process.py:100-196, :86-98).
  * d_recs: [K] records of all images (image-major, per-image order preserved); h_recs the same
- * array on the host (used only to size launches).  d_dense_desc [B,256,height/8,width/8] NCHW,
- * d_dense_score [B,height,width].  The end-point clip of line_process.py:114-116 is applied, and
+ * array on the host (used only to size launches).  d_dense_desc [B,256,height/8,width/8] NCHW
+ * (dense_is_nhwc = 0, the reference's 'dense_descriptor') or [B,height/8,width/8,256] (dense_is_nhwc != 0, what
+ * linetr_superpoint_heads emits: no layout pass), d_dense_score [B,height,width].  The end-point clip of line_process.py:114-116 is applied, and
  * the clipped end points are what `out.klines` holds (reference quirk: it mutates through a view).
  * d_sub2line [N] int32 (key-line index of every sub-line INSIDE ITS IMAGE, non-decreasing per image)
  * is written for linetr_match.  `out.desc` may be NULL to skip descriptor sampling. */
 int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N,
                     double token_distance, int32_t max_tokens, const float* d_dense_desc,
                     const float* d_dense_score, int32_t n_images, int32_t height, int32_t width,
-                    int32_t align_corners, LinetrTokens out, int32_t* d_sub2line, void* d_workspace,
-                    int64_t workspace_bytes, void* stream);
+                    int32_t align_corners, int32_t dense_is_nhwc, LinetrTokens out, int32_t* d_sub2line,
+                    void* d_workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- device: descriptor network ------------------------------------------------------------- */
 
@@ -201,6 +202,17 @@ int linetr_match(LinetrHandle* h, int32_t n_pairs, const int32_t* h_dims, const 
                  const int64_t* h_off_n1, const int32_t* d_sub2line1, float nn_thresh, int32_t mutual,
                  float* d_dk, const int64_t* h_off_dk, int32_t* d_match01, const int64_t* h_off_k0,
                  void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* linetr_match with separate offsets for the key-line maps: pair p reads its descriptors at row h_off_n0[p] of d_desc0
+ * and its sub-line -> key-line map at element h_off_s0[p] of d_sub2line0 (same for side 1; NULL offsets = h_off_n*).
+ * This is the form global matching uses after the multi-GPU all-gather, where descriptors and maps of all ranks sit
+ * at different places of ONE gathered buffer (linetr_amd/parallel.py; no reference counterpart, BASELINE.json cfg4). */
+int linetr_match_gathered(LinetrHandle* h, int32_t n_pairs, const int32_t* h_dims, const float* d_desc0,
+                          const int64_t* h_off_n0, const int32_t* d_sub2line0, const int64_t* h_off_s0,
+                          const float* d_desc1, const int64_t* h_off_n1, const int32_t* d_sub2line1,
+                          const int64_t* h_off_s1, float nn_thresh, int32_t mutual, float* d_dk,
+                          const int64_t* h_off_dk, int32_t* d_match01, const int64_t* h_off_k0, void* d_workspace,
+                          int64_t workspace_bytes, void* stream);
 
 /* nn_matcher_distmat (models/nn_matcher.py:3-31) on a distance matrix that already lives on the device:
  * d_dist [n0,n1] float32 -> d_match01 [n0] (index into side 1 or -1).  `h` may be NULL for the three

@@ -77,13 +77,14 @@ def lib():
                                   vp, i64, vp]
     L.linetr_tokenize_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.linetr_tokenize_workspace_bytes.restype = i64
-    L.linetr_tokenize.argtypes = [vp, vp, i32, i32, f64, i32, vp, vp, i32, i32, i32, i32, Tokens, vp, vp, i64, vp]
+    L.linetr_tokenize.argtypes = [vp, vp, i32, i32, f64, i32, vp, vp, i32, i32, i32, i32, i32, Tokens, vp, vp, i64, vp]
     L.linetr_forward_workspace_bytes.argtypes = [vp, i32, i32]
     L.linetr_forward_workspace_bytes.restype = i64
     L.linetr_forward.argtypes = [vp, C.POINTER(Tokens), vp, vp, i32, i32, vp, vp, i64, vp]
     L.linetr_match_workspace_bytes.argtypes = [i32, i64, i64, i64]
     L.linetr_match_workspace_bytes.restype = i64
     L.linetr_match.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, i64, vp]
+    L.linetr_match_gathered.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, i64, vp]
     L.linetr_match_points.argtypes = [vp, vp, i32, vp, i32, f32, i32, vp, vp, vp, i64, vp]
     L.linetr_match_distmat.argtypes = [vp, vp, i32, i32, f32, i32, vp, vp, i64, vp]
     L.linetr_match_distmat_workspace_bytes.argtypes = [i32, i32]
@@ -95,7 +96,7 @@ def lib():
     L.linetr_debug_gemm.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.linetr_set_profiling.argtypes = [vp, i32]
     L.linetr_get_profile.argtypes = [vp, C.POINTER(ProfileEntry), i32, C.POINTER(i32)]
-    if L.linetr_abi_version() != 1:
+    if L.linetr_abi_version() != 2:
         raise RuntimeError("liblinetr_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -103,7 +104,7 @@ def lib():
 
 EXPORTS = ["linetr_abi_version", "linetr_last_error", "linetr_create", "linetr_destroy", "linetr_prefilter",
            "linetr_prefilter_batch", "linetr_pack_lines", "linetr_tokenize_workspace_bytes", "linetr_tokenize", "linetr_forward_workspace_bytes",
-           "linetr_forward", "linetr_describe_workspace_bytes", "linetr_describe", "linetr_match_workspace_bytes", "linetr_match", "linetr_match_points",
+           "linetr_forward", "linetr_describe_workspace_bytes", "linetr_describe", "linetr_match_workspace_bytes", "linetr_match", "linetr_match_gathered", "linetr_match_points",
            "linetr_match_distmat", "linetr_match_distmat_workspace_bytes", "linetr_superpoint_heads", "linetr_set_precision", "linetr_get_precision", "linetr_debug_posenc", "linetr_debug_gemm", "linetr_set_profiling", "linetr_get_profile"]
 
 

@@ -740,8 +740,8 @@ extern "C" int64_t linetr_tokenize_workspace_bytes(int32_t n_images, int32_t hei
 
 extern "C" int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N, double td,
                                int32_t T, const float* d_dense_desc, const float* d_dense_score, int32_t n_images,
-                               int32_t height, int32_t width, int32_t align_corners, LinetrTokens out,
-                               int32_t* d_sub2line, void* d_ws, int64_t ws_bytes, void* stream) {
+                               int32_t height, int32_t width, int32_t align_corners, int32_t dense_is_nhwc,
+                               LinetrTokens out, int32_t* d_sub2line, void* d_ws, int64_t ws_bytes, void* stream) {
   if (!h) return fail(LINETR_E_ARG, "null handle");
   if (K <= 0 || N <= 0) return LINETR_OK;
   if (!d_recs || !d_dense_score || !out.sublines || !out.pnt || !out.mask || !out.resp || !out.angle_sub ||
@@ -769,7 +769,7 @@ extern "C" int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int
     LT_LAUNCH_CHECK();
   }
   if (out.desc) {
-    {
+    if (!dense_is_nhwc) {   // a channel-last map (the repo's producer) is sampled in place
       ProfScope ps(h, st, "nchw_to_nhwc", 0, 2.0 * n_images * P * D * 4);
       hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(P, 64), D / 64, n_images), dim3(256), 0, st, d_dense_desc,
                          nhwc, D, P);
@@ -778,7 +778,7 @@ extern "C" int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int
     const int64_t ntok = (int64_t)N * T;
     ProfScope ps(h, st, "sample_desc", 0, (double)ntok * D * 4 * 2);
     hipLaunchKernelGGL(sample_desc_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, st, out.pnt, s2l_g, d_recs,
-                       ntok, T, nhwc, Hc, Wc, align_corners, out.desc);
+                       ntok, T, dense_is_nhwc ? d_dense_desc : nhwc, Hc, Wc, align_corners, out.desc);
     LT_LAUNCH_CHECK();
   }
   return LINETR_OK;
@@ -1209,10 +1209,25 @@ extern "C" int64_t linetr_match_workspace_bytes(int32_t n_pairs, int64_t sum_n0n
   return align_up((int64_t)n_pairs * sizeof(PairDesc), 256) + align_up(sum_n0n1 * 4, 256) + align_up(scratch * 4, 256) + 256;
 }
 
+extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* dims, const float* d_desc0,
+                                     const int64_t* off_n0, const int32_t* d_s2l0, const int64_t* off_s0,
+                                     const float* d_desc1, const int64_t* off_n1, const int32_t* d_s2l1,
+                                     const int64_t* off_s1, float thr, int32_t mutual, float* d_dk, const int64_t* off_dk,
+                                     int32_t* d_match01, const int64_t* off_k0, void* d_ws, int64_t ws_bytes, void* stream);
+
 extern "C" int linetr_match(LinetrHandle* h, int32_t P, const int32_t* dims, const float* d_desc0, const int64_t* off_n0,
                             const int32_t* d_s2l0, const float* d_desc1, const int64_t* off_n1, const int32_t* d_s2l1,
                             float thr, int32_t mutual, float* d_dk, const int64_t* off_dk, int32_t* d_match01,
                             const int64_t* off_k0, void* d_ws, int64_t ws_bytes, void* stream) {
+  return linetr_match_gathered(h, P, dims, d_desc0, off_n0, d_s2l0, nullptr, d_desc1, off_n1, d_s2l1, nullptr, thr, mutual,
+                               d_dk, off_dk, d_match01, off_k0, d_ws, ws_bytes, stream);
+}
+
+extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* dims, const float* d_desc0,
+                                     const int64_t* off_n0, const int32_t* d_s2l0, const int64_t* off_s0,
+                                     const float* d_desc1, const int64_t* off_n1, const int32_t* d_s2l1,
+                                     const int64_t* off_s1, float thr, int32_t mutual, float* d_dk, const int64_t* off_dk,
+                                     int32_t* d_match01, const int64_t* off_k0, void* d_ws, int64_t ws_bytes, void* stream) {
   if (P < 0) return fail(LINETR_E_ARG, "match: bad argument");
   if (P == 0) return LINETR_OK;
   if (!dims || !off_n0 || !off_n1 || !off_dk || !off_k0 || !d_ws) return fail(LINETR_E_ARG, "match: null argument");
@@ -1230,6 +1245,8 @@ extern "C" int linetr_match(LinetrHandle* h, int32_t P, const int32_t* dims, con
     if (d.n0 < 0 || d.n1 < 0 || d.k0 < 0 || d.k1 < 0 || d.k0 > d.n0 || d.k1 > d.n1)
       return fail(LINETR_E_ARG, "match: bad dims for pair %d", p);
     d.off_n0 = off_n0[p]; d.off_n1 = off_n1[p]; d.off_dk = off_dk[p]; d.off_k0 = off_k0[p];
+    d.off_s0 = off_s0 ? off_s0[p] : off_n0[p];
+    d.off_s1 = off_s1 ? off_s1[p] : off_n1[p];
     d.off_d = od; od += (int64_t)d.n0 * d.n1;
     d.chunks = cdiv(std::max(d.k0, 1), PM_ROWS);
     d.pad_ = 0;

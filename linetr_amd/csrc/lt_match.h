@@ -8,7 +8,8 @@ namespace lt {
 
 struct PairDesc {          // one image pair (device copy lives in the workspace)
   int n0, k0, n1, k1;
-  int64_t off_n0, off_n1;  // row offsets into desc0 / desc1 / sub2line0 / sub2line1
+  int64_t off_n0, off_n1;  // row offsets into desc0 / desc1
+  int64_t off_s0, off_s1;  // element offsets into sub2line0 / sub2line1 (== off_n0 / off_n1 unless the caller says otherwise)
   int64_t off_d;           // offset of D [n0,n1] in the workspace
   int64_t off_dk;          // offset of Dk [k0,k1] in the output
   int64_t off_k0;          // offset of match01 [k0]
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(256) void pair_pool_kernel(const PairDesc* __restri
   const int i0 = chunk * PM_ROWS, rows = min(PM_ROWS, pd.k0 - i0);
   int* seg1 = pm_lds;
   int* seg0 = pm_lds + pd.k1 + 1;
-  const int* m0 = s2l0 + pd.off_n0;
-  const int* m1 = s2l1 + pd.off_n1;
+  const int* m0 = s2l0 + pd.off_s0;
+  const int* m1 = s2l1 + pd.off_s1;
   for (int j = tid; j <= pd.k1; j += 256) seg1[j] = j == pd.k1 ? pd.n1 : seg_lower_bound(m1, pd.n1, j);
   if (tid <= rows) seg0[tid] = i0 + tid == pd.k0 ? pd.n0 : seg_lower_bound(m0, pd.n0, i0 + tid);
   __syncthreads();

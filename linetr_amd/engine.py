@@ -207,8 +207,9 @@ class Engine:
 
     # ------------------------------------------------------------------ device stages
     def tokenize(self, recs, cu_k, cu_n, dense_desc, dense_score, *, token_distance, max_tokens, align_corners=False,
-                 sample_desc=True) -> TokenBatch:
-        """line_tokenizer on the device.  dense_desc [B,256,H/8,W/8], dense_score [B,H,W]."""
+                 sample_desc=True, dense_layout="nchw") -> TokenBatch:
+        """line_tokenizer on the device.  dense_desc [B,256,H/8,W/8] (dense_layout='nchw') or [B,H/8,W/8,256]
+        ('nhwc', the producer's layout: no transposition pass), dense_score [B,H,W]."""
         B = len(cu_k) - 1
         K, N, T = int(cu_k[-1]), int(cu_n[-1]), int(max_tokens)
         dense_desc = self._f32(dense_desc)
@@ -220,8 +221,10 @@ class Engine:
         if dense_desc.shape[0] != B or dense_score.shape[0] != B:
             raise ValueError("dense maps must have one entry per image")
         H, W = int(dense_score.shape[-2]), int(dense_score.shape[-1])
-        if dense_desc.shape[1] != D or dense_desc.shape[2] * 8 != H or dense_desc.shape[3] * 8 != W:
-            raise ValueError(f"dense_descriptor shape {tuple(dense_desc.shape)} does not match dense_score {H}x{W}")
+        nhwc = dense_layout == "nhwc"
+        want = (B, H // 8, W // 8, D) if nhwc else (B, D, H // 8, W // 8)
+        if tuple(dense_desc.shape) != want:
+            raise ValueError(f"dense_descriptor shape {tuple(dense_desc.shape)} does not match {want} ({dense_layout})")
         dev = self.device
         f = dict(dtype=torch.float32, device=dev)
         tb = TokenBatch(
@@ -253,7 +256,7 @@ class Engine:
             ct.desc = None
         nat.check(self._L.linetr_tokenize(self._h, d_recs.data_ptr(), K, N, float(token_distance), T,
                                           dense_desc.data_ptr(), dense_score.data_ptr(), B, H, W, int(bool(align_corners)),
-                                          ct, tb.sub2line.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+                                          int(nhwc), ct, tb.sub2line.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         tb.extra["d_recs"] = d_recs  # keep alive until the stream has consumed it
         return tb
 
@@ -384,6 +387,7 @@ class Engine:
             last["slot"]["event"] = ev
             d_cu = d_blob[last["rec_bytes"] + 4 * (B + 1):].view(torch.int32)
             tb.extra["d_recs"], tb.extra["d_cu_n"] = d_blob, d_cu
+            tb.extra["d_cu_k"] = d_blob[last["rec_bytes"]:last["rec_bytes"] + 4 * (B + 1)].view(torch.int32)
             return d_blob, d_cu
         d_recs = torch.from_numpy(recs.view(np.uint8).reshape(-1)).to(dev)
         tb.extra["d_recs"] = d_recs
@@ -440,6 +444,35 @@ class Engine:
                                        float(thr), int(bool(mutual)), dk.data_ptr(), nat.np_ptr(off_dk[:-1].copy()),
                                        m01.data_ptr(), nat.np_ptr(off_k0), ws.data_ptr(), ws.numel(), self._stream()))
         return dk[:int(off_dk[-1])], off_dk, m01[:int(cu_k0[-1])]
+
+    def match_offsets(self, desc_flat, s2l_flat, dims, off_n0, off_s0, off_n1, off_s1, thr, mutual=True):
+        """linetr_match_gathered: P pairs whose descriptors (rows of desc_flat [R,256]) and key-line maps (elements of
+        s2l_flat int32) sit at arbitrary offsets of the same two buffers -- the form global matching over the all-gathered
+        set uses (parallel.global_match).  dims [P,4] = (n0,k0,n1,k1).
+        Returns (Dk_flat, off_dk host [P+1], match01 int32 [sum k0], off_k0 host [P+1])."""
+        dims = np.ascontiguousarray(dims, dtype=np.int32)
+        P = len(dims)
+        off_dk = np.zeros(P + 1, dtype=np.int64)
+        np.cumsum(dims[:, 1].astype(np.int64) * dims[:, 3].astype(np.int64), out=off_dk[1:])
+        off_k0 = np.zeros(P + 1, dtype=np.int64)
+        np.cumsum(dims[:, 1].astype(np.int64), out=off_k0[1:])
+        dk = torch.empty((max(int(off_dk[-1]), 1),), dtype=torch.float32, device=self.device)
+        m01 = torch.empty((max(int(off_k0[-1]), 1),), dtype=torch.int32, device=self.device)
+        if P == 0:
+            return dk[:0], off_dk, m01[:0], off_k0
+        sum_nn = int((dims[:, 0].astype(np.int64) * dims[:, 2].astype(np.int64)).sum())
+        sum_k = int(dims[:, 1].sum() + dims[:, 3].sum())
+        ws = self._workspace("match", self._L.linetr_match_workspace_bytes(P, sum_nn, 0, sum_k))
+        i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+        o0, o1, s0, s1 = i64(off_n0), i64(off_n1), i64(off_s0), i64(off_s1)
+        odk, ok0 = off_dk[:-1].copy(), off_k0[:-1].copy()
+        d = self._f32(desc_flat)
+        nat.check(self._L.linetr_match_gathered(self._h, P, nat.np_ptr(dims), d.data_ptr(), nat.np_ptr(o0), s2l_flat.data_ptr(),
+                                                nat.np_ptr(s0), d.data_ptr(), nat.np_ptr(o1), s2l_flat.data_ptr(),
+                                                nat.np_ptr(s1), float(thr), int(bool(mutual)), dk.data_ptr(),
+                                                nat.np_ptr(odk), m01.data_ptr(), nat.np_ptr(ok0), ws.data_ptr(), ws.numel(),
+                                                self._stream()))
+        return dk[:int(off_dk[-1])], off_dk, m01[:int(off_k0[-1])], off_k0
 
     def match_points(self, desc0_cn: torch.Tensor, desc1_cn: torch.Tensor, thr, mutual=True):
         """nn_matcher on [256,n] descriptors; returns (dist [n0,n1] device, match01 [n0] device)."""

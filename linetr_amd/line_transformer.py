@@ -175,6 +175,27 @@ class LineTransformer(nn.Module):
         self._engine = None
         return super()._apply(fn, *a, **k)
 
+    def _weights_version(self):
+        """Changes whenever a parameter / buffer is modified in place (optimizer step, p.data.copy_, fine-tuning): the
+        native engine holds a folded COPY of the weights and must be rebuilt then."""
+        return sum(int(t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    # the native handle is a ctypes pointer: never pickled / deep-copied, rebuilt on first use instead
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engine"] = None
+        state["_engine_key"] = None
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k in ("_engine", "_engine_key") else copy.deepcopy(v, memo)
+        return new
+
     def engine(self, device=None) -> Engine:
         dev = torch.device(device) if device is not None else self._device()
         if dev.type != "cuda":
@@ -182,7 +203,7 @@ class LineTransformer(nn.Module):
                                ".to('cuda'); there is no CPU fallback")
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
-        key = (dev, tuple(self.image_shape[-2:]))
+        key = (dev, tuple(self.image_shape[-2:]), self._weights_version())
         if self._engine is None or self._engine_key != key:
             c = self.config
             self._engine = Engine(self.state_dict(), dev, descriptor_dim=c["descriptor_dim"],
@@ -204,13 +225,17 @@ class LineTransformer(nn.Module):
         K = len(klines["klines"])
         if K == 0:
             return klines
-        dd, ds = pred_superpoint["dense_descriptor"], pred_superpoint["dense_score"]
+        ds = pred_superpoint["dense_score"]
+        # a producer that also hands out the channel-last map (linetr_amd.superpoint.FusedHeadSuperPoint) saves the
+        # NCHW -> NHWC pass; the reference's key is used otherwise
+        layout = "nhwc" if pred_superpoint.get("dense_descriptor_nhwc") is not None else "nchw"
+        dd = pred_superpoint["dense_descriptor_nhwc" if layout == "nhwc" else "dense_descriptor"]
         eng = self.engine(dd.device)
         td, T = self.config["token_distance"], self.config["max_tokens"]
         recs, N = eng.pack(klines["klines"], klines["length_klines"], klines["angles"], td, T)
         align = int(torch.__version__[2]) > 2   # the reference's own version switch (line_process.py:93)
         tb = eng.tokenize(recs, np.array([0, K], np.int32), np.array([0, N], np.int32), dd, ds, token_distance=td,
-                          max_tokens=T, align_corners=align)
+                          max_tokens=T, align_corners=align, dense_layout=layout)
         n_sub = torch.from_numpy(recs["n_sub"].astype(np.int64)).to(tb.sub2line.device)
         s2l = tb.sub2line.long()
         A = torch.zeros((K, N), device=tb.sub2line.device)

@@ -36,8 +36,17 @@ class Matching(torch.nn.Module):
     def __init__(self, config={}, superpoint=None, lsd=None):
         super().__init__()
         self.auto_min_length = config["auto_min_length"]
-        self.superpoint = superpoint if superpoint is not None else _frontend("superpoint", "SuperPoint",
-                                                                              config.get("superpoint", {}))
+        if superpoint is None:
+            superpoint = _frontend("superpoint", "SuperPoint", config.get("superpoint", {}))
+            # The host project's SuperPoint (models/superpoint.py:100-205) is wrapped so that its two head post-processing
+            # steps run on linetr_superpoint_heads and the descriptor map ALSO comes out channel-last: the tokeniser then
+            # needs no NCHW -> NHWC pass.  Same dict as the reference's forward plus 'dense_descriptor_nhwc'.
+            # An injected instance is used as given; config['fuse_superpoint_heads'] = False keeps the plain module.
+            if config.get("fuse_superpoint_heads", True) and all(hasattr(superpoint, a) for a in
+                                                                  ("convPa", "convPb", "convDa", "convDb", "relu", "pool")):
+                from .superpoint import FusedHeadSuperPoint
+                superpoint = FusedHeadSuperPoint(superpoint)
+        self.superpoint = superpoint
         self.lsd = lsd if lsd is not None else _frontend("line_detector", "LSD", config.get("lsd", {}))
         self.linetransformer = LineTransformer(config.get("linetransformer", {}))
 

@@ -1,6 +1,13 @@
 """Multi-GPU plumbing: image pairs shard embarrassingly over ranks (pair p -> rank p mod R); the only
-data-path collective is ONE all-gather of the padded line descriptors (+ counts in the same buffer)
-so that every rank holds the global descriptor set for any-vs-any matching.
+data-path collective is ONE all-gather of a fixed-size slab per rank that carries the line descriptors
+together with everything global matching needs about them (per-image sub-line / key-line counts and the
+sub-line -> key-line map), so that every rank holds the global descriptor set for any-vs-any matching
+(BASELINE.json cfg4).
+
+Slab layout, float32 [header_rows + map_rows + rows_cap, 256]:
+    header (int32 bit-cast):  [n_images, n_0 .. n_{cap-1}, k_0 .. k_{cap-1}]      sub-line / key-line counts per image
+    map    (int32 bit-cast):  sub2line[rows_cap]                                  key-line index of every sub-line
+    rows:                     line_desc[N,256], zero-padded to rows_cap
 
 torch.distributed backend "nccl" is RCCL on ROCm (xGMI inside a node); the same code runs on "gloo"
 with CPU tensors, which is how the N>1 path is covered without GPUs (tests/test_distributed_cpu.py).
@@ -20,39 +27,89 @@ def shard_pairs(n_pairs: int, rank: int, world: int):
     return list(range(rank, n_pairs, world))
 
 
+def owner_of(pair: int, world: int):
+    """(rank, local index) of a global pair under shard_pairs."""
+    return pair % world, pair // world
+
+
 def header_rows(n_images_cap: int) -> int:
-    """Rows of the [rows,256] float32 buffer reserved for the int32 header (count + per-image sizes)."""
-    return (1 + n_images_cap + D - 1) // D
+    """Rows of the slab reserved for the int32 header (image count + per-image sub-line and key-line counts)."""
+    return (1 + 2 * n_images_cap + D - 1) // D
 
 
-def pack_descriptors(line_desc: torch.Tensor, cu_n: np.ndarray, n_images_cap: int, rows_cap: int,
-                     out: torch.Tensor | None = None) -> torch.Tensor:
-    """[N,256] + per-image sub-line counts -> fixed-size buffer [header + rows_cap, 256].
+def map_rows(rows_cap: int) -> int:
+    """Rows of the slab that hold the sub-line -> key-line map."""
+    return (rows_cap + D - 1) // D
 
-    The header stores int32 values bit-cast into the float32 buffer: [n_images, n_0, n_1, ...]."""
+
+def slab_rows(n_images_cap: int, rows_cap: int) -> int:
+    return header_rows(n_images_cap) + map_rows(rows_cap) + rows_cap
+
+
+def _as_i32(x, device):
+    if torch.is_tensor(x):
+        return x.to(device=device, dtype=torch.int32)
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).to(device)
+
+
+def pack_descriptors(line_desc: torch.Tensor, cu_n, n_images_cap: int, rows_cap: int, out: torch.Tensor | None = None,
+                     cu_k=None, sub2line: torch.Tensor | None = None, d_cu_n: torch.Tensor | None = None,
+                     d_cu_k: torch.Tensor | None = None) -> torch.Tensor:
+    """[N,256] descriptors + per-image counts (+ key-line counts and the sub-line map) -> one fixed-size slab.
+
+    cu_n / cu_k are the host prefix sums [B+1]; when the same arrays already live on the device (d_cu_n / d_cu_k, as
+    Engine.describe leaves them) the header is assembled there and nothing is copied from the host."""
     n_img = len(cu_n) - 1
     N = int(cu_n[-1])
     if n_img > n_images_cap or N > rows_cap:
         raise ValueError(f"capacity exceeded: {n_img}>{n_images_cap} images or {N}>{rows_cap} rows")
-    hr = header_rows(n_images_cap)
+    hr, mr = header_rows(n_images_cap), map_rows(rows_cap)
+    dev = line_desc.device
     if out is None:
-        out = torch.zeros((hr + rows_cap, D), dtype=torch.float32, device=line_desc.device)
-    hdr = np.zeros(hr * D, dtype=np.int32)
-    hdr[0] = n_img
-    hdr[1:1 + n_img] = np.diff(cu_n)
-    out[:hr].view(torch.int32).view(-1).copy_(torch.from_numpy(hdr), non_blocking=True)
-    out[hr:hr + N].copy_(line_desc[:N])
+        out = torch.zeros((hr + mr + rows_cap, D), dtype=torch.float32, device=dev)
+    hdr = out[:hr].view(torch.int32).view(-1)
+    if d_cu_n is not None and (cu_k is None or d_cu_k is not None):
+        hdr[0:1].fill_(n_img)
+        hdr[1:1 + n_img] = d_cu_n[1:n_img + 1] - d_cu_n[:n_img]
+        if d_cu_k is not None:
+            hdr[1 + n_images_cap:1 + n_images_cap + n_img] = d_cu_k[1:n_img + 1] - d_cu_k[:n_img]
+    else:
+        h = np.zeros(1 + 2 * n_images_cap, dtype=np.int32)
+        h[0] = n_img
+        h[1:1 + n_img] = np.diff(cu_n)
+        if cu_k is not None:
+            h[1 + n_images_cap:1 + n_images_cap + n_img] = np.diff(cu_k)
+        src = torch.from_numpy(h)
+        if dev.type == "cuda":
+            src = src.pin_memory()
+        hdr[:h.size].copy_(src, non_blocking=True)
+    if sub2line is not None:
+        out[hr:hr + mr].view(torch.int32).view(-1)[:N].copy_(sub2line[:N])
+    out[hr + mr:hr + mr + N].copy_(line_desc[:N])
     return out
 
 
-def unpack_descriptors(buf: torch.Tensor, n_images_cap: int):
-    """Inverse of pack_descriptors for one rank's slab: returns (line_desc [N,256] view, cu_n)."""
+def unpack_descriptors(buf: torch.Tensor, n_images_cap: int, rows_cap: int | None = None, with_lines: bool = False):
+    """Inverse of pack_descriptors for one rank's slab: (line_desc [N,256] view, cu_n) or, with_lines=True,
+    (line_desc, cu_n, sub2line [N] int32 view, cu_k).  One small D2H copy of the header (synchronises)."""
     hr = header_rows(n_images_cap)
-    hdr = buf[:hr].view(torch.int32).view(-1)[:1 + n_images_cap].cpu().numpy()
+    if rows_cap is None:                       # infer from the slab height:  rows = hr + ceil(cap/256) + cap
+        rest = buf.shape[0] - hr
+        rows_cap = rest - (rest + D) // (D + 1)
+        while map_rows(rows_cap) + rows_cap < rest:
+            rows_cap += 1
+    mr = map_rows(rows_cap)
+    hdr = buf[:hr].view(torch.int32).view(-1)[:1 + 2 * n_images_cap].cpu().numpy()
     n_img = int(hdr[0])
     cu = np.zeros(n_img + 1, dtype=np.int32)
     np.cumsum(hdr[1:1 + n_img], out=cu[1:])
-    return buf[hr:hr + int(cu[-1])], cu
+    desc = buf[hr + mr:hr + mr + int(cu[-1])]
+    if not with_lines:
+        return desc, cu
+    cu_k = np.zeros(n_img + 1, dtype=np.int32)
+    np.cumsum(hdr[1 + n_images_cap:1 + n_images_cap + n_img], out=cu_k[1:])
+    s2l = buf[hr:hr + mr].view(torch.int32).view(-1)[:int(cu[-1])]
+    return desc, cu, s2l, cu_k
 
 
 def allgather_descriptors(packed: torch.Tensor, group=None, async_op: bool = False):
@@ -65,3 +122,52 @@ def allgather_descriptors(packed: torch.Tensor, group=None, async_op: bool = Fal
     work = dist.all_gather_into_tensor(out, packed.contiguous(), group=group, async_op=async_op)  # dim-0 concatenation
     out = out.view((world, rows) + tuple(packed.shape[1:]))
     return (work, out) if async_op else out
+
+
+class GatheredSet:
+    """The global descriptor set after the all-gather: per-rank views + host tables, images addressed globally.
+
+    Slab r holds the images of rank r in local order; with pairs sharded round-robin, the two images of global pair p
+    are local images 2*(p // R) and 2*(p // R) + 1 of rank p % R."""
+
+    def __init__(self, gathered: torch.Tensor, n_images_cap: int, rows_cap: int):
+        self.world = int(gathered.shape[0])
+        self.flat = gathered.reshape(-1, D)
+        self.slab = int(gathered.shape[1])
+        self.hr, self.mr = header_rows(n_images_cap), map_rows(rows_cap)
+        hdr = gathered[:, :self.hr].reshape(self.world, -1).view(torch.int32)[:, :1 + 2 * n_images_cap].cpu().numpy()
+        self.cu_n, self.cu_k = [], []
+        for r in range(self.world):
+            n_img = int(hdr[r, 0])
+            self.cu_n.append(np.concatenate([[0], np.cumsum(hdr[r, 1:1 + n_img])]).astype(np.int64))
+            self.cu_k.append(np.concatenate([[0], np.cumsum(hdr[r, 1 + n_images_cap:1 + n_images_cap + n_img])]).astype(np.int64))
+        # one int32 view of the whole buffer: the sub-line maps are addressed with absolute element offsets
+        self.flat_i32 = self.flat.view(torch.int32).view(-1)
+
+    def image(self, rank: int, local_image: int):
+        """(row offset into self.flat, n, element offset of the image's sub2line in flat_i32, k)."""
+        cn, ck = self.cu_n[rank], self.cu_k[rank]
+        n0 = int(cn[local_image])
+        row = rank * self.slab + self.hr + self.mr + n0
+        s2l = (rank * self.slab + self.hr) * D + n0
+        return row, int(cn[local_image + 1]) - n0, s2l, int(ck[local_image + 1] - ck[local_image])
+
+    def pair_image(self, pair: int, side: int):
+        r, loc = owner_of(pair, self.world)
+        return self.image(r, 2 * loc + side)
+
+
+def global_match(eng, gs: GatheredSet, queries, candidates, thr: float, mutual: bool = True):
+    """Match image `queries[i]` against image `candidates[i]` for all i in ONE linetr_match call, every image addressed
+    inside the gathered buffer (so any rank's descriptors can be on either side).
+    queries / candidates: lists of (rank, local_image).  Returns (dk_flat, off_dk, match01, off_k0) as Engine.match."""
+    P = len(queries)
+    dims = np.zeros((P, 4), dtype=np.int32)
+    off0 = np.zeros(P, dtype=np.int64); off1 = np.zeros(P, dtype=np.int64)
+    s0 = np.zeros(P, dtype=np.int64); s1 = np.zeros(P, dtype=np.int64)
+    for i, (q, c) in enumerate(zip(queries, candidates)):
+        r0, n0, m0, k0 = gs.image(*q)
+        r1, n1, m1, k1 = gs.image(*c)
+        dims[i] = (n0, k0, n1, k1)
+        off0[i], off1[i], s0[i], s1[i] = r0, r1, m0, m1
+    return eng.match_offsets(gs.flat, gs.flat_i32, dims, off0, s0, off1, s1, thr, mutual)

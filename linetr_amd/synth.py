@@ -240,3 +240,199 @@ def superpoint_state_dict(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
         sd[name + ".weight"] = (rs.standard_normal((co, ci, k, k)) * std).astype(np.float32)
         sd[name + ".bias"] = (rs.standard_normal(co) * 0.05).astype(np.float32)
     return sd
+
+
+# ----------------------------------------------------------------------------
+# cfg4: homography-augmented pairs.  Restates the recipe of the reference's dataset builder
+# (/root/reference/dataloaders/utils/homographies.py:12-141, called with the parameters of
+# /root/reference/dataloaders/confs/homography.yaml:31-46 on the normalised [-1,1]^2 square and rescaled to pixels as
+# /root/reference/dataloaders/build_homography_dataset.py:122-145 does) on a seeded RandomState.  Image 1 is image 0
+# seen through the homography: line end points are warped, lines leaving the image are dropped.
+# ----------------------------------------------------------------------------
+
+HOMOGRAPHY_PARAMS = dict(perspective=True, scaling=True, translation=True, rotation=True, patch_ratio=0.85,
+                         perspective_amplitude_x=0.2, perspective_amplitude_y=0.2, scaling_amplitude=0.2,
+                         max_angle=1.0472, allow_artifacts=True)
+
+
+def _truncnorm(rs, scale, size, loc=0.0, std_trunc=2.0):
+    """N(loc, scale) truncated to +-std_trunc sigma (scipy.stats.truncnorm(-2, 2, loc, scale)) by rejection."""
+    out = np.empty(size, dtype=np.float64)
+    i = 0
+    while i < size:
+        v = rs.standard_normal()
+        if abs(v) <= std_trunc:
+            out[i] = loc + scale * v
+            i += 1
+    return out
+
+
+def _perspective_transform(src, dst):
+    """3x3 H with dst ~ H src for four point pairs (cv2.getPerspectiveTransform on float32-rounded points)."""
+    src = np.asarray(src, np.float32).astype(np.float64)
+    dst = np.asarray(dst, np.float32).astype(np.float64)
+    a, b = [], []
+    for (x, y), (u, v) in zip(src, dst):
+        a.append([x, y, 1, 0, 0, 0, -x * u, -y * u]); b.append(u)
+        a.append([0, 0, 0, x, y, 1, -x * v, -y * v]); b.append(v)
+    h = np.linalg.solve(np.asarray(a), np.asarray(b))
+    return np.append(h, 1.0).reshape(3, 3)
+
+
+def sample_homography(rs, shape=(2.0, 2.0), shift=-1.0, perspective=True, scaling=True, rotation=True,
+                      translation=True, n_scales=5, n_angles=25, scaling_amplitude=0.1, perspective_amplitude_x=0.1,
+                      perspective_amplitude_y=0.1, patch_ratio=0.5, max_angle=math.pi / 2, allow_artifacts=False,
+                      translation_overflow=0.0):
+    """A random homography between the unit square's corners and a perturbed centred patch
+    (homographies.py:48-141: perspective -> scaling -> translation -> rotation, in that order, with the same
+    validity rules; `rs` replaces the global numpy RNG)."""
+    pts1 = np.array([[0., 0.], [0., 1.], [1., 1.], [1., 0.]])
+    margin = (1 - patch_ratio) / 2
+    pts2 = margin + np.array([[0, 0], [0, patch_ratio], [patch_ratio, patch_ratio], [patch_ratio, 0]], dtype=np.float64)
+    if perspective:
+        if not allow_artifacts:
+            perspective_amplitude_x = min(perspective_amplitude_x, margin)
+            perspective_amplitude_y = min(perspective_amplitude_y, margin)
+        pd = _truncnorm(rs, perspective_amplitude_y / 2, 1)[0]
+        hl = _truncnorm(rs, perspective_amplitude_x / 2, 1)[0]
+        hr = _truncnorm(rs, perspective_amplitude_x / 2, 1)[0]
+        pts2 = pts2 + np.array([[hl, pd], [hl, -pd], [hr, pd], [hr, -pd]])
+    if scaling:
+        scales = np.concatenate(([1.0], _truncnorm(rs, scaling_amplitude / 2, n_scales, loc=1.0)))
+        center = pts2.mean(axis=0, keepdims=True)
+        scaled = (pts2 - center)[None] * scales[:, None, None] + center
+        if allow_artifacts:
+            valid = np.arange(n_scales)
+        else:
+            valid = np.where(((scaled >= 0.) & (scaled < 1.)).all(axis=(1, 2)))[0]
+        pts2 = scaled[valid[rs.randint(valid.shape[0])]]
+    if translation:
+        t_min, t_max = pts2.min(axis=0), (1 - pts2).min(axis=0)
+        if allow_artifacts:
+            t_min = t_min + translation_overflow
+            t_max = t_max + translation_overflow
+        pts2 = pts2 + np.array([rs.uniform(-t_min[0], t_max[0]), rs.uniform(-t_min[1], t_max[1])])[None]
+    if rotation:
+        angles = np.concatenate((np.linspace(-max_angle, max_angle, num=n_angles), [0.0]))
+        center = pts2.mean(axis=0, keepdims=True)
+        rot = np.stack([np.cos(angles), -np.sin(angles), np.sin(angles), np.cos(angles)], axis=1).reshape(-1, 2, 2)
+        rotated = np.matmul((pts2 - center)[None], rot) + center
+        if allow_artifacts:
+            valid = np.arange(n_angles)
+        else:
+            valid = np.where(((rotated >= 0.) & (rotated < 1.)).all(axis=(1, 2)))[0]
+        pts2 = rotated[valid[rs.randint(valid.shape[0])]]
+    size = np.asarray(shape, dtype=np.float64)[::-1][None]
+    return _perspective_transform(pts1 * size + shift, pts2 * size + shift)
+
+
+def pixel_homography(rs, height, width, strength: float = 1.0, **params):
+    """Homography x1 ~ M x0 taking image-0 pixels to image-1 pixels: the builder samples on [-1,1]^2, rescales to
+    pixels and warps the image with the INVERSE (build_homography_dataset.py:141-164).
+    strength < 1 shrinks the sampled homography towards the identity (H -> I + strength (H - I) on the normalised
+    square): the seeded, untrained weights of this repo are not viewpoint-invariant, so recall against the known
+    homography is only meaningful for mild views; strength = 1 is the yaml's recipe unchanged."""
+    hn = sample_homography(rs, **{**HOMOGRAPHY_PARAMS, **params})
+    if strength != 1.0:
+        hn = hn / hn[2, 2]
+        hn = np.eye(3) + float(strength) * (hn - np.eye(3))
+    trans = np.array([[2. / width, 0., -1.], [0., 2. / height, -1.], [0., 0., 1.]])
+    h_pix = np.linalg.inv(trans) @ hn @ trans
+    m = np.linalg.inv(h_pix)
+    return m / m[2, 2]
+
+
+def warp_points(m, xy):
+    """[...,2] points through the 3x3 homography m."""
+    xy = np.asarray(xy, dtype=np.float64)
+    q = xy @ m[:2, :2].T + m[:2, 2]
+    w = xy @ m[2, :2] + m[2, 2]
+    return q / w[..., None]
+
+
+def homography_pair(seed: int, n_lines: int = 200, height: int = 480, width: int = 640, len_lo: float = 17.0,
+                    len_hi: float = 167.0, margin: float = 10.0, common_frac: float = 0.85, strength: float = 1.0):
+    """One homography-augmented pair of detector outputs.
+
+    Returns (lines0 [n,6], lines1 [n,6], M, gt) where M takes image-0 pixels to image-1 pixels and gt [n] gives, for
+    every row of lines0, the row of lines1 that is its warp (or -1).  About `common_frac` of the lines are seen in
+    both images (their warped end points stay inside the margin box); the rest are lines of image 0 whose warp leaves
+    image 1, respectively fresh lines that only image 1 has.  Image-1 rows are shuffled.  All coordinates are f32
+    values, lineLength = f32(hypot) of the (warped) end points, octave 0."""
+    rs = np.random.RandomState(seed)
+    m = pixel_homography(rs, height, width, strength)
+    n_common = int(round(n_lines * common_frac))
+
+    def inside(x, y):
+        return margin <= x <= width - margin and margin <= y <= height - margin
+
+    def row(sx, sy, ex, ey):
+        sx, sy, ex, ey = (float(np.float32(v)) for v in (sx, sy, ex, ey))
+        return [sx, sy, ex, ey, float(np.float32(math.hypot(ex - sx, ey - sy))), 0.0]
+
+    def draw():
+        while True:
+            sx = rs.uniform(margin, width - margin)
+            sy = rs.uniform(margin, height - margin)
+            ln = rs.uniform(len_lo, len_hi)
+            th = rs.uniform(0.0, 2.0 * math.pi)
+            ex, ey = sx + ln * math.cos(th), sy + ln * math.sin(th)
+            if inside(ex, ey):
+                return sx, sy, ex, ey
+
+    common0, common1, only0 = [], [], []
+    tries = 0
+    while len(common0) < n_common or len(only0) < n_lines - n_common:
+        tries += 1
+        if tries > 200 * n_lines:     # a degenerate view (hardly any overlap): fill up with whatever fits
+            break
+        l0 = draw()
+        w = warp_points(m, np.array([[l0[0], l0[1]], [l0[2], l0[3]]]))
+        ok = inside(*w[0]) and inside(*w[1]) and math.hypot(*(w[1] - w[0])) >= len_lo
+        if ok and len(common0) < n_common:
+            common0.append(row(*l0)); common1.append(row(w[0, 0], w[0, 1], w[1, 0], w[1, 1]))
+        elif not ok and len(only0) < n_lines - n_common:
+            only0.append(row(*l0))
+    while len(common0) + len(only0) < n_lines:
+        only0.append(row(*draw()))
+    only1 = [row(*draw()) for _ in range(n_lines - len(common1))]
+    lines0 = np.asarray(common0 + only0, dtype=np.float64).reshape(-1, 6)
+    l1 = np.asarray(common1 + only1, dtype=np.float64).reshape(-1, 6)
+    perm0 = rs.permutation(n_lines)
+    perm1 = rs.permutation(n_lines)
+    lines0, lines1 = lines0[perm0], l1[perm1]
+    inv1 = np.empty(n_lines, dtype=np.int64)
+    inv1[perm1] = np.arange(n_lines)
+    src = perm0                                            # lines0[i] was row perm0[i] of the unshuffled list
+    gt = np.where(src < len(common0), inv1[np.minimum(src, n_lines - 1)], -1)
+    return lines0, lines1, m, gt
+
+
+def warp_dense_maps(dense_desc, dense_score, m, noise: float = 0.05, seed: int = 0):
+    """Dense maps of image 1 = the maps of image 0 seen through m (x1 ~ m x0): bilinear resampling at the maps' own
+    resolution (descriptor grid 1/8), a little seeded noise, descriptors re-normalised.  torch tensors in, same
+    device/dtype out ([1,256,Hc,Wc], [1,H,W])."""
+    import torch
+    import torch.nn.functional as F
+    dev = dense_desc.device
+    H, W = int(dense_score.shape[-2]), int(dense_score.shape[-1])
+    minv = torch.from_numpy(np.linalg.inv(m)).to(device=dev, dtype=torch.float32)
+
+    def grid(h, w, step):
+        ys, xs = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32),
+                                torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
+        x1 = xs * step + (step - 1) / 2.0                 # pixel centre of the cell in image 1
+        y1 = ys * step + (step - 1) / 2.0
+        den = minv[2, 0] * x1 + minv[2, 1] * y1 + minv[2, 2]
+        x0 = (minv[0, 0] * x1 + minv[0, 1] * y1 + minv[0, 2]) / den
+        y0 = (minv[1, 0] * x1 + minv[1, 1] * y1 + minv[1, 2]) / den
+        gx = (x0 - (step - 1) / 2.0) / step               # cell coordinates in image 0's map
+        gy = (y0 - (step - 1) / 2.0) / step
+        return torch.stack([2 * (gx + 0.5) / w - 1, 2 * (gy + 0.5) / h - 1], dim=-1)[None]
+
+    g = torch.Generator(device=dev).manual_seed(int(seed))
+    dd = F.grid_sample(dense_desc, grid(H // 8, W // 8, 8), mode="bilinear", padding_mode="border", align_corners=False)
+    dd = dd + noise * torch.randn(dd.shape, generator=g, device=dev) / math.sqrt(dd.shape[1])
+    dd = F.normalize(dd, p=2, dim=1)
+    ds = F.grid_sample(dense_score[None], grid(H, W, 1), mode="bilinear", padding_mode="border", align_corners=False)[0]
+    return dd.contiguous(), ds.clamp(0, 1).contiguous()

@@ -207,3 +207,151 @@ def test_nn_matcher_known_answers():
         assert np.array_equal(nn_matcher_distmat(g[f"{k}_dist"], 0.8, False), g[f"{k}_oneway"]), k
     M, D = nn_matcher(g["point_desc0"], g["point_desc1"], 0.7, True)
     assert np.array_equal(M, g["point_M"]) and np.abs(D - g["point_D"]).max() < 1e-5
+
+
+def _golden_matching(g, **cfg):
+    from models.matching import Matching
+    mt = Matching({"auto_min_length": True, "superpoint": {}, "lsd": {}, "linetransformer": {**LT_CFG}, **cfg},
+                  superpoint=FakeSuperPoint([int(g["a_seed"]), int(g["b_seed"])]), lsd=FakeLSD([g["a_lines"], g["b_lines"]]))
+    mt.linetransformer.load_state_dict(synth.to_torch_state_dict(synth.calibrated_state_dict()))
+    return mt.eval().to("cuda")
+
+
+def test_matching_anchor_caching_like_the_demo():
+    """demo_LineTR.py:155,207,250: the anchor frame's outputs are fed back as keypoints0 / scores0 / descriptors0 /
+    klines0 / line_desc0 / mat_klines2sublines0 (+ image0) and only image 1 is processed.  With frame b of the golden
+    pair as anchor and frame a as the new image the line matches are the golden pair's, transposed."""
+    g = load("cfg2_pair")
+    mt = _golden_matching(g)
+    img = torch.zeros(1, 1, 480, 640, device="cuda")
+    pred = mt({"image0": img, "image1": img.clone()})
+    keys = ["keypoints", "scores", "descriptors", "klines", "line_desc", "mat_klines2sublines"]     # demo_LineTR.py:155
+    last = {k + "0": pred[k + "1"] for k in keys}
+    last["image0"] = img
+    mt.superpoint.seeds = [int(g["a_seed"])]          # only ONE image may go through SuperPoint / LSD now
+    mt.lsd.sets = [g["a_lines"]]
+    pred2 = mt({**last, "image1": img.clone()})
+    assert mt.superpoint.seeds == [] and mt.lsd.sets == []
+    assert "klines0" not in pred2 and "keypoints0" not in pred2 and "klines1" in pred2 and "keypoints1" in pred2
+    assert np.array_equal(pred2["matches_l"].numpy()[0], g["pair_M"][0].T)
+    assert np.abs(pred2["matching_scores_l"].numpy()[0] - g["pair_Dk"][0].T).max() < 1e-4
+    assert torch.equal(pred2["klines1"].cpu(), pred["klines0"].cpu())
+    assert (pred2["line_desc1"] - pred["line_desc0"]).abs().max().item() < 1e-6
+    # and the demo reads them back exactly like this (demo_LineTR.py:207-222)
+    kl0 = last["klines0"][0].cpu().numpy()
+    kl1 = pred2["klines1"][0].cpu().numpy()
+    ml = np.where(pred2["matches_l"][0].cpu().numpy() > 0)
+    assert kl0[ml[0]].shape == kl1[ml[1]].shape == (int(g["pair_M"].sum()), 2, 2)
+
+
+def test_npz_payload_roundtrip_like_match_line_pairs(tmp_path):
+    """match_line_pairs.py:91-104: every value of the returned dict is indexed with [0], tensors go through
+    .cpu().numpy(), and eight arrays are written with np.savez.  Same key set, shapes and dtypes here."""
+    g = load("cfg2_pair")
+    pred_matches = _golden_matching(g)({"image0": torch.zeros(1, 1, 480, 640, device="cuda"),
+                                        "image1": torch.zeros(1, 1, 480, 640, device="cuda")})
+    pred = {k: v[0].cpu().numpy() for k, v in pred_matches.items() if torch.is_tensor(v[0])}
+    pred = {**pred, **{k: v[0] for k, v in pred_matches.items() if not torch.is_tensor(v[0])}}
+    out = {"keypoints0": pred["keypoints0"], "keypoints1": pred["keypoints1"], "matches_p": pred["matches_p"],
+           "match_confidence_p": pred["matching_scores_p"], "keylines0": pred["klines0"], "keylines1": pred["klines1"],
+           "matches_l": pred["matches_l"], "match_confidence_l": pred["matching_scores_l"]}
+    path = tmp_path / "a_b_matches.npz"
+    np.savez(str(path), **out)
+    z = np.load(str(path))
+    assert sorted(z.files) == sorted(out)
+    n0, n1 = z["keypoints0"].shape[0], z["keypoints1"].shape[0]
+    want = {"keypoints0": ((n0, 2), np.float32), "keypoints1": ((n1, 2), np.float32), "matches_p": ((n0, n1), np.float64),
+            "match_confidence_p": ((n0, n1), np.float32), "keylines0": ((199, 2, 2), np.float32),
+            "keylines1": ((199, 2, 2), np.float32), "matches_l": ((199, 199), np.float64),
+            "match_confidence_l": ((199, 199), np.float32)}
+    for k, (shape, dt) in want.items():
+        assert z[k].shape == shape and z[k].dtype == dt, (k, z[k].shape, z[k].dtype)
+    assert np.array_equal(z["matches_l"], g["pair_M"][0]) and np.array_equal(z["keylines0"], g["a_klines"][0])
+    assert np.abs(z["match_confidence_l"] - g["pair_Dk"][0]).max() < 1e-4
+
+
+def test_forward_batch_on_the_golden_pair():
+    """forward_batch fed the reference-generated cfg2 pair (twice, as a batch of two pairs): matches identical to the
+    golden, descriptors within 1e-4, key-lines bit-exact (the golden has no equal-length lines, so the native
+    pre-filter's tie rule does not come into play)."""
+    g = load("cfg2_pair")
+    from models.matching import Matching
+    seeds = [int(g["a_seed"]), int(g["b_seed"])] * 2
+    mt = Matching({"auto_min_length": True, "linetransformer": {**LT_CFG}}, superpoint=FakeSuperPoint(seeds),
+                  lsd=FakeLSD([g["a_lines"], g["b_lines"]] * 2))
+    mt.linetransformer.load_state_dict(synth.to_torch_state_dict(synth.calibrated_state_dict()))
+    mt = mt.eval().to("cuda")
+    img = torch.zeros(1, 1, 480, 640, device="cuda")
+    out = mt.forward_batch([{"image0": img, "image1": img.clone()} for _ in range(2)])
+    for pred in out:
+        assert np.array_equal(pred["matches_l"].numpy(), g["pair_M"])
+        assert np.abs(pred["matching_scores_l"].numpy() - g["pair_Dk"]).max() < 1e-4
+        for s, t in (("0", "a"), ("1", "b")):
+            assert np.array_equal(pred["klines" + s].cpu().numpy(), g[f"{t}_klines"])
+            assert np.abs(pred["line_desc" + s].cpu().numpy() - g[f"{t}_line_desc"]).max() < 1e-4
+            assert np.array_equal(pred["mat_klines2sublines" + s].cpu().numpy(), g[f"{t}_mat_klines2sublines"])
+
+
+def test_prefilter_tie_order_native_vs_numpy():
+    """Equal-length lines: the batched native pre-filter orders ties stable-argsort-reversed (documented deviation,
+    DESIGN.md section 8); NumPy's argsort on this host may order them differently.  Either way the SET of key-lines and
+    every descriptor is the same -- only the row order of tied lines may differ -- and with all lengths distinct the two
+    paths agree row for row."""
+    from linetr_amd.engine import Engine
+    from linetr_amd.line_transformer import change_cv2_T_np, filter_by_length, remove_borders
+    eng = Engine(synth.calibrated_state_dict(), "cuda:0")
+    rows = synth.synth_lines(77, 40, 480, 640)
+    rows[5, 4] = rows[9, 4] = rows[21, 4] = 55.0            # three lines of equal detector length
+    recs, cu_k, cu_n = eng.prefilter([rows], 480, 640, remove_borders=8, min_length=16, max_keylines=-1,
+                                     token_distance=8, max_tokens=21)
+    kl = change_cv2_T_np(synth.array_to_keylines(rows))
+    kl = filter_by_length(remove_borders(kl, 8, 480, 640, np.ones((480, 640))), 16, -1)
+    nat = np.stack([recs["sp"], recs["ep"]], axis=1)
+    assert nat.shape == kl["klines"].shape
+    key = lambda a: sorted(map(tuple, a.reshape(len(a), -1).tolist()))
+    assert key(nat) == key(kl["klines"])
+    assert np.array_equal(recs["length"], kl["length_klines"])           # lengths are sorted identically
+    tied = np.isin(kl["length_klines"], [55.0])
+    assert np.array_equal(nat[~tied], kl["klines"][~tied])
+
+
+def test_matching_wraps_the_host_superpoint(monkeypatch):
+    """Matching() without an injected SuperPoint builds the host project's models.superpoint.SuperPoint and wraps it with
+    FusedHeadSuperPoint (heads on linetr_superpoint_heads, channel-last map for the tokeniser); the line branch then
+    gives the same descriptors and matches as the un-fused module."""
+    import sys
+    import types
+    from test_gpu_producer import _Helpers, _StandInSuperPoint
+    from linetr_amd.superpoint import FusedHeadSuperPoint
+
+    class SuperPoint(_StandInSuperPoint):
+        def __init__(self, config):
+            super().__init__()
+            self.config = {**self.config, "nn_threshold": 0.7, **config}
+            self.load_state_dict({k: torch.from_numpy(v) for k, v in synth.superpoint_state_dict(0).items()})
+
+    mod = types.ModuleType("models.superpoint")
+    mod.SuperPoint = SuperPoint
+    for fn in ("simple_nms", "remove_borders", "top_k_keypoints", "sample_descriptors"):
+        setattr(mod, fn, getattr(_Helpers, fn))
+    SuperPoint.__module__ = "models.superpoint"
+    monkeypatch.setitem(sys.modules, "models.superpoint", mod)
+    from models.matching import Matching
+    lines = [synth.synth_lines(61, 80, 96, 128, 17.0, 60.0, margin=9.0), synth.synth_lines(62, 80, 96, 128, 17.0, 60.0, margin=9.0)]
+    rs = np.random.RandomState(1)
+    imgs = [torch.from_numpy(rs.rand(1, 1, 96, 128).astype(np.float32)).cuda() for _ in range(2)]
+    preds = []
+    for fuse in (True, False):
+        mt = Matching({"auto_min_length": True, "linetransformer": {**LT_CFG}, "fuse_superpoint_heads": fuse}, lsd=FakeLSD(lines))
+        assert isinstance(mt.superpoint, FusedHeadSuperPoint) == fuse
+        mt.linetransformer.load_state_dict(synth.to_torch_state_dict(synth.calibrated_state_dict()))
+        mt = mt.eval().to("cuda")
+        if not fuse:                                     # the plain stand-in has no forward of its own: borrow the wrapper's maths
+            plain = FusedHeadSuperPoint(mt.superpoint)
+            sp_forward = lambda data, plain=plain: {k: v for k, v in plain(data).items() if k != "dense_descriptor_nhwc"}
+            mt.superpoint.forward = sp_forward
+        preds.append(mt({"image0": imgs[0], "image1": imgs[1]}))
+    a, b = preds
+    assert "dense_descriptor_nhwc0" in a and "dense_descriptor_nhwc0" not in b
+    assert torch.equal(a["matches_l"], b["matches_l"]) and torch.equal(a["klines0"].cpu(), b["klines0"].cpu())
+    assert (a["line_desc1"] - b["line_desc1"]).abs().max().item() < 1e-6

@@ -117,3 +117,24 @@ def test_fused_posenc_layers_vs_torch(rows):
     xin = torch.cat([(sn[:, 0] + sn[:, 1]) / 2, resp[:, None], ang], dim=1)
     want = _folded_mlp_reference(sd, "klenc.line_position_enc.encoder", xin)
     assert (got - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-6), ("bf16x6", 2e-6), ("f16x3", 4e-6), ("bf16x3", 3e-5)])
+@pytest.mark.parametrize("M,N,K,act", [(398, 512, 512, 1), (33, 256, 1024, 2), (1, 768, 256, 0), (400, 64, 544, 3)])
+def test_gemm_small_m_kernel(eng, mode, tol, M, N, K, act):
+    """Single-pair sizes: the barrier-free K-split kernel (lt_gemm_small.h: 32 x 32 tiles, the block's 4 waves split K,
+    fragments straight from global memory) with every epilogue piece, ragged M, K = 17 tiles (uneven split), against
+    float64.  In f32 mode the same shapes run on the tiled fp32 kernel."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    R = torch.randn(M, N, device="cuda", generator=g)
+    eng.set_precision(mode)
+    try:
+        Y = eng.debug_gemm(A, W, b, R, act)
+    finally:
+        eng.set_precision("bf16x6")
+    x = A.double() @ W.double().t() + b.double()
+    x = [x, torch.relu(x), torch.nn.functional.gelu(x), (2 - 2 * x).clamp(min=0)][act] + R.double()
+    assert ((Y.double() - x).abs().max() / x.abs().max()).item() < tol

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(nat.EXPORTS), declared ^ set(nat.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.linetr_abi_version() == 1
+    assert L.linetr_abi_version() == 2
     assert C.sizeof(nat.LineRec) == 80
 
 

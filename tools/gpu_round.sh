@@ -1,0 +1,49 @@
+#!/bin/bash
+# One gpurun call = every measurement of a round, stage by stage (a failing stage does not stop the next one).
+#   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh r02a "tests bench shapes prof pmc cfg4 two"'
+tag=${1:-rXX}; stages=${2:-"tests bench"}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+O=gpurun_out/$tag
+has() { [[ " $stages " == *" $1 "* ]]; }
+if has tests; then
+  timeout 900 python -m pytest tests -m gpu -x -q > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -4 ${O}_pytest.log
+fi
+if has bench; then
+  timeout 600 python bench.py --steps 20 --warmup 5 > ${O}_bench.json 2> ${O}_bench.log; echo "bench rc=$?"; cut -c1-900 ${O}_bench.json
+fi
+if has shapes; then   # per-GEMM-shape HIP-event profile of the cfg3 step
+  LINETR_PROFILE_SHAPES=1 timeout 300 python bench.py --steps 10 --no-cpu-baseline --no-alt-precisions --no-sub-workloads > ${O}_bench_shapes.json 2> ${O}_bench_shapes.log
+  python - ${O}_bench_shapes.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+for k, v in sorted(d["kernels"].items(), key=lambda kv: -kv[1]["ms"])[:24]:
+    print(f"{v['ms']:8.4f} ms x{v['calls']:3d} {v['tflops']}  {k}")
+PY
+fi
+if has prof; then     # rocprofv3 kernel stats, one run per workload
+  for wl in cfg3 cfg2 cfg5; do
+    timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$wl -o p -- \
+      python bench.py --workload $wl --steps 5 --warmup 2 --settle-s 0.5 --no-cpu-baseline --no-alt-precisions --no-sub-workloads \
+      > ${O}_${wl}_bench_under_rocprof.json 2> ${O}_${wl}_prof.log
+    f=$(ls gpurun_out/prof_${tag}_$wl/*kernel_stats.csv 2>/dev/null | head -1)
+    [ -n "$f" ] && cp "$f" ${O}_${wl}_kernel_stats.csv && head -7 ${O}_${wl}_kernel_stats.csv | cut -c1-150
+    rm -rf gpurun_out/prof_${tag}_$wl
+  done
+fi
+if has pmc; then
+  bash tools/pmc_kernels.sh $tag
+fi
+if has cfg4; then
+  timeout 600 python bench.py --workload cfg4 --steps 3 --warmup 1 --settle-s 1 > ${O}_cfg4.json 2> ${O}_cfg4.log; echo "cfg4 rc=$?"; cut -c1-1200 ${O}_cfg4.json
+  timeout 300 python bench.py --workload cfg4 --pairs-total 128 --homography-strength 0.05 --steps 3 --warmup 1 --settle-s 0.5 > ${O}_cfg4_mild.json 2> ${O}_cfg4_mild.log; cut -c1-400 ${O}_cfg4_mild.json
+fi
+if has two; then      # the N>1 code path on one device (gloo carries the collective): correctness of the plumbing only
+  LINETR_BENCH_ONE_DEVICE=1 LINETR_BENCH_BACKEND=gloo timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+    --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --settle-s 0.5 > ${O}_two_ranks.json 2> ${O}_two_ranks.log
+  echo "two rc=$?"; cut -c1-600 ${O}_two_ranks.json; tail -3 ${O}_two_ranks.log
+  LINETR_BENCH_ONE_DEVICE=1 LINETR_BENCH_BACKEND=gloo timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+    --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --workload cfg4 --pairs-total 64 --pairs 16 --steps 2 --warmup 1 --settle-s 0.3 \
+    > ${O}_two_ranks_cfg4.json 2> ${O}_two_ranks_cfg4.log
+  echo "two cfg4 rc=$?"; cut -c1-600 ${O}_two_ranks_cfg4.json; tail -3 ${O}_two_ranks_cfg4.log
+fi
