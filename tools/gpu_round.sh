@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 O=gpurun_out/$tag
 has() { [[ " $stages " == *" $1 "* ]]; }
 if has tests; then
-  timeout 900 python -m pytest tests -m gpu -x -q > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -4 ${O}_pytest.log
+  timeout 900 python -m pytest tests -m gpu -q --maxfail=12 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -4 ${O}_pytest.log
 fi
 if has bench; then
   timeout 600 python bench.py --steps 20 --warmup 5 > ${O}_bench.json 2> ${O}_bench.log; echo "bench rc=$?"; cut -c1-900 ${O}_bench.json
