@@ -90,7 +90,6 @@ class Pipeline:
         self.n_streams = n_streams
         self.layout = layout
         self.n_img_cap = 2 * pairs
-        self.rows_cap = sum(len(l) for l in lines)
         self.packed = [None, None]      # double-buffered: the all-gather of step i overlaps the compute of step i+1
         self.pending = [None, None]
         self.slot = 0
@@ -98,6 +97,9 @@ class Pipeline:
         self.offsets = np.zeros(len(lines) + 1, dtype=np.int32)
         np.cumsum([len(l) for l in lines], out=self.offsets[1:])
         self.cat = np.ascontiguousarray(np.concatenate(lines), dtype=np.float64)
+        # rows of the all-gather slab: the batch's sub-line count (a long line has several sub-lines), known from the
+        # host pre-filter alone
+        self.rows_cap = max(int(self.prefilter_only()[2][-1]), 1)
 
     def prefilter_only(self):
         e, c = self.eng, LINE_CFG
@@ -657,6 +659,10 @@ def main():
     lines, dd_nchw, dd_nhwc, ds, hw, T = make_inputs(args.workload, pairs, rank, device, eng)
     feed = dd_nhwc if args.dense_layout == "nhwc" else dd_nchw
     pipe = Pipeline(eng, lines, feed, ds, hw, T, world, pairs, args.streams, args.dense_layout)
+    if world > 1:     # every rank's slab must have the same height: the largest sub-line count of any rank
+        t = torch.tensor([pipe.rows_cap], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        pipe.rows_cap = int(t.item())
 
     def barrier():
         pipe.drain()

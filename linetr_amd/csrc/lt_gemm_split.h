@@ -83,6 +83,7 @@ struct SplitGemmArgs {
   GemmArgs g;                 // g.W unused
   const unsigned char* Wsp;   // split weights
   int64_t gWsp;               // bytes between groups
+  int wide_epi = 0;           // epilogue through LDS with dwordx4 row stores (set by gemm_split_launch_t)
 };
 
 template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0, int PFD = 1, bool PIPE = false>
@@ -412,6 +413,55 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
 
   const float* bias = g.bias ? g.bias + grp * g.gBias : nullptr;
   float* Y = g.Y + grp * g.gY;
+  if (sa.wide_epi) {
+    // Epilogue through LDS: the 32x32 C/D layout gives a lane ONE column and 16 rows, so direct stores are 64 dword
+    // stores per lane (512 wave-instructions of 256 B per 128x256 block) and the block ends on a store-ISSUE-bound tail
+    // about as long as the main loop of a K = 256 GEMM.  Instead every wave parks its TM x TN accumulator tile in its own
+    // LDS region (row stride TN floats: the 32-lane halves of ds_write_b32 and the 16-lane groups of ds_read_b128 both
+    // hit distinct banks) and writes it out as dwordx4 rows: 16 store instructions per lane, 1 KiB each; the residual
+    // comes in the same way.  Wave-private regions: one block barrier (the tile buffers are dead), none inside.
+    constexpr int LPR = TN / 4;           // lanes per output row
+    constexpr int RPI = 64 / LPR;         // rows per wave-instruction
+    constexpr int NIT = TM / RPI;
+    __syncthreads();
+    float* ep = reinterpret_cast<float*>(smem_s) + wave * (TM * TN);
+    const int er = lane / LPR, ec = (lane % LPR) * 4;
+    const int grow0 = m0 + wm * TM + er, gcol = n0 + wn * TN + ec;
+    f32x4 rres[NIT];
+    if (g.R) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = grow0 + it * RPI;
+        rres[it] = row < g.M ? *reinterpret_cast<const f32x4*>(g.R + (int64_t)row * g.ldr + gcol) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const float bv = bias ? bias[n0 + wn * TN + j * 32 + (lane & 31)] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bv;
+          if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (g.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+          else if (g.act == ACT_DIST) v = fmaxf(2.f - 2.f * v, 0.f);
+          ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TN + j * 32 + (lane & 31)] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = grow0 + it * RPI;
+      f32x4 v = *reinterpret_cast<const f32x4*>(ep + (er + it * RPI) * TN + ec);
+      if (g.R) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] += rres[it][c];
+      }
+      if (row < g.M) *reinterpret_cast<f32x4*>(Y + (int64_t)row * g.ldy + gcol) = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int col = n0 + wn * TN + j * 32 + (lane & 31);
@@ -436,7 +486,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
 
 template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0, int PFD = 1, bool PIPE = false>
 inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t st) {
-  constexpr size_t lds = (size_t)(DB ? 2 : 1) * (BM + BN) * (PL * 64 + 16);
+  constexpr size_t lds_main = (size_t)(DB ? 2 : 1) * (BM + BN) * (PL * 64 + 16);
+  constexpr size_t lds_epi = (size_t)BM * BN * sizeof(float);    // every wave's TM x TN accumulator tile
+  constexpr bool epi_fits = lds_epi <= 160 * 1024;
+  constexpr size_t lds = (epi_fits && lds_epi > lds_main) ? lds_epi : lds_main;
+  static const bool narrow = getenv("LINETR_GEMM_NARROW_EPI") != nullptr;   // tuning aid: direct dword stores
+  SplitGemmArgs sa2 = sa;
+  // the LDS epilogue needs 16-byte aligned rows (ldy / ldr multiples of 4 floats; the entry points guarantee it for
+  // their own buffers, debug_gemm checks it)
+  sa2.wide_epi = !narrow && sa.g.ldy % 4 == 0 && (!sa.g.R || sa.g.ldr % 4 == 0) && epi_fits;
   static unsigned long long attr_done = 0;   // one bit per device: the opt-in is a per-device function attribute
   const unsigned long long dev_bit = current_device_bit();
   if (!(attr_done & dev_bit)) {
@@ -445,7 +503,7 @@ inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t
     attr_done |= dev_bit;
   }
   dim3 grid((sa.g.N / BN) * cdiv(sa.g.M, BM), groups);
-  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT, PFD, PIPE>), grid, dim3(WM * WN * 64), lds, st, sa);
+  hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT, PFD, PIPE>), grid, dim3(WM * WN * 64), lds, st, sa2);
 }
 
 template <int PL, int FMT>

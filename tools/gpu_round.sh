@@ -21,6 +21,30 @@ for k, v in sorted(d["kernels"].items(), key=lambda kv: -kv[1]["ms"])[:24]:
     print(f"{v['ms']:8.4f} ms x{v['calls']:3d} {v['tflops']}  {k}")
 PY
 fi
+if has hostprof; then   # where the host side of a cfg3 step goes (cProfile over 30 steps)
+  timeout 300 python - > ${O}_hostprof.txt 2>&1 <<'PY'
+import cProfile, pstats, sys, torch
+sys.argv = ["bench.py"]
+import bench
+from linetr_amd import synth
+from linetr_amd.engine import Engine
+dev = torch.device("cuda:0")
+eng = Engine(synth.calibrated_state_dict(), dev, image_shape=[480, 640])
+lines, dd, nhwc, ds, hw, T = bench.make_inputs("cfg3", 64, 0, dev, eng)
+pipe = bench.Pipeline(eng, lines, nhwc, ds, hw, T, 1, 64)
+for _ in range(50):
+    pipe.step()
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(30):
+    pipe.step()
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+PY
+  grep -A30 "cumulative" ${O}_hostprof.txt | head -34
+fi
 if has prof; then     # rocprofv3 kernel stats, one run per workload
   for wl in cfg3 cfg2 cfg5; do
     timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$wl -o p -- \

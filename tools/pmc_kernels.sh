@@ -25,9 +25,11 @@ def load(name):
     for r in csv.DictReader(open(f[0])):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
-out = {"note": "averages per launch over one rocprofv3 --pmc pass of `bench.py --steps 2` (cfg3); mfma_busy = "
-               "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 4 SIMDs * 256 CUs); SQ_* wave counters are in quad-cycles "
-               "(MI355X_MICROARCH.md)", "kernels": {}}
+out = {"note": "averages per launch over one rocprofv3 --pmc pass of `bench.py --steps 2` (cfg3).  mfma_busy = "
+               "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8): SQ_VALU_MFMA_BUSY_CYCLES is summed over all "
+               "SIMDs (= 32 cycles x the number of 32x32x16 MFMAs, checked against the GEMM's 6*2MNK flops) and "
+               "GRBM_GUI_ACTIVE over the 8 XCDs (GRBM_GUI_ACTIVE / 8 / kernel duration = 2.2 GHz).  SQ_WAVE_CYCLES and the "
+               "SQ_WAIT_* / SQ_ACTIVE_* counters are in quad-cycles (MI355X_MICROARCH.md)", "kernels": {}}
 for name in ("sq", "sq2"):
     for k, cs in load(name).items():
         rec = out["kernels"].setdefault(k, {})
@@ -36,7 +38,8 @@ for name in ("sq", "sq2"):
         rec["launches"] = max(rec.get("launches", 0), max(len(v) for v in cs.values()))
 for k, rec in out["kernels"].items():
     if rec.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in rec:
-        rec["mfma_busy"] = round(rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (rec["GRBM_GUI_ACTIVE"] * 1024.0), 4)
+        rec["mfma_busy"] = round(rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (rec["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
+        rec["cycles_per_xcd"] = rec["GRBM_GUI_ACTIVE"] / 8.0
     if rec.get("SQ_WAVE_CYCLES"):
         for c in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):
             if c in rec:
