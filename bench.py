@@ -768,6 +768,7 @@ def main():
                    "collective": "all_gather(line_desc + counts + key-line maps)" if world > 1 else "none"},
         "ms_per_step_median": round(float(np.median(per_step)), 4), "ms_per_step_p10": round(float(np.percentile(per_step, 10)), 4),
         "ms_per_step_p90": round(float(np.percentile(per_step, 90)), 4),
+        "ms_per_step_each": [round(float(v), 3) for v in per_step],
         "host_ms_per_step": round(float(np.mean(host_ms)), 4), "host_prefilter_ms": round(host_prefilter_ms, 4),
         "settle": {"seconds_min": args.settle_s, "windows": len(settle_hist), "first_ms": round(settle_hist[0], 4),
                    "last3_ms": [round(v, 4) for v in settle_hist[-3:]]},

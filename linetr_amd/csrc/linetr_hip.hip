@@ -964,9 +964,11 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
         ProfScope ps(h, st, "sig_attn_bf16x6", fl, (double)N * D * 16);
         static const bool attn4 = getenv("LINETR_ATTN_4WAVE") != nullptr;   // tuning aid: 128-query blocks
         // few (image, head) pairs: 64-query blocks, so that a single pair still spreads over 32 CUs instead of 8
-        if (!attn4 && (int64_t)n_images * HEADS * cdiv(max_n, 256) < 64)
-          hipLaunchKernelGGL(sig_attn_split_kernel<2>, dim3(n_images, HEADS, cdiv(max_n, 64)), dim3(128), 0, st, w.qkv, cu_dev,
-                             w.msgp);
+        static const bool no_small_attn = getenv("LINETR_NO_SMALL_ATTN") != nullptr;   // tuning aid
+        // few (image, head) pairs: 32-query blocks whose 4 waves also split the KV range (a single pair spreads over 56 CUs
+        // and the critical path is 2 KV chunks instead of 7)
+        if (!attn4 && !no_small_attn && (int64_t)n_images * HEADS * cdiv(max_n, 256) < 64)
+          hipLaunchKernelGGL(sig_attn_small_kernel, dim3(n_images, HEADS, cdiv(max_n, 32)), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
         else if (attn4 || max_n <= 128)
           hipLaunchKernelGGL(sig_attn_split_kernel<4>, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
         else
@@ -1233,9 +1235,15 @@ extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* 
   if (!dims || !off_n0 || !off_n1 || !off_dk || !off_k0 || !d_ws) return fail(LINETR_E_ARG, "match: null argument");
   hipStream_t st = (hipStream_t)stream;
   if (h) LT_HIP(hipSetDevice(h->device));
-  int slot = 0;
-  PairDesc* pd = (PairDesc*)staging_ring().acquire((size_t)P * sizeof(PairDesc), &slot);
-  if (!pd) return fail(LINETR_E_HIP, "match: pinned staging allocation failed");
+  PairTable tab{};
+  int slot = -1;
+  PairDesc* pd = tab.inl;
+  if (P > PT_INLINE) {
+    pd = (PairDesc*)staging_ring().acquire((size_t)P * sizeof(PairDesc), &slot);
+    if (!pd) return fail(LINETR_E_HIP, "match: pinned staging allocation failed");
+  } else {
+    tab.n_inline = P;
+  }
   int64_t od = 0, os = 0, sum_k = 0;
   int max_n0 = 0, max_n1 = 0, max_k1 = 0, max_chunks = 0;
   double flops = 0;
@@ -1262,12 +1270,15 @@ extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* 
   PairDesc* d_pd = (PairDesc*)base;
   float* d_dist = (float*)(base + align_up((int64_t)P * sizeof(PairDesc), 256));
   int* d_scr = (int*)((char*)d_dist + align_up(od * 4, 256));
-  LT_HIP(hipMemcpyAsync(d_pd, pd, P * sizeof(PairDesc), hipMemcpyHostToDevice, st));
-  if (int e = staging_ring().commit(slot, st)) return e;
+  if (slot >= 0) {
+    LT_HIP(hipMemcpyAsync(d_pd, pd, P * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+    if (int e = staging_ring().commit(slot, st)) return e;
+    tab.ptr = d_pd;
+  }
   if (max_n0 > 0 && max_n1 > 0) {
     if (!d_desc0 || !d_desc1 || !d_s2l0 || !d_s2l1 || !d_dk) return fail(LINETR_E_ARG, "match: null tensor");
     ProfScope ps(h, st, "pair_dist", flops, 0);
-    hipLaunchKernelGGL(pair_dist_kernel, dim3(cdiv(max_n1, 64), cdiv(max_n0, 64), P), dim3(256), 0, st, d_pd, d_desc0,
+    hipLaunchKernelGGL(pair_dist_kernel, dim3(cdiv(max_n1, 64), cdiv(max_n0, 64), P), dim3(256), 0, st, tab, d_desc0,
                        d_desc1, d_dist);
     LT_LAUNCH_CHECK();
   }
@@ -1275,13 +1286,13 @@ extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* 
     ProfScope ps(h, st, "pair_match", 0, 0);
     if (max_k1 > 0) {
       hipLaunchKernelGGL(pair_pool_kernel, dim3(max_chunks, P), dim3(256), (size_t)(max_k1 + PM_ROWS + 2) * sizeof(int), st,
-                         d_pd, d_s2l0, d_s2l1, d_dist, d_dk, d_scr);
+                         tab, d_s2l0, d_s2l1, d_dist, d_dk, d_scr);
       LT_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(pair_final_kernel, dim3(P), dim3(256), 0, st, d_pd, thr, mutual, d_match01, d_scr);
+    hipLaunchKernelGGL(pair_final_kernel, dim3(P), dim3(256), 0, st, tab, thr, mutual, d_match01, d_scr);
     LT_LAUNCH_CHECK();
   }
-  return LINETR_OK;   // fully asynchronous: the PairDesc table was staged in pinned memory owned by the ring
+  return LINETR_OK;   // fully asynchronous: the pair table travels in the kernel arguments or in ring-owned pinned memory
 }
 
 extern "C" int linetr_match_points(LinetrHandle* h, const float* d0_cn, int32_t n0, const float* d1_cn, int32_t n1,
@@ -1342,26 +1353,24 @@ extern "C" int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_
   char* base = (char*)d_ws;
   const int m = std::max(n0, n1);
   int slot = 0;
-  char* host = (char*)staging_ring().acquire(256 + (size_t)m * sizeof(int), &slot);
-  if (!host) return fail(LINETR_E_HIP, "match_distmat: pinned staging allocation failed");
-  PairDesc* pd = (PairDesc*)host;
-  *pd = PairDesc{};
+  int* iota = (int*)staging_ring().acquire((size_t)m * sizeof(int), &slot);
+  if (!iota) return fail(LINETR_E_HIP, "match_distmat: pinned staging allocation failed");
+  PairTable tab{};
+  tab.n_inline = 1;
+  PairDesc* pd = tab.inl;
   pd->n0 = pd->k0 = n0; pd->n1 = pd->k1 = n1;
   pd->chunks = cdiv(n0, PM_ROWS);
-  int* iota = (int*)(host + 256);
   std::iota(iota, iota + m, 0);
-  LT_HIP(hipMemcpyAsync(base, pd, sizeof(PairDesc), hipMemcpyHostToDevice, st));
   LT_HIP(hipMemcpyAsync(base + o_id0, iota, n0 * 4, hipMemcpyHostToDevice, st));
   if (n1 > 0) LT_HIP(hipMemcpyAsync(base + o_id1, iota, n1 * 4, hipMemcpyHostToDevice, st));
   if (int e = staging_ring().commit(slot, st)) return e;
   if (n1 > 0) {
-    hipLaunchKernelGGL(pair_pool_kernel, dim3(pd->chunks, 1), dim3(256), (size_t)(n1 + PM_ROWS + 2) * sizeof(int), st,
-                       (const PairDesc*)base, (const int*)(base + o_id0), (const int*)(base + o_id1), d_dist,
-                       (float*)(base + o_dk), (int*)(base + o_scr));
+    hipLaunchKernelGGL(pair_pool_kernel, dim3(pd->chunks, 1), dim3(256), (size_t)(n1 + PM_ROWS + 2) * sizeof(int), st, tab,
+                       (const int*)(base + o_id0), (const int*)(base + o_id1), d_dist, (float*)(base + o_dk),
+                       (int*)(base + o_scr));
     LT_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(pair_final_kernel, dim3(1), dim3(256), 0, st, (const PairDesc*)base, thr, mutual, d_match01,
-                     (int*)(base + o_scr));
+  hipLaunchKernelGGL(pair_final_kernel, dim3(1), dim3(256), 0, st, tab, thr, mutual, d_match01, (int*)(base + o_scr));
   LT_LAUNCH_CHECK();
   return LINETR_OK;
 }

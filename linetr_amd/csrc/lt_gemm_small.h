@@ -5,9 +5,11 @@
 // LDS with a block barrier per 32-wide K tile -- ~0.9 us per K tile of pure latency, 14 us per GEMM, 28 GEMMs per
 // forward.  Here nothing is staged and nothing is synchronised inside the main loop:
 //   * one block = one 32 x 32 output tile, so a 400 x 512 GEMM still launches 208 blocks;
-//   * the block's 4 waves split K four ways; every lane fetches its MFMA fragments straight from global memory
-//     (activations: 2 x dwordx4 of fp32 per 16-wide K step, split into planes in registers; weights: one 16-byte
-//     piece per plane of the pre-split image [N][K/32][PL][32]) with up to 4 K tiles (40 loads) in flight per wave;
+//   * the block's 4 waves split K four ways; every wave stages its own K tiles through a WAVE-PRIVATE LDS region:
+//     coalesced global loads (a K tile of an activation row is one 128-byte line, of a weight row PL*64 contiguous
+//     bytes; fetching MFMA fragments straight from global memory made every lane its own cache line and the address
+//     unit the bottleneck), up to 4 K tiles (40 loads) in flight per wave in registers, then ds_write -> ds_read of the
+//     fragments -> split -> MFMAs with no block barrier, because the LDS executes one wave's instructions in order;
 //   * the four partial 32 x 32 accumulators are summed through LDS in a FIXED order (deterministic) and the epilogue
 //     (bias / activation / residual) writes float4 rows.
 // A tiles are re-read N/32 times and W tiles M/32 times, all from L2 -- fine for the small problems this kernel is
@@ -20,6 +22,12 @@ namespace lt {
 template <int PL, int FMT>
 __global__ __launch_bounds__(256) void gemm_split_small_kernel(SplitGemmArgs sa) {
   const GemmArgs& g = sa.g;
+  constexpr int RS = PL * 64 + 16;                 // W row stride in LDS (bytes), as in gemm_split_kernel
+  constexpr int AS = 36;                           // A row stride in LDS (floats): 4 * odd -> conflict-free ds_read_b128
+  constexpr int A_BYTES = 32 * AS * 4, W_BYTES = 32 * RS;
+  constexpr int W_PCS = PL * 4;                    // 16-byte pieces per W row and K tile
+  constexpr int W_LD = (32 * W_PCS + 63) / 64;     // W load instructions per K tile
+  __shared__ __attribute__((aligned(16))) unsigned char stage[4][2][A_BYTES + W_BYTES];   // [wave][buffer]
   __shared__ float red[4][32 * 33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gx = g.N / 32;
@@ -32,53 +40,77 @@ __global__ __launch_bounds__(256) void gemm_split_small_kernel(SplitGemmArgs sa)
   const int nk = g.K / 32;
   const int kt0 = nk * wave / 4, kt1 = nk * (wave + 1) / 4;   // this wave's K tiles
 
+  // global loads, coalesced: A rows as 8 lanes x 16 B (a K tile of a row is one 128-byte line), W rows as W_PCS lanes x 16 B
+  const int a_r = lane >> 3, a_c = (lane & 7) * 4;
+  int64_t a_off[4], a2_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int r = m0 + a_r + 8 * i;
+    r = r < g.M ? r : g.M - 1;
+    a_off[i] = (int64_t)r * g.lda + a_c;
+    a2_off[i] = (int64_t)r * g.lda2 + a_c;
+  }
+  int64_t w_off[W_LD];
+  int w_lds[W_LD];
+#pragma unroll
+  for (int i = 0; i < W_LD; ++i) {
+    int q = lane + 64 * i;
+    q = q < 32 * W_PCS ? q : 32 * W_PCS - 1;       // PL = 3: the last instruction is half empty, lanes repeat the last piece
+    const int r = q / W_PCS, pc = q % W_PCS;
+    w_off[i] = (int64_t)(n0 + r) * nk * (PL * 64) + pc * 16;
+    w_lds[i] = r * RS + pc * 16;
+  }
+  // fragment reads: lane = (row lane & 31, K half lane >> 5)
   const int frow = lane & 31, half = lane >> 5;
-  int arow = m0 + frow;
-  arow = arow < g.M ? arow : g.M - 1;
-  const float* a_row = A + (int64_t)arow * g.lda;
-  const float* a2_row = A2 ? A2 + (int64_t)arow * g.lda2 : nullptr;
-  const unsigned char* w_row = Wsp + (int64_t)(n0 + frow) * nk * (PL * 64) + half * 16;
 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  constexpr int GRP = 4;                       // K tiles in flight per wave
+  constexpr int GRP = 4;                           // K tiles in flight per wave (registers)
   for (int kt = kt0; kt < kt1; kt += GRP) {
-    f32x4 ra[GRP][2][2];                       // [tile][step][low/high 4 floats of this lane's 8]
-    f32x4 rw[GRP][2][PL];
+    f32x4 ra[GRP][4], rw[GRP][W_LD];
 #pragma unroll
     for (int u = 0; u < GRP; ++u) {
-      if (kt + u < kt1) {                      // wave-uniform
+      if (kt + u < kt1) {                          // wave-uniform
         const int k0 = (kt + u) * 32;
-        const float* src = k0 < K1 ? a_row + k0 : a2_row + (k0 - K1);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          ra[u][s][0] = *reinterpret_cast<const f32x4*>(src + s * 16 + half * 8);
-          ra[u][s][1] = *reinterpret_cast<const f32x4*>(src + s * 16 + half * 8 + 4);
+        for (int i = 0; i < 4; ++i)
+          ra[u][i] = k0 < K1 ? *reinterpret_cast<const f32x4*>(A + a_off[i] + k0)
+                             : *reinterpret_cast<const f32x4*>(A2 + a2_off[i] + (k0 - K1));
 #pragma unroll
-          for (int p = 0; p < PL; ++p)
-            rw[u][s][p] = *reinterpret_cast<const f32x4*>(w_row + (int64_t)(kt + u) * (PL * 64) + p * 64 + s * 32);
-        }
+        for (int i = 0; i < W_LD; ++i)
+          rw[u][i] = *reinterpret_cast<const f32x4*>(Wsp + w_off[i] + (int64_t)(kt + u) * (PL * 64));
       }
     }
 #pragma unroll
     for (int u = 0; u < GRP; ++u) {
       if (kt + u < kt1) {
+        // wave-private staging (no block barrier: the LDS executes one wave's instructions in order); two buffers so the
+        // stores of tile u+1 do not wait behind the fragment reads of tile u
+        unsigned char* As = stage[wave][u & 1];
+        unsigned char* Ws = As + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(As + ((a_r + 8 * i) * AS + a_c) * 4) = ra[u][i];
+#pragma unroll
+        for (int i = 0; i < W_LD; ++i) *reinterpret_cast<f32x4*>(Ws + w_lds[i]) = rw[u][i];
+        __builtin_amdgcn_wave_barrier();           // compiler-only: the fragment reads below see other lanes' stores
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(As + (frow * AS + s * 16 + half * 8) * 4);
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(As + (frow * AS + s * 16 + half * 8 + 4) * 4);
           unsigned a[PL], b[PL], c[PL], d[PL];
-          split_pair<PL, FMT>(ra[u][s][0][0], ra[u][s][0][1], a);
-          split_pair<PL, FMT>(ra[u][s][0][2], ra[u][s][0][3], b);
-          split_pair<PL, FMT>(ra[u][s][1][0], ra[u][s][1][1], c);
-          split_pair<PL, FMT>(ra[u][s][1][2], ra[u][s][1][3], d);
+          split_pair<PL, FMT>(x0[0], x0[1], a);
+          split_pair<PL, FMT>(x0[2], x0[3], b);
+          split_pair<PL, FMT>(x1[0], x1[1], c);
+          split_pair<PL, FMT>(x1[2], x1[3], d);
           bf16x8 af[PL], bf[PL];
 #pragma unroll
           for (int p = 0; p < PL; ++p) {
             union { bf16x8 v; unsigned w[4]; } x;
             x.w[0] = a[p]; x.w[1] = b[p]; x.w[2] = c[p]; x.w[3] = d[p];
             af[p] = x.v;
-            bf[p] = __builtin_bit_cast(bf16x8, rw[u][s][p]);
+            bf[p] = *reinterpret_cast<const bf16x8*>(Ws + frow * RS + p * 64 + s * 32 + half * 16);
           }
           // cross terms with pa + pb <= PL-1, smallest first (same order as gemm_split_kernel)
 #pragma unroll

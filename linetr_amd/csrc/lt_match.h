@@ -18,18 +18,28 @@ struct PairDesc {          // one image pair (device copy lives in the workspace
   int32_t pad_;
 };
 
+// Pair table handed to the matcher kernels: up to PT_INLINE descriptors travel inside the kernel arguments (no H2D copy
+// on the latency path of a single pair), larger batches through a device array.
+constexpr int PT_INLINE = 8;
+struct PairTable {
+  const PairDesc* ptr;
+  int n_inline;
+  PairDesc inl[PT_INLINE];
+  __device__ __forceinline__ PairDesc get(int i) const { return n_inline ? inl[i] : ptr[i]; }
+};
+
 constexpr int PM_ROWS = 8;          // key-line rows of Dk per block of pair_pool_kernel
 constexpr int PM_MAX_K1 = 12000;    // seg1 table of a pair must fit the block's LDS (48 KB)
 
 // D[a][b] = max(2 - 2 * <d0[a], d1[b]>, 0), fp32 MFMA, 64x64 tile per block, K = 256.
 // grid (tiles_b, tiles_a, pair)
-__global__ __launch_bounds__(256) void pair_dist_kernel(const PairDesc* __restrict__ pairs,
+__global__ __launch_bounds__(256) void pair_dist_kernel(const PairTable pairs,
                                                         const float* __restrict__ desc0,
                                                         const float* __restrict__ desc1, float* __restrict__ dist) {
   constexpr int LS = 36;
   __shared__ __attribute__((aligned(16))) float As[64 * LS];
   __shared__ __attribute__((aligned(16))) float Bs[64 * LS];
-  const PairDesc pd = pairs[blockIdx.z];
+  const PairDesc pd = pairs.get(blockIdx.z);
   const int a0 = blockIdx.y * 64, b0 = blockIdx.x * 64;
   if (a0 >= pd.n0 || b0 >= pd.n1) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -90,11 +100,11 @@ __device__ __forceinline__ int seg_lower_bound(const int* __restrict__ m, int n,
   return lo;
 }
 
-__global__ __launch_bounds__(256) void pair_pool_kernel(const PairDesc* __restrict__ pairs, const int* __restrict__ s2l0,
+__global__ __launch_bounds__(256) void pair_pool_kernel(const PairTable pairs, const int* __restrict__ s2l0,
                                                         const int* __restrict__ s2l1, const float* __restrict__ dist,
                                                         float* __restrict__ dk_out, int* __restrict__ scratch) {
   extern __shared__ int pm_lds[];                    // seg1[k1+1] | seg0[PM_ROWS+1]
-  const PairDesc pd = pairs[blockIdx.y];
+  const PairDesc pd = pairs.get(blockIdx.y);
   const int chunk = blockIdx.x;
   if (chunk >= pd.chunks || pd.k1 <= 0) return;
   const int tid = threadIdx.x;
@@ -159,9 +169,9 @@ __global__ __launch_bounds__(256) void pair_pool_kernel(const PairDesc* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void pair_final_kernel(const PairDesc* __restrict__ pairs, float thr, int mutual,
+__global__ __launch_bounds__(256) void pair_final_kernel(const PairTable pairs, float thr, int mutual,
                                                          int* __restrict__ match01, int* __restrict__ scratch) {
-  const PairDesc pd = pairs[blockIdx.x];
+  const PairDesc pd = pairs.get(blockIdx.x);
   const int tid = threadIdx.x;
   int* row_arg = scratch + pd.off_seg;
   const float* row_min = reinterpret_cast<const float*>(row_arg + pd.k0);

@@ -900,4 +900,205 @@ __global__ __launch_bounds__(NW * 64) void sig_attn_split_kernel(const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Latency form of sig_attn_split_kernel for a few images (single pair): the KV range is split across the block's 4 waves
+// as well.  grid (image, head, 32-query tile), 256 threads; wave w takes the 32-row KV chunks w, w+4, ... of its
+// (image, head), stages them in a WAVE-PRIVATE LDS region (no block barrier in the loop), runs the same split-bf16
+// QK^T / online softmax / PV as above, and the four partial (m, l, O) are merged through LDS at the end (exact: the
+// softmax is rescaled to the common maximum).  A single 2 x 199-line pair launches 56 blocks of 4 waves whose critical
+// path is 2 chunks, instead of 8 (or 32) blocks walking 7 chunks each.
+// ---------------------------------------------------------------------------------------------
+constexpr int ATL_RK = 3 * 128 + 16;   // K plane row stride (bytes): [kv][3][64 d]
+constexpr int ATL_RV = 3 * 64 + 8;     // V^T plane row stride (bytes): [d][3][32 kv]
+constexpr int ATL_WAVE_BYTES = 32 * ATL_RK + DH * ATL_RV;   // 12 800 + 12 800
+
+__global__ __launch_bounds__(256) void sig_attn_small_kernel(const float* __restrict__ qkv, const int* __restrict__ cu_sub,
+                                                             float* __restrict__ out /*[N][256] head-major*/) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * ATL_WAVE_BYTES];
+  const int img = blockIdx.x, head = blockIdx.y;
+  const int n0 = cu_sub[img], Ni = cu_sub[img + 1] - n0;
+  const int q0 = blockIdx.z * 32;
+  if (q0 >= Ni) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h2 = lane >> 5, lq = lane & 31;
+  const int q = q0 + lq;
+  const float* base = qkv + (int64_t)n0 * 768;
+  unsigned char* Ks = lds + wave * ATL_WAVE_BYTES;
+  unsigned char* Vt = Ks + 32 * ATL_RK;
+
+  bf16x8 qf[4][3];
+  {
+    const int qr = q < Ni ? q : Ni - 1;
+    const float* qp = base + (int64_t)qr * 768 + head * DH + h2 * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + s * 16);
+      f32x4 x1 = *reinterpret_cast<const f32x4*>(qp + s * 16 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x0[e] *= LOG2E; x1[e] *= LOG2E; }
+      unsigned a[3], b[3], c[3], d[3];
+      split_pair<3>(x0[0], x0[1], a); split_pair<3>(x0[2], x0[3], b);
+      split_pair<3>(x1[0], x1[1], c); split_pair<3>(x1[2], x1[3], d);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        union { bf16x8 v; unsigned w[4]; } u;
+        u.w[0] = a[p]; u.w[1] = b[p]; u.w[2] = c[p]; u.w[3] = d[p];
+        qf[s][p] = u.v;
+      }
+    }
+  }
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+
+  // staging of one 32-row chunk by one wave: 16 lanes x float4 per row, 4 rows per pass, 8 passes
+  const int srow = lane >> 4, sc4 = (lane & 15) * 4;
+  f32x4 kreg[8], vreg[8];
+  auto fetch = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kv = kv0 + srow + 4 * i;
+      kreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kv < Ni) {
+        const float* p = base + (int64_t)kv * 768 + head * DH + sc4;
+        kreg[i] = *reinterpret_cast<const f32x4*>(p + 256);
+        vreg[i] = *reinterpret_cast<const f32x4*>(p + 512);
+      }
+    }
+  };
+  if (wave * 32 < Ni) fetch(wave * 32);
+  for (int kv0 = wave * 32; kv0 < Ni; kv0 += 128) {       // wave-uniform trip count
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = srow + 4 * i;
+      unsigned a[3], b[3];
+      split_pair<3>(kreg[i][0], kreg[i][1], a);
+      split_pair<3>(kreg[i][2], kreg[i][3], b);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(Ks + r * ATL_RK + p * 128 + sc4 * 2) = u32x2{a[p], b[p]};
+      split_pair<3>(vreg[i][0], vreg[i][1], a);
+      split_pair<3>(vreg[i][2], vreg[i][3], b);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {  // transposed: element (kv=r, d=sc4+j) -> Vt[d][p][r]
+        unsigned short* col = reinterpret_cast<unsigned short*>(Vt + p * 64 + r * 2);
+        col[(sc4 + 0) * (ATL_RV / 2)] = (unsigned short)(a[p] & 0xffffu);
+        col[(sc4 + 1) * (ATL_RV / 2)] = (unsigned short)(a[p] >> 16);
+        col[(sc4 + 2) * (ATL_RV / 2)] = (unsigned short)(b[p] & 0xffffu);
+        col[(sc4 + 3) * (ATL_RV / 2)] = (unsigned short)(b[p] >> 16);
+      }
+    }
+    if (kv0 + 128 < Ni) fetch(kv0 + 128);
+    __builtin_amdgcn_wave_barrier();     // compiler-only: wave-private LDS, executed in order
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    const unsigned char* kp = Ks + lq * ATL_RK + h2 * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 ka[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ka[p] = *reinterpret_cast<const bf16x8*>(kp + p * 128 + s * 32);
+      st = mfma_split<0>(ka[2], qf[s][0], st);
+      st = mfma_split<0>(ka[1], qf[s][1], st);
+      st = mfma_split<0>(ka[0], qf[s][2], st);
+      st = mfma_split<0>(ka[1], qf[s][0], st);
+      st = mfma_split<0>(ka[0], qf[s][1], st);
+      st = mfma_split<0>(ka[0], qf[s][0], st);
+    }
+    if (kv0 + 32 > Ni) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kv0 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= Ni) st[r] = -INFINITY;
+    }
+    float mx = st[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
+    mx = xor32_max(mx);
+    const float m_new = fmaxf(m, mx);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - m_new); ps += st[r]; }
+    ps = xor32_sum(ps);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);   // m = -inf on the first chunk -> 0
+    l = l * alpha + ps;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    m = m_new;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8 pp[3];
+      {
+        unsigned w[4][3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_pair<3>(st[8 * t + 2 * e], st[8 * t + 2 * e + 1], w[e]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          union { bf16x8 v; unsigned u[4]; } x;
+          x.u[0] = w[0][p]; x.u[1] = w[1][p]; x.u[2] = w[2][p]; x.u[3] = w[3][p];
+          pp[p] = x.v;
+        }
+      }
+      const unsigned char* vp = Vt + lq * ATL_RV + (16 * t + 4 * h2) * 2;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        bf16x8 va[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(vp + dt * 32 * ATL_RV + p * 64);
+          const u32x2 hi = *reinterpret_cast<const u32x2*>(vp + dt * 32 * ATL_RV + p * 64 + 16);
+          union { bf16x8 v; unsigned u[4]; } x;
+          x.u[0] = lo[0]; x.u[1] = lo[1]; x.u[2] = hi[0]; x.u[3] = hi[1];
+          va[p] = x.v;
+        }
+        f32x16& o = dt == 0 ? o0 : o1;
+        o = mfma_split<0>(va[2], pp[0], o);
+        o = mfma_split<0>(va[1], pp[1], o);
+        o = mfma_split<0>(va[0], pp[2], o);
+        o = mfma_split<0>(va[1], pp[0], o);
+        o = mfma_split<0>(va[0], pp[1], o);
+        o = mfma_split<0>(va[0], pp[0], o);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- merge the four partial results: O = sum_w 2^(m_w - M) O_w / sum_w 2^(m_w - M) l_w
+  __syncthreads();                                   // all staging regions are dead
+  float* Op = reinterpret_cast<float*>(lds);         // [4][64 d][33]  (q padded to 33)
+  float* ML = Op + 4 * 64 * 33;                      // [4][2][32]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = (r & 3) + 8 * (r >> 2) + 4 * h2;
+    Op[(wave * 64 + d) * 33 + lq] = o0[r];
+    Op[(wave * 64 + d + 32) * 33 + lq] = o1[r];
+  }
+  if (h2 == 0) { ML[(wave * 2 + 0) * 32 + lq] = m; ML[(wave * 2 + 1) * 32 + lq] = l; }
+  __syncthreads();
+  const int oq = tid >> 3, od = (tid & 7) * 8;       // thread -> (query, 8 consecutive d)
+  if (q0 + oq < Ni) {
+    float mw[4], M = -INFINITY, L = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { mw[w] = ML[(w * 2) * 32 + oq]; M = fmaxf(M, mw[w]); }
+    float sc[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      sc[w] = mw[w] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mw[w] - M);   // a wave without any chunk contributes nothing
+      L += sc[w] * ML[(w * 2 + 1) * 32 + oq];
+    }
+    const float inv = 1.f / L;
+    float res[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) a += sc[w] * Op[(w * 64 + od + e) * 33 + oq];
+      res[e] = a * inv;
+    }
+    float* op = out + (int64_t)(n0 + q0 + oq) * D + head * DH + od;
+    *reinterpret_cast<f32x4*>(op) = f32x4{res[0], res[1], res[2], res[3]};
+    *reinterpret_cast<f32x4*>(op + 4) = f32x4{res[4], res[5], res[6], res[7]};
+  }
+}
+
 }  // namespace lt
