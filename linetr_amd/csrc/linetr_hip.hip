@@ -48,6 +48,7 @@ struct LinetrHandle {
   const float *Watt, *batt, *Wfc, *bfc, *ln1g, *ln1b, *Wf1, *bf1, *Wf2, *bf2, *ln2g, *ln2b;
   std::vector<SigLayer> sig;
   const float *Wfin, *bfin;
+  const float *Wfin2 = nullptr, *bfin2 = nullptr;   // final projection with the last signature layer's second MLP GEMM folded in
   // split-bf16 copies of every GEMM weight (2 and 3 planes), keyed by the fp32 pointer
   int precision = LINETR_PREC_BF16X6;
   unsigned char* split_arena = nullptr;
@@ -222,14 +223,27 @@ const char* gemm_class_name(const GemmArgs& g, int groups, const char* kind) {
   return it->second.c_str();
 }
 
+struct NormSpec {          // row normalisation that follows a [M,256] GEMM (see GemmArgs::norm)
+  int mode = 0;            // 1 LayerNorm, 2 L2
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  const float* add2 = nullptr;   // added after the normalisation, row stride 256
+  float eps = 0.f;
+};
+
 int run_gemm(LinetrHandle* h, hipStream_t st, const float* A, int lda, const float* A2, int lda2, int K1,
              const float* W, const float* bias, const float* R, int ldr, float* Y, int ldy, int M, int N,
-             int K, int act, int groups = 1, int64_t gA = 0, int64_t gW = 0, int64_t gBias = 0, int64_t gY = 0) {
+             int K, int act, int groups = 1, int64_t gA = 0, int64_t gW = 0, int64_t gBias = 0, int64_t gY = 0,
+             const NormSpec* fused_norm = nullptr) {
   GemmArgs g;
   g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.K1 = K1;
   g.W = W; g.ldw = K; g.bias = bias; g.R = R; g.ldr = ldr; g.Y = Y; g.ldy = ldy;
   g.M = M; g.N = N; g.K = K; g.act = act;
   g.gA = gA; g.gW = gW; g.gBias = gBias; g.gY = gY;
+  if (fused_norm) {
+    g.norm = fused_norm->mode; g.gamma = fused_norm->gamma; g.beta = fused_norm->beta;
+    g.add2 = fused_norm->add2; g.ldadd2 = D; g.eps = fused_norm->eps;
+  }
   const double fl = 2.0 * M * (double)N * K * groups;
   const double by = 4.0 * groups * ((double)M * K + (double)N * K + (double)M * N);
   if (h->precision == LINETR_PREC_F32) {
@@ -256,6 +270,28 @@ int run_gemm(LinetrHandle* h, hipStream_t st, const float* A, int lda, const flo
   sa.gWsp = gW * 6;
   ProfScope ps(h, st, gemm_class_name(g, groups, "gemm_bf16x6"), fl, by);
   return gemm_split_launch<3>(sa, groups, st);
+}
+
+// Y[M,256] = norm(epi(A W^T + bias) (+ R)) (+ add2).  The split-bf16 128x256 tile owns complete rows and normalises them
+// in its epilogue (one launch and one [M,256] round trip less); every other case runs the GEMM into `tmp` and then
+// row_norm_kernel.  Same arithmetic either way.
+int run_gemm_norm(LinetrHandle* h, hipStream_t st, const float* A, int lda, const float* A2, int lda2, int K1,
+                  const float* W, const float* bias, const float* R, float* tmp, float* Y, int M, int K,
+                  const NormSpec& ns) {
+  const bool no_fuse = getenv("LINETR_NO_FUSED_NORM") != nullptr;   // tuning / test aid (read per call)
+  bool fuse = !no_fuse && h->precision != LINETR_PREC_F32 && !getenv("LINETR_GEMM_TILE") && !getenv("LINETR_GEMM_NARROW_EPI");
+  if (fuse) {
+    GemmArgs g{};
+    g.M = M; g.N = D; g.K = K; g.lda = lda; g.ldy = D; g.ldr = D; g.R = R; g.A2 = A2; g.lda2 = lda2; g.K1 = K1;
+    fuse = strcmp(split_tile_name(g, 1, h->precision == LINETR_PREC_BF16X6 ? 3 : 2), "128x256") == 0;
+  }
+  if (fuse) return run_gemm(h, st, A, lda, A2, lda2, K1, W, bias, R, D, Y, D, M, D, K, ACT_NONE, 1, 0, 0, 0, 0, &ns);
+  if (int e = run_gemm(h, st, A, lda, A2, lda2, K1, W, bias, R, D, tmp, D, M, D, K, ACT_NONE)) return e;
+  ProfScope ps(h, st, "row_norm", 0, (double)M * D * (ns.add2 ? 12 : 8));
+  hipLaunchKernelGGL(row_norm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, tmp, M, ns.mode == 2 ? 1 : 0, ns.gamma, ns.beta,
+                     ns.add2, ns.eps, Y);
+  LT_LAUNCH_CHECK();
+  return 0;
 }
 
 // ---- float64 weight preparation ---------------------------------------------------------------
@@ -519,6 +555,28 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
     if (err) return err;
     place_w(&H->Wfin, to_d(W, D * D), D, D);
     place(&H->bfin, to_d(b, D));
+    if (cfg->n_sig_layers > 0) {
+      // x_out = z + W2 hid + b2 (line_transformer.py:180-183) and final_proj is linear (:245), so
+      //   final_proj(x_out) = [Wfin | Wfin W2] [z ; hid] + (Wfin b2 + bfin)          (float64, once)
+      const std::string p = "selfattn.layers." + std::to_string(cfg->n_sig_layers - 1) + ".";
+      const float* W2 = tm.get(p + "mlp.3.weight", 2 * D * D, err);
+      const float* b2 = tm.get(p + "mlp.3.bias", D, err);
+      if (err) return err;
+      std::vector<double> Wf((size_t)D * 3 * D), bf(D);
+      for (int o = 0; o < D; ++o) {
+        for (int i = 0; i < D; ++i) Wf[(size_t)o * 3 * D + i] = W[o * D + i];
+        for (int j = 0; j < 2 * D; ++j) {
+          double sacc = 0.0;
+          for (int m = 0; m < D; ++m) sacc += (double)W[o * D + m] * (double)W2[(size_t)m * 2 * D + j];
+          Wf[(size_t)o * 3 * D + D + j] = sacc;
+        }
+        double bacc = b[o];
+        for (int m = 0; m < D; ++m) bacc += (double)W[o * D + m] * (double)b2[m];
+        bf[o] = bacc;
+      }
+      place_w(&H->Wfin2, Wf, D, 3 * D);
+      place(&H->bfin2, bf);
+    }
   }
 
   LT_HIP(hipMalloc((void**)&H->arena, ar.host.size() * sizeof(float)));
@@ -931,20 +989,15 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   }
   if ((e = run_gemm(h, st, w.pooled, HEADS * POOLW, nullptr, 0, 0, h->Watt, h->batt, nullptr, 0, w.att, D, N, DH, POOLW,
                     ACT_NONE, HEADS, POOLW, (int64_t)DH * POOLW, DH, DH))) return e;
-  if ((e = run_gemm(h, st, w.att, D, nullptr, 0, 0, h->Wfc, h->bfc, nullptr, 0, w.fc, D, N, D, D, ACT_NONE))) return e;
-  {
-    ProfScope ps(h, st, "row_norm", 0, (double)N * D * 8);
-    hipLaunchKernelGGL(row_norm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, w.fc, N, 0, h->ln1g, h->ln1b,
-                       (const float*)nullptr, 1e-6f, w.o);
-    LT_LAUNCH_CHECK();
+  {  // o = LN(fc(att) + cls)  (line_attention.py:36-40; the CLS residual sits in the bias)
+    NormSpec ns; ns.mode = 1; ns.gamma = h->ln1g; ns.beta = h->ln1b; ns.eps = 1e-6f;
+    if ((e = run_gemm_norm(h, st, w.att, D, nullptr, 0, 0, h->Wfc, h->bfc, nullptr, w.fc, w.o, N, D, ns))) return e;
   }
   if ((e = run_gemm(h, st, w.o, D, nullptr, 0, 0, h->Wf1, h->bf1, nullptr, 0, w.f1, c.d_inner, N, c.d_inner, D, ACT_GELU))) return e;
-  if ((e = run_gemm(h, st, w.f1, c.d_inner, nullptr, 0, 0, h->Wf2, h->bf2, w.o, D, w.f2, D, N, D, c.d_inner, ACT_NONE))) return e;
   if (ts.use_side) LT_HIP(hipStreamWaitEvent(st, h->ev_lpos, 0));
-  {  // sentence = line_pos + LN(ffn) (line_transformer.py:128)
-    ProfScope ps(h, st, "row_norm", 0, (double)N * D * 12);
-    hipLaunchKernelGGL(row_norm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, w.f2, N, 0, h->ln2g, h->ln2b, w.lpos, 1e-6f, w.zA);
-    LT_LAUNCH_CHECK();
+  {  // sentence = line_pos + LN(w_2(gelu(w_1 o)) + o)  (line_attention.py:79-83, line_transformer.py:128)
+    NormSpec ns; ns.mode = 1; ns.gamma = h->ln2g; ns.beta = h->ln2b; ns.add2 = w.lpos; ns.eps = 1e-6f;
+    if ((e = run_gemm_norm(h, st, w.f1, c.d_inner, nullptr, 0, 0, h->Wf2, h->bf2, w.o, w.f2, w.zA, N, c.d_inner, ns))) return e;
   }
   // ---- line signature network
   float *z = w.zA, *zn = w.zB;
@@ -978,15 +1031,16 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
       LT_LAUNCH_CHECK();
     }
     if ((e = run_gemm(h, st, z, D, w.msgp, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ACT_RELU))) return e;
+    if (l + 1 == h->sig.size()) break;   // the last layer's second MLP GEMM is folded into the final projection below
     if ((e = run_gemm(h, st, w.hid, 2 * D, nullptr, 0, 0, S.W2, S.b2, z, D, zn, D, N, D, 2 * D, ACT_NONE))) return e;
     std::swap(z, zn);
   }
-  if ((e = run_gemm(h, st, z, D, nullptr, 0, 0, h->Wfin, h->bfin, nullptr, 0, zn, D, N, D, D, ACT_NONE))) return e;
-  {
-    ProfScope ps(h, st, "row_norm", 0, (double)N * D * 8);
-    hipLaunchKernelGGL(row_norm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, zn, N, 1, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, 0.f, d_line_desc);
-    LT_LAUNCH_CHECK();
+  NormSpec l2; l2.mode = 2;      // F.normalize(final_proj(.), dim=1)  (line_transformer.py:245-246)
+  if (h->sig.empty()) {
+    if ((e = run_gemm_norm(h, st, z, D, nullptr, 0, 0, h->Wfin, h->bfin, nullptr, zn, d_line_desc, N, D, l2))) return e;
+  } else {
+    // final_proj(z + W2 hid + b2) = [Wfin | Wfin W2] [z ; hid] + (Wfin b2 + bfin): one K = 768 GEMM instead of two launches
+    if ((e = run_gemm_norm(h, st, z, D, w.hid, 2 * D, D, h->Wfin2, h->bfin2, nullptr, zn, d_line_desc, N, 3 * D, l2))) return e;
   }
   return LINETR_OK;
 }

@@ -31,6 +31,15 @@ struct GemmArgs {
   int act;
   // grouped launch (blockIdx.z = g): element strides added per group
   int64_t gA, gW, gBias, gY;
+  // optional row normalisation fused into the epilogue of tiles that own complete 256-wide rows (split-bf16 128x256
+  // tile only; run_gemm_norm falls back to row_norm_kernel otherwise).  Applied AFTER bias / activation / residual:
+  //   norm 1: LayerNorm(x) * gamma + beta (eps inside the sqrt), norm 2: x / max(||x||_2, 1e-12); then + add2.
+  int norm = 0;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  const float* add2 = nullptr;
+  int ldadd2 = 0;
+  float eps = 0.f;
 };
 
 constexpr int GEMM_BK = 32;

@@ -427,8 +427,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
     float* ep = reinterpret_cast<float*>(smem_s) + wave * (TM * TN);
     const int er = lane / LPR, ec = (lane % LPR) * 4;
     const int grow0 = m0 + wm * TM + er, gcol = n0 + wn * TN + ec;
+    const bool row_norm = BN == 256 && g.norm != 0;      // this tile owns complete rows (dispatcher guarantees N == 256)
     f32x4 rres[NIT];
-    if (g.R) {
+    if (g.R && !row_norm) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int row = grow0 + it * RPI;
@@ -448,6 +449,53 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
           else if (g.act == ACT_DIST) v = fmaxf(2.f - 2.f * v, 0.f);
           ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TN + j * 32 + (lane & 31)] = v;
         }
+      }
+    }
+    if constexpr (BN == 256) {
+      if (row_norm) {
+        // LayerNorm / L2 normalisation of whole rows (same arithmetic, in the same order, as row_norm_kernel): every wave
+        // takes BM / waves rows, a lane 4 consecutive columns; the row is gathered from the WN accumulator regions.
+        __syncthreads();
+        constexpr int RPW = BM / (WM * WN);
+        const float* epb = reinterpret_cast<const float*>(smem_s);
+        const int c0 = lane * 4, wn_c = c0 / TN, cc = c0 % TN;
+        for (int it = 0; it < RPW; ++it) {
+          const int rl = wave * RPW + it;
+          const int row = m0 + rl;
+          if (row >= g.M) break;                        // wave-uniform
+          f32x4 v = *reinterpret_cast<const f32x4*>(epb + ((rl / TM) * WN + wn_c) * (TM * TN) + (rl % TM) * TN + cc);
+          if (g.R) {
+            const f32x4 rr = *reinterpret_cast<const f32x4*>(g.R + (int64_t)row * g.ldr + c0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += rr[c];
+          }
+          f32x4 o;
+          if (g.norm == 1) {
+            const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256);
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float d = v[c] - mean; q += d * d; }
+            const float rstd = 1.f / sqrtf(wave_sum(q) * (1.f / 256) + g.eps);
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(g.gamma + c0);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(g.beta + c0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = (v[c] - mean) * rstd * ga[c] + be[c];
+          } else {
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q += v[c] * v[c];
+            const float nrm = fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = v[c] / nrm;
+          }
+          if (g.add2) {
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(g.add2 + (int64_t)row * g.ldadd2 + c0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] += a2[c];
+          }
+          *reinterpret_cast<f32x4*>(Y + (int64_t)row * g.ldy + c0) = o;
+        }
+        return;
       }
     }
 #pragma unroll

@@ -121,3 +121,17 @@ def test_precision_modes_agree(eng):
     assert (out["bf16x6"] - out["f32"]).abs().max().item() < 3e-6      # fp32-faithful
     assert (out["bf16x3"] - out["f32"]).abs().max().item() < 5e-5      # inside the 1e-4 budget
     assert (out["f16x3"] - out["f32"]).abs().max().item() < 6e-6       # fp32-class (2^-22 per product)
+
+
+def test_fused_row_norm_epilogue_equals_separate_kernel(eng, monkeypatch):
+    """cfg3 batch (25 472 rows: the 128x256 GEMM tile owns complete rows): LayerNorm x 2 and the final L2 normalisation
+    fused into the GEMM epilogues (lt_gemm_split.h) against the same GEMMs followed by row_norm_kernel
+    (LINETR_NO_FUSED_NORM=1).  Same arithmetic in the same order, so the descriptors agree to the last bits."""
+    _, cat, off, dd, ds = batch_inputs(128)
+    monkeypatch.delenv("LINETR_NO_FUSED_NORM", raising=False)
+    _, fused = describe(eng, cat, off, dd, ds)
+    monkeypatch.setenv("LINETR_NO_FUSED_NORM", "1")
+    _, plain = describe(eng, cat, off, dd, ds)
+    assert fused.shape == plain.shape and fused.shape[0] == 128 * 199
+    assert (fused - plain).abs().max().item() <= 2e-7
+    assert ((fused.norm(dim=1) - 1).abs() < 1e-5).all()

@@ -42,8 +42,20 @@ for _ in range(30):
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+# the single-pair call (cfg2): what the host does before / between the 44 launches
+lines, dd, nhwc, ds, hw, T = bench.make_inputs("cfg2", 1, 0, dev, eng)
+one = bench.Pipeline(eng, lines, nhwc, ds, hw, T, 1, 1)
+for _ in range(50):
+    one.step(); torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(100):
+    one.step(); torch.cuda.synchronize()
+pr.disable()
+print("==== cfg2, 100 synchronous steps")
+pstats.Stats(pr).sort_stats("tottime").print_stats(16)
 PY
-  grep -A30 "cumulative" ${O}_hostprof.txt | head -34
+  grep -A26 "==== cfg2" ${O}_hostprof.txt | cut -c1-150
 fi
 if has prof; then     # rocprofv3 kernel stats, one run per workload
   for wl in cfg3 cfg2 cfg5; do
