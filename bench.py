@@ -221,6 +221,10 @@ def timed_steps(step_fn, barrier_fn, steps, device):
     host time spent inside each step call."""
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     host = np.zeros(steps)
+    if os.environ.get("LINETR_BENCH_NOGC"):      # experiment: is the Python garbage collector behind the slow steps?
+        import gc
+        gc.collect()
+        gc.disable()
     barrier_fn()
     evs[0].record()
     t0 = time.perf_counter()
@@ -769,6 +773,7 @@ def main():
         "ms_per_step_median": round(float(np.median(per_step)), 4), "ms_per_step_p10": round(float(np.percentile(per_step, 10)), 4),
         "ms_per_step_p90": round(float(np.percentile(per_step, 90)), 4),
         "ms_per_step_each": [round(float(v), 3) for v in per_step],
+        "host_ms_each": [round(float(v), 3) for v in host_ms],
         "host_ms_per_step": round(float(np.mean(host_ms)), 4), "host_prefilter_ms": round(host_prefilter_ms, 4),
         "settle": {"seconds_min": args.settle_s, "windows": len(settle_hist), "first_ms": round(settle_hist[0], 4),
                    "last3_ms": [round(v, 4) for v in settle_hist[-3:]]},

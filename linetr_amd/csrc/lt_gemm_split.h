@@ -595,6 +595,7 @@ inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st
     else gemm_split_launch_t<256, 128, 4, 2, PL, true, FMT, 1, true>(sa, groups, st);
   }
   else if (!strcmp(tile, "128x256") && g.N % 256 == 0) gemm_split_launch_t<128, 256, 2, 4, PL, true, FMT, PL == 3 ? 2 : 1, true>(sa, groups, st);
+  else if (!strcmp(tile, "64x256") && g.N % 256 == 0) gemm_split_launch_t<64, 256, 1, 4, PL, true, FMT, PL == 3 ? 2 : 1, true>(sa, groups, st);
   else if (!strcmp(tile, "128x128")) gemm_split_launch_t<128, 128, 2, 2, PL, true, FMT>(sa, groups, st);
   else if (PL == 2 && !strcmp(tile, "256x256") && g.N % 256 == 0) gemm_split_launch_t<256, 256, 4, 2, 2, true, FMT>(sa, groups, st);
   else if (!strcmp(tile, "64x64")) gemm_split_launch_t<64, 64, 2, 2, PL, true, FMT, 4>(sa, groups, st);
