@@ -561,21 +561,24 @@ template <int PL, int FMT>
 inline void gemm_split_small_launch(const SplitGemmArgs& sa, int groups, hipStream_t st);   // lt_gemm_small.h (single-pair sizes)
 inline bool small_gemm_wins(const GemmArgs& g, int groups);
 
-// Tile choice: 8-wave 256x128 blocks (2 waves/SIMD inside one block, half the LDS staging per MFMA) once
-// there are enough of them to occupy most CUs; smaller tiles for small M so the grid still fills the chip.
+// Tile choice, from the measured table tools/gemm_tiles_probe.py prints (bf16x6, MI355X, profiles/r02_tiles_probe.txt):
+//   * 8-wave 128x256 blocks (fixed-order pipeline, one block per CU) as soon as there are ~140 of them: 9584x512x512 runs
+//     43 us on 150 such blocks against 64 us on 300 128x128 blocks;
+//   * below that the 4-wave 64x64 tile (53 KB of LDS: three blocks per CU, deep register prefetch) while its grid fits the
+//     768 resident slots, then 64x128 (two per CU, 512 slots), then 64x256;
+//   * single-pair sizes go to the barrier-free K-split kernel (lt_gemm_small.h).
 inline const char* split_tile_name(const GemmArgs& g, int groups, int pl = 3) {
   if (small_gemm_wins(g, groups)) return "32x32k4";   // latency-bound sizes: barrier-free K-split kernel
   if (g.N % 128 != 0) return "128x64";
-  const int64_t t256 = (int64_t)cdiv(g.M, 256) * (g.N / 128) * groups;
-  // same block size either way; 128x256 halves the A rows a block has to split per MFMA (+2-4 % measured)
   static const bool no112 = getenv("LINETR_NO_TILE112") != nullptr;   // tuning aid
   if (!no112 && pl == 2 && split16_wins(g, groups)) return "112x256";   // saves a round of blocks (lt_gemm_split16.h)
-  if (t256 >= 192) return g.N % 256 == 0 ? "128x256" : "256x128";
-  const int64_t t128 = (int64_t)cdiv(g.M, 128) * (g.N / 128) * groups;
-  if (t128 >= 256) return "128x128";
-  // small problems (single pair: M ~ 400): latency-bound -> more, smaller blocks with a deep register prefetch
-  const int64_t t64 = (int64_t)cdiv(g.M, 64) * (g.N / 128) * groups;
-  return t64 >= 96 ? "64x128" : "64x64";
+  const int64_t r128 = cdiv(g.M, 128), r64 = cdiv(g.M, 64);
+  if (g.N % 256 == 0 && r128 * (g.N / 256) * groups >= 140) return "128x256";
+  if (g.N % 256 != 0 && (int64_t)cdiv(g.M, 256) * (g.N / 128) * groups >= 192) return "256x128";
+  if (r64 * (g.N / 64) * groups <= 768) return "64x64";
+  if (r64 * (g.N / 128) * groups <= 512) return "64x128";
+  if (g.N % 256 == 0) return r64 * (g.N / 256) * groups >= 140 ? "64x256" : "64x128";
+  return "128x128";
 }
 
 template <int PL, int FMT = 0>

@@ -18,10 +18,12 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
     eng = Engine(synth.make_state_dict(0), "cuda:0")
     eng.set_precision(sys.argv[2])
     g = torch.Generator(device="cuda").manual_seed(1)
+    keep = []       # debug_gemm(cache_weights=True) keys its split copy by the weight POINTER: never let one be reused
     for M, N, K in SHAPES:
         A = torch.randn(M, K, device="cuda", generator=g)
         W = torch.randn(N, K, device="cuda", generator=g)
         R = torch.randn(M, N, device="cuda", generator=g)
+        keep.append(W)
         try:
             for _ in range(5):
                 eng.debug_gemm(A, W, None, R, 1, cache_weights=True)
