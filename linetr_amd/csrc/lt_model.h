@@ -710,23 +710,55 @@ __global__ __launch_bounds__(256) void sig_attn_kernel(const float* __restrict__
 // per 32-row kv chunk instead of 64 x 64.
 //   * Q fragments: split once into VGPRs (12 x bf16x8).
 //   * K tile in LDS as planes [kv][3][64 d] (row stride 400 B = 4*25 dwords -> conflict-free ds_read_b128).
-//   * V tile in LDS TRANSPOSED as planes [d][3][64 kv] (row stride 392 B = 2*49 dwords -> conflict-free b64):
-//     the PV B-operand P^T[kv][q] comes straight from the S^T accumulator registers (k-slot e of step t is
-//     register 8t+e, i.e. kv = 16t + 4*(lane>>5) + e for e<4 and +8 for e>=4), so the matching A operand
-//     V^T[d][kv] is two 4-element runs of one LDS row.
+//   * V tile in LDS row-major as planes [kv][3][64 d] like K (row stride 576 B); the PV B-operand P^T[kv][q] comes
+//     straight from the S^T accumulator registers (k-slot e of step t is register 8t+e, i.e.
+//     kv = 16t + 4*(lane>>5) + e for e<4 and +8 for e>=4), and the matching A operand V^T[d][kv] -- two runs of four kv
+//     for one d -- is fetched with gfx950's transposing LDS read (v_frags_tr), so staging V costs three 8-byte stores per
+//     thread instead of twelve 2-byte scatter stores into a transposed image.
 //   * softmax stays fp32 and in-lane as in sig_attn_kernel.
 // ---------------------------------------------------------------------------------------------
+#ifndef LT_ATTN_OCC2
+// 1: the 8-wave kernel is capped at 128 VGPRs so that TWO blocks share a CU (4 waves per SIMD) and fetches its K / V rows
+// right before staging them -- the second block covers the latency -- instead of carrying a register prefetch.
+// Measured at cfg3 (7 launches per step): 0.366 ms with one block per CU and the prefetch, 0.337 ms this way.
+#define LT_ATTN_OCC2 1
+#endif
 constexpr int ATS_RK = 3 * 128 + 16;   // K plane row stride (bytes)
-constexpr int ATS_RV = 3 * 128 + 8;    // V^T plane row stride (bytes)
+constexpr int ATS_RV = 576;            // V plane row stride (bytes): 144 dwords = 16 (mod 64), see below
+
+// Six transposing LDS reads (gfx950 ds_read_b64_tr_b16) = the V^T fragments of one 16-wide kv step and one 32-wide d
+// block: V stays ROW-major
+// in LDS ([kv][3 planes][64 d], staged with three 8-byte stores per thread like K) and the hardware hands lane
+// (d = lane & 31, half h) the four values V[kv0 + 4h + j][d], j = 0..3 -- exactly the k-slots the P^T accumulator
+// registers occupy (tools/ubench/tr_read_probe.hip prints the mapping).  Within a 16-lane group lane i addresses row
+// (i >> 2), 4-column chunk (i & 3); lanes 16-31 take the next 16 columns, the upper half-wave starts 4 rows down.
+// Bank check: a half-wave reads 4 rows x 64 bytes; with a row stride of 16 dwords (mod 64) the four rows land on four
+// disjoint quarters of the 64 banks.  `base` is the lane's byte address for kv0 = 0, plane 0, d block 0.
+// out[p][0/1] for d block DT: plane p, kv run KV0 + {0..3} / KV0 + 8 + {0..3}.
+template <int KV0, int DT>
+__device__ __forceinline__ void v_frags_tr(unsigned base, u32x2 (&o)[3][2]) {
+  constexpr int R0 = KV0 * ATS_RV + DT * 64, R1 = (KV0 + 8) * ATS_RV + DT * 64;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %6 offset:%7\n\t"
+      "ds_read_b64_tr_b16 %1, %6 offset:%8\n\t"
+      "ds_read_b64_tr_b16 %2, %6 offset:%9\n\t"
+      "ds_read_b64_tr_b16 %3, %6 offset:%10\n\t"
+      "ds_read_b64_tr_b16 %4, %6 offset:%11\n\t"
+      "ds_read_b64_tr_b16 %5, %6 offset:%12\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0][0]), "=&v"(o[0][1]), "=&v"(o[1][0]), "=&v"(o[1][1]), "=&v"(o[2][0]), "=&v"(o[2][1])
+      : "v"(base), "n"(R0), "n"(R1), "n"(R0 + 128), "n"(R1 + 128), "n"(R0 + 256), "n"(R1 + 256)
+      : "memory");
+}
 
 // NW waves per block = 32 NW query rows per block.  With 8 waves the K / V tiles of an (image, head) are split and
 // staged once for up to 256 queries instead of once per 128.
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void sig_attn_split_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(NW * 64, (NW == 8 && LT_ATTN_OCC2) ? 4 : 1) void sig_attn_split_kernel(const float* __restrict__ qkv,
                                                                  const int* __restrict__ cu_sub,
                                                                  float* __restrict__ out /*[N][256] head-major*/) {
   __shared__ __attribute__((aligned(16))) unsigned char Ks[ATT_KT * ATS_RK];
-  __shared__ __attribute__((aligned(16))) unsigned char Vt[DH * ATS_RV];
+  __shared__ __attribute__((aligned(16))) unsigned char Vs[ATT_KT * ATS_RV];
   const int img = blockIdx.x, head = blockIdx.y;
   const int n0 = cu_sub[img], Ni = cu_sub[img + 1] - n0;
   const int q0 = blockIdx.z * (NW * 32);
@@ -763,6 +795,8 @@ __global__ __launch_bounds__(NW * 64) void sig_attn_split_kernel(const float* __
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m = -INFINITY, l = 0.f;
 
+  // lane address of the transposing V reads for kv0 = 0 (see v_frags_tr)
+  const unsigned v_base = (unsigned)(size_t)(Vs + (((lane & 15) >> 2) + 4 * h2) * ATS_RV + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2);
   const int srow = tid >> 4, sc4 = (tid & 15) * 4;  // staging: 4 NW rows x 16 float4 per pass
   constexpr int NPASS = ATT_KT / (4 * NW);
   // K / V rows of the NEXT tile travel in registers while the current tile is being consumed: the global-load latency
@@ -781,8 +815,9 @@ __global__ __launch_bounds__(NW * 64) void sig_attn_split_kernel(const float* __
       }
     }
   };
-  fetch(0);
+  if (!LT_ATTN_OCC2) fetch(0);
   for (int t0 = 0; t0 < Ni; t0 += ATT_KT) {
+    if (LT_ATTN_OCC2) fetch(t0);     // no register prefetch: the second resident block covers the latency instead
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
@@ -796,15 +831,9 @@ __global__ __launch_bounds__(NW * 64) void sig_attn_split_kernel(const float* __
       split_pair<3>(vx[0], vx[1], a);
       split_pair<3>(vx[2], vx[3], b);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {  // transposed: element (kv=r, d=sc4+j) -> Vt[d][p][r]
-        unsigned short* col = reinterpret_cast<unsigned short*>(Vt + p * 128 + r * 2);
-        col[(sc4 + 0) * (ATS_RV / 2)] = (unsigned short)(a[p] & 0xffffu);
-        col[(sc4 + 1) * (ATS_RV / 2)] = (unsigned short)(a[p] >> 16);
-        col[(sc4 + 2) * (ATS_RV / 2)] = (unsigned short)(b[p] & 0xffffu);
-        col[(sc4 + 3) * (ATS_RV / 2)] = (unsigned short)(b[p] >> 16);
-      }
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(Vs + r * ATS_RV + p * 128 + sc4 * 2) = u32x2{a[p], b[p]};
     }
-    if (t0 + ATT_KT < Ni) fetch(t0 + ATT_KT);   // block-uniform
+    if (!LT_ATTN_OCC2 && t0 + ATT_KT < Ni) fetch(t0 + ATT_KT);   // block-uniform
     __syncthreads();
     if (!wave_active) continue;
 #pragma unroll
@@ -865,16 +894,21 @@ __global__ __launch_bounds__(NW * 64) void sig_attn_split_kernel(const float* __
             pp[p] = x.v;
           }
         }
-        const unsigned char* vp = Vt + lq * ATS_RV + (c * 32 + 16 * t + 4 * h2) * 2;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
+          u32x2 vr[3][2];
+          if (dt == 0) {
+            if (c == 0) { if (t == 0) v_frags_tr<0, 0>(v_base, vr); else v_frags_tr<16, 0>(v_base, vr); }
+            else        { if (t == 0) v_frags_tr<32, 0>(v_base, vr); else v_frags_tr<48, 0>(v_base, vr); }
+          } else {
+            if (c == 0) { if (t == 0) v_frags_tr<0, 1>(v_base, vr); else v_frags_tr<16, 1>(v_base, vr); }
+            else        { if (t == 0) v_frags_tr<32, 1>(v_base, vr); else v_frags_tr<48, 1>(v_base, vr); }
+          }
           bf16x8 va[3];
 #pragma unroll
           for (int p = 0; p < 3; ++p) {
-            const u32x2 lo = *reinterpret_cast<const u32x2*>(vp + dt * 32 * ATS_RV + p * 128);
-            const u32x2 hi = *reinterpret_cast<const u32x2*>(vp + dt * 32 * ATS_RV + p * 128 + 16);
             union { bf16x8 v; unsigned u[4]; } x;
-            x.u[0] = lo[0]; x.u[1] = lo[1]; x.u[2] = hi[0]; x.u[3] = hi[1];
+            x.u[0] = vr[p][0][0]; x.u[1] = vr[p][0][1]; x.u[2] = vr[p][1][0]; x.u[3] = vr[p][1][1];
             va[p] = x.v;
           }
           f32x16& o = dt == 0 ? o0 : o1;
