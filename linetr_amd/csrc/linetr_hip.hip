@@ -70,12 +70,15 @@ struct LinetrHandle {
 
 namespace {
 
-// Measured on MI355X: at cfg3 (25 k sub-lines) overlapping the NHWC transpose / line-position MLP with the
-// token-MLP GEMMs buys ~2 % (both sides contend for the same per-CU fetch path); for a single pair the extra
-// event waits COST 0.4 ms.  Hence only large batches fork.
+// Side stream (NHWC transposition / line-position MLP next to the token-MLP GEMMs): OFF by default since r02.
+// Measured on MI355X at cfg3: whenever the host runs a few steps ahead of the GPU -- the normal state of the batched
+// path -- roughly every third step lost ~1 ms to the interplay of the two hardware queues (per-step HIP events:
+// 2.84 ms median, 3.8-3.9 ms on the slow steps, mean 3.0); with everything on one stream every step takes 2.82 ms
+// (8.9 M vs 8.4 M descriptors/s; NCHW-fed 8.27 M vs 7.94 M).  LINETR_SIDE_STREAM=1 turns the fork back on for
+// experiments; it still only applies to large batches (for a single pair the event waits cost more than they hide).
 bool side_stream_ready(LinetrHandle* h, int n_sublines) {
-  static const bool off = getenv("LINETR_NO_SIDE_STREAM") != nullptr;
-  if (off || n_sublines < 8192) return false;
+  static const bool on = getenv("LINETR_SIDE_STREAM") != nullptr && getenv("LINETR_NO_SIDE_STREAM") == nullptr;
+  if (!on || n_sublines < 8192) return false;
   if (h->side) return true;
   if (h->side_failed) return false;
   // create into locals and publish only when all five objects exist: a half-built set must never be used
