@@ -60,6 +60,10 @@ struct LinetrHandle {
   hipStream_t side = nullptr;
   bool side_failed = false;
   hipEvent_t ev_fork = nullptr, ev_tok = nullptr, ev_nhwc = nullptr, ev_lpos = nullptr;
+  // stream-K workspace of the 128x256 GEMM (partial accumulator tiles + flags, one slot per CU; lt_gemm_split.h)
+  float* sk_ws = nullptr;
+  unsigned* sk_flags = nullptr;
+  unsigned sk_epoch = 0;
   // profiling
   bool profiling = false;
   std::vector<ProfClass> classes;
@@ -257,6 +261,7 @@ int run_gemm(LinetrHandle* h, hipStream_t st, const float* A, int lda, const flo
   if (it == h->split.end()) return fail(LINETR_E_ARG, "gemm: weight has no split-bf16 copy");
   SplitGemmArgs sa;
   sa.g = g;
+  sa.sk_ws = h->sk_ws; sa.sk_flags = h->sk_flags; sa.sk_epoch = ++h->sk_epoch;
   if (h->precision == LINETR_PREC_BF16X3) {
     sa.Wsp = h->split_arena + it->second.off2;
     sa.gWsp = gW * 4;
@@ -609,6 +614,13 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
     LT_LAUNCH_CHECK();
     LT_HIP(hipDeviceSynchronize());
   }
+  {  // stream-K workspace: 256 slots of one 128x256 fp32 tile + 257 flags (zeroed once; epochs start at 1)
+    constexpr size_t slots = 256, slot_bytes = 128 * 256 * sizeof(float);
+    LT_HIP(hipMalloc((void**)&H->sk_ws, slots * slot_bytes));
+    LT_HIP(hipMalloc((void**)&H->sk_flags, (slots + 1) * sizeof(unsigned)));
+    LT_HIP(hipMemset(H->sk_flags, 0, (slots + 1) * sizeof(unsigned)));
+    LT_HIP(hipDeviceSynchronize());
+  }
   if (const char* e = getenv("LINETR_PRECISION")) {
     if (!strcmp(e, "f32")) H->precision = LINETR_PREC_F32;
     else if (!strcmp(e, "bf16x3")) H->precision = LINETR_PREC_BF16X3;
@@ -637,6 +649,8 @@ extern "C" void linetr_destroy(LinetrHandle* h) {
     if (e) (void)hipEventDestroy(e);
   if (h->arena) (void)hipFree(h->arena);
   if (h->split_arena) (void)hipFree(h->split_arena);
+  if (h->sk_ws) (void)hipFree(h->sk_ws);
+  if (h->sk_flags) (void)hipFree(h->sk_flags);
   for (auto& kv : h->debug_split) (void)hipFree(kv.second);
   delete h;
 }

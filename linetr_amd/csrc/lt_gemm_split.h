@@ -84,7 +84,38 @@ struct SplitGemmArgs {
   const unsigned char* Wsp;   // split weights
   int64_t gWsp;               // bytes between groups
   int wide_epi = 0;           // epilogue through LDS with dwordx4 row stores (set by gemm_split_launch_t)
+  // stream-K tail (128x256 pipelined kernel only; see gemm_split_kernel): tiles >= sk_first are shared by sk_blocks
+  // blocks that each take an equal run of (tile, K-tile) iterations
+  int sk_first = 0, sk_blocks = 0;
+  float* sk_ws = nullptr;           // [sk_blocks][BM * BN] partial accumulator tiles
+  unsigned* sk_flags = nullptr;     // [sk_blocks] = epoch once the block's partial tile is published; [sk_blocks] = error flag
+  unsigned sk_epoch = 0;
 };
+
+// ---- stream-K hand-off (MI355X_MICROARCH.md, "Valid forms"): plain stores -> block barrier -> lane-0 agent release ->
+// vmcnt(0) -> relaxed agent flag store;  consumer: relaxed poll (bounded) -> agent acquire -> block barrier -> plain loads.
+__device__ __forceinline__ void sk_publish(unsigned* flag, unsigned epoch) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ void sk_wait(const unsigned* flag, unsigned epoch, unsigned* err) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > 400000) {      // ~0.1 s: never hang the device; the launch is then reported as failed by the host check
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
 
 template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0, int PFD = 1, bool PIPE = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs sa) {
@@ -106,27 +137,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
   const int wm = wave / WN, wn = wave % WN;
   // XCD-aware tile order: hardware places block b on XCD b % 8 (speed assumption only).  Give every XCD a
   // contiguous run of tiles, column tiles of one row tile adjacent, so the A row tile is fetched into ONE L2.
+  constexpr bool SK = PIPE && BM == 128 && BN == 256;   // the instantiation that may carry a stream-K tail
   const int gx = g.N / BN, gy = (g.M + BM - 1) / BM;
-  const int ntile = gx * gy;
+  const int ntile_all = gx * gy;
+  const int ntile = (SK && sa.sk_blocks > 0) ? sa.sk_first : ntile_all;   // tiles of the data-parallel part
   int tile;
   {
     const int b = blockIdx.x, q = ntile / 8, r = ntile % 8, xcd = b % 8, k = b / 8;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
-  const int m0 = (tile / gx) * BM, n0 = (tile % gx) * BN;
+  int m0 = (tile / gx) * BM, n0 = (tile % gx) * BN;   // re-assigned per segment by stream-K blocks
   const int grp = blockIdx.y;
   const float* A = g.A + grp * g.gA;
   const float* A2 = g.A2 ? g.A2 + grp * g.gA : nullptr;
   const unsigned char* Wsp = sa.Wsp + grp * sa.gWsp;
   const int K1 = g.A2 ? g.K1 : g.K;
-  const int nk = g.K / 32;
+  const int nkw = g.K / 32;          // K tiles of the whole problem (row stride of the split weights)
+  int nk = nkw, kbase = 0;           // K tiles of the current segment and its first K tile (stream-K: a part of a tile's K range)
 
   const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
   static_assert(PFD >= 1 && (DB || PFD == 1) && (!PIPE || PFD <= 2), "deep prefetch needs the double-buffered LDS");
   f32x4 ra_[PFD][A_F4];   // PFD tiles in flight in registers (PFD > 1: small-M launches, where one tile's MFMAs are
   f32x4 rb_[PFD][B_PCS];  // far shorter than the L2/HBM latency and one-deep prefetch leaves the CU waiting)
   auto gload_set = [&](int kt, f32x4 (&ra)[A_F4], f32x4 (&rb)[B_PCS]) {
-    const int k0 = kt * 32;
+    const int k0 = (kbase + kt) * 32;
     const float* src = A; int ld = g.lda; int kk = k0;
     if (k0 >= K1) { src = A2; ld = g.lda2; kk = k0 - K1; }
 #pragma unroll
@@ -139,7 +173,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
     for (int i = 0; i < B_PCS; ++i) {
       const int p = tid + i * NT;
       const int r = p / (PL * 4), pc = p % (PL * 4);
-      rb[i] = *reinterpret_cast<const f32x4*>(Wsp + ((int64_t)(n0 + r) * nk + kt) * (PL * 64) + pc * 16);
+      rb[i] = *reinterpret_cast<const f32x4*>(Wsp + ((int64_t)(n0 + r) * nkw + kbase + kt) * (PL * 64) + pc * 16);
     }
   };
   auto lstore_set = [&](int buf, const f32x4 (&ra)[A_F4], const f32x4 (&rb)[B_PCS]) {
@@ -163,12 +197,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
   auto lstore = [&](int buf) { lstore_set(buf, ra_[0], rb_[0]); };
 
   f32x16 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int frow = lane & 31, fk = (lane >> 5) * 16;  // byte offset of this lane's 8 bf16 inside a 16-wide K step
   // Fragments of one 16-wide K step: MI + NI rows x PL planes, one ds_read_b128 each.
@@ -210,6 +238,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
     }
   };
 
+  // one pass over K tiles [kbase, kbase + nk) of tile (m0, n0): zeroes the accumulators, stages, multiplies
+  auto mainloop = [&]() {
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   gload(0);
   lstore(0);
   if constexpr (PFD == 1 || PIPE) {
@@ -263,11 +299,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
         if (dbg_mode & 2) return;
         if (dbg_mode & 1) {
           if (u < A_F4) ra[u] = *reinterpret_cast<const f32x4*>(A + (int64_t)(lrow + u * (NT / 8)) * g.lda + lc4);
-          else { const int pq = tid + (u - A_F4) * NT; rb[u - A_F4] = *reinterpret_cast<const f32x4*>(Wsp + (int64_t)(pq / (PL * 4)) * nk * (PL * 64) + (pq % (PL * 4)) * 16); }
+          else { const int pq = tid + (u - A_F4) * NT; rb[u - A_F4] = *reinterpret_cast<const f32x4*>(Wsp + (int64_t)(pq / (PL * 4)) * nkw * (PL * 64) + (pq % (PL * 4)) * 16); }
           return;
         }
         if (u < A_F4) {
-          const int k0 = kt * 32;
+          const int k0 = (kbase + kt) * 32;
           const float* src = A; int ld = g.lda; int kk = k0;
           if (k0 >= K1) { src = A2; ld = g.lda2; kk = k0 - K1; }
           int r = m0 + lrow + u * (NT / 8);
@@ -276,7 +312,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
         } else {
           const int pq = tid + (u - A_F4) * NT;
           const int r = pq / (PL * 4), pc = pq % (PL * 4);
-          rb[u - A_F4] = *reinterpret_cast<const f32x4*>(Wsp + ((int64_t)(n0 + r) * nk + kt) * (PL * 64) + pc * 16);
+          rb[u - A_F4] = *reinterpret_cast<const f32x4*>(Wsp + ((int64_t)(n0 + r) * nkw + kbase + kt) * (PL * 64) + pc * 16);
         }
       };
       auto step_store = [&](int u, int buf, const f32x4 (&ra)[A_F4], const f32x4 (&rb)[B_PCS]) {
@@ -411,8 +447,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
     }
   }
 
+  };   // mainloop
+
   const float* bias = g.bias ? g.bias + grp * g.gBias : nullptr;
   float* Y = g.Y + grp * g.gY;
+  auto epilogue = [&]() {
   if (sa.wide_epi) {
     // Epilogue through LDS: the 32x32 C/D layout gives a lane ONE column and 16 rows, so direct stores are 64 dword
     // stores per lane (512 wave-instructions of 256 B per 128x256 block) and the block ends on a store-ISSUE-bound tail
@@ -530,6 +569,75 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
       }
     }
   }
+  };   // epilogue
+
+  if constexpr (SK) {
+    if (sa.sk_blocks > 0 && (int)blockIdx.x >= sa.sk_first) {
+      // ---- stream-K tail.  The tiles the data-parallel part leaves over (ntile_all - sk_first of them: fewer than one
+      // per CU, so a plain launch would end on a partly empty round) are cut into (tile, K tile) iterations and every one
+      // of the sk_blocks blocks takes an equal run of them.  A tile whose K range is shared is finished by the block that
+      // holds its FIRST K tiles: the others publish their partial accumulator tile through the workspace.
+      // Runs are handed out in REVERSE block order: block s takes run (sk_blocks - 1 - s).  A block starts with the
+      // tail of a shared tile (publishes immediately) and ends with the head of another one, whose remaining parts
+      // belong to blocks s-1, s-2 .. -- LOWER indices, dispatched earlier (so the wait cannot starve an un-dispatched
+      // block) and published at the very beginning of those blocks' lives (so the wait is normally over already).
+      // Fixed partition and fixed summation order: deterministic.
+      const int S = sa.sk_blocks, s_ = (int)blockIdx.x - sa.sk_first;
+      const int64_t I = (int64_t)(ntile_all - sa.sk_first) * nkw;
+      auto run_lo = [&](int it) { return I * it / S; };
+      const int it = S - 1 - s_;
+      int64_t i = run_lo(it);
+      const int64_t hi = run_lo(it + 1);
+      constexpr int SLOT = BM * BN;
+      while (i < hi) {
+        const int t = sa.sk_first + (int)(i / nkw);
+        const int kb = (int)(i % nkw);
+        const int ke = (int)((int64_t)nkw < kb + (hi - i) ? (int64_t)nkw : kb + (hi - i));
+        m0 = (t / gx) * BM; n0 = (t % gx) * BN; kbase = kb; nk = ke - kb;
+        __syncthreads();                       // LDS of the previous segment (tiles or epilogue regions) is dead
+        mainloop();
+        if (kb > 0) {                          // tail / middle part of a shared tile: publish
+          float* slot = sa.sk_ws + (int64_t)s_ * SLOT;
+#pragma unroll
+          for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b)
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(slot + ((((a * NI + b) * 4 + q) * NT) + tid) * 4) =
+                    f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+          sk_publish(sa.sk_flags + s_, sa.sk_epoch);
+        } else {
+          if (ke < nkw) {                      // head of a shared tile (last segment of this block): collect the rest
+            int rem = nkw - ke;
+            for (int j = s_ - 1; rem > 0 && j >= 0; --j) {
+              const int itj = S - 1 - j;
+              const int len = (int)(run_lo(itj + 1) - run_lo(itj));
+              if (len == 0) continue;
+              sk_wait(sa.sk_flags + j, sa.sk_epoch, sa.sk_flags + S);
+              const float* slot = sa.sk_ws + (int64_t)j * SLOT;
+#pragma unroll
+              for (int a = 0; a < MI; ++a)
+#pragma unroll
+                for (int b = 0; b < NI; ++b)
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(slot + ((((a * NI + b) * 4 + q) * NT) + tid) * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[a][b][4 * q + c] += v[c];
+                  }
+              rem -= len < rem ? len : rem;
+            }
+          }
+          epilogue();
+        }
+        i += ke - kb;
+      }
+      return;
+    }
+  }
+  mainloop();
+  epilogue();
 }
 
 template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0, int PFD = 1, bool PIPE = false>
@@ -551,6 +659,28 @@ inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t
     attr_done |= dev_bit;
   }
   dim3 grid((sa.g.N / BN) * cdiv(sa.g.M, BM), groups);
+  sa2.sk_first = sa2.sk_blocks = 0;
+  if constexpr (PIPE && BM == 128 && BN == 256) {
+    // stream-K tail: when the last round of tiles would leave a good part of the chip idle, those tiles are shared by one
+    // block per CU instead (see the kernel).  Measured quantisation: 25472 x 512 x 512 (398 tiles) took as long as
+    // 32768 x 512 x 512 (512 tiles), 104 us.
+    static const bool no_sk = getenv("LINETR_NO_STREAMK") != nullptr;   // tuning aid
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const int T = (int)grid.x, nkw = sa.g.K / 32;
+    const int full = T / n_cu * n_cu, rem = T - full;
+    const int idle_ok = full > 0 ? n_cu * 13 / 16 : n_cu * 11 / 16;    // only when >= 3/16 (5/16 for a single round) of the CUs would idle
+    if (!no_sk && sa.sk_ws && groups == 1 && sa2.wide_epi && rem > 0 && rem <= idle_ok && (int64_t)rem * nkw >= 2 * n_cu &&
+        n_cu <= 256) {
+      sa2.sk_first = full;
+      sa2.sk_blocks = n_cu;
+      grid.x = full + n_cu;
+    }
+  }
   hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT, PFD, PIPE>), grid, dim3(WM * WN * 64), lds, st, sa2);
 }
 
