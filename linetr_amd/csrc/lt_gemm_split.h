@@ -117,7 +117,7 @@ __device__ __forceinline__ void sk_wait(const unsigned* flag, unsigned epoch, un
   __syncthreads();
 }
 
-template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0, int PFD = 1, bool PIPE = false>
+template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0, int PFD = 1, bool PIPE = false, bool SKT = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs sa) {
   const GemmArgs& g = sa.g;
   constexpr int NT = WM * WN * 64;
@@ -137,7 +137,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
   const int wm = wave / WN, wn = wave % WN;
   // XCD-aware tile order: hardware places block b on XCD b % 8 (speed assumption only).  Give every XCD a
   // contiguous run of tiles, column tiles of one row tile adjacent, so the A row tile is fetched into ONE L2.
-  constexpr bool SK = PIPE && BM == 128 && BN == 256;   // the instantiation that may carry a stream-K tail
+  constexpr bool SK = SKT;   // the instantiation that carries a stream-K tail (its own kernel: the extra state costs registers)
+  static_assert(!SKT || (PIPE && BM == 128 && BN == 256), "stream-K is built for the pipelined 128x256 tile only");
   const int gx = g.N / BN, gy = (g.M + BM - 1) / BM;
   const int ntile_all = gx * gy;
   const int ntile = (SK && sa.sk_blocks > 0) ? sa.sk_first : ntile_all;   // tiles of the data-parallel part
@@ -571,73 +572,80 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
   }
   };   // epilogue
 
+  // ---- stream-K tail.  The tiles the data-parallel part leaves over (ntile_all - sk_first of them: fewer than one per
+  // CU, so a plain launch would end on a partly empty round) are cut into (tile, K tile) iterations and every one of the
+  // sk_blocks blocks takes an equal run of them.  A tile whose K range is shared is finished by the block that holds its
+  // FIRST K tiles: the others publish their partial accumulator tile through the workspace.
+  // Runs are handed out in REVERSE block order: block s takes run (sk_blocks - 1 - s).  A block starts with the tail of
+  // a shared tile (publishes immediately) and ends with the head of another one, whose remaining parts belong to
+  // blocks s-1, s-2 .. -- LOWER indices, dispatched earlier (so the wait cannot starve an un-dispatched block) and
+  // published at the very beginning of those blocks' lives (so the wait is normally over already).  Fixed partition
+  // and fixed summation order: deterministic.  Data-parallel blocks run the loop below exactly once.
+  bool sk = false;
+  int s_ = 0, S = 1;
+  // 32-bit on purpose (at most 256 tiles x 64 K tiles x 256 runs): 64-bit divisions cost dozens of registers here
+  unsigned it_i = 0, it_hi = 1, I = 0;
   if constexpr (SK) {
     if (sa.sk_blocks > 0 && (int)blockIdx.x >= sa.sk_first) {
-      // ---- stream-K tail.  The tiles the data-parallel part leaves over (ntile_all - sk_first of them: fewer than one
-      // per CU, so a plain launch would end on a partly empty round) are cut into (tile, K tile) iterations and every one
-      // of the sk_blocks blocks takes an equal run of them.  A tile whose K range is shared is finished by the block that
-      // holds its FIRST K tiles: the others publish their partial accumulator tile through the workspace.
-      // Runs are handed out in REVERSE block order: block s takes run (sk_blocks - 1 - s).  A block starts with the
-      // tail of a shared tile (publishes immediately) and ends with the head of another one, whose remaining parts
-      // belong to blocks s-1, s-2 .. -- LOWER indices, dispatched earlier (so the wait cannot starve an un-dispatched
-      // block) and published at the very beginning of those blocks' lives (so the wait is normally over already).
-      // Fixed partition and fixed summation order: deterministic.
-      const int S = sa.sk_blocks, s_ = (int)blockIdx.x - sa.sk_first;
-      const int64_t I = (int64_t)(ntile_all - sa.sk_first) * nkw;
-      auto run_lo = [&](int it) { return I * it / S; };
-      const int it = S - 1 - s_;
-      int64_t i = run_lo(it);
-      const int64_t hi = run_lo(it + 1);
-      constexpr int SLOT = BM * BN;
-      while (i < hi) {
-        const int t = sa.sk_first + (int)(i / nkw);
-        const int kb = (int)(i % nkw);
-        const int ke = (int)((int64_t)nkw < kb + (hi - i) ? (int64_t)nkw : kb + (hi - i));
-        m0 = (t / gx) * BM; n0 = (t % gx) * BN; kbase = kb; nk = ke - kb;
-        __syncthreads();                       // LDS of the previous segment (tiles or epilogue regions) is dead
-        mainloop();
-        if (kb > 0) {                          // tail / middle part of a shared tile: publish
-          float* slot = sa.sk_ws + (int64_t)s_ * SLOT;
+      sk = true;
+      S = sa.sk_blocks; s_ = (int)blockIdx.x - sa.sk_first;
+      I = (unsigned)(ntile_all - sa.sk_first) * (unsigned)nkw;
+      it_i = I * (unsigned)(S - 1 - s_) / (unsigned)S;
+      it_hi = I * (unsigned)(S - s_) / (unsigned)S;
+      if (it_i >= it_hi) return;
+    }
+  }
+  constexpr int SLOT = BM * BN;
+  for (;;) {
+    int kb = 0, ke = nkw;
+    if (SK && sk) {
+      const unsigned tq = it_i / (unsigned)nkw;
+      const int t = sa.sk_first + (int)tq;
+      kb = (int)(it_i - tq * (unsigned)nkw);
+      ke = kb + (int)(it_hi - it_i) < nkw ? kb + (int)(it_hi - it_i) : nkw;
+      m0 = (t / gx) * BM; n0 = (t % gx) * BN;
+      __syncthreads();                         // LDS of the previous segment (tiles or epilogue regions) is dead
+    }
+    kbase = kb; nk = ke - kb;
+    mainloop();
+    if (SK && sk && kb > 0) {                  // tail / middle part of a shared tile: publish
+      float* slot = sa.sk_ws + (int64_t)s_ * SLOT;
+#pragma unroll
+      for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(slot + ((((a * NI + b) * 4 + q) * NT) + tid) * 4) =
+                f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+      sk_publish(sa.sk_flags + s_, sa.sk_epoch);
+    } else {
+      if (SK && sk && ke < nkw) {              // head of a shared tile (last segment of this block): collect the rest
+        int rem = nkw - ke;
+        for (int j = s_ - 1; rem > 0 && j >= 0; --j) {
+          const int len = (int)(I * (unsigned)(S - j) / (unsigned)S - I * (unsigned)(S - 1 - j) / (unsigned)S);
+          if (len == 0) continue;
+          sk_wait(sa.sk_flags + j, sa.sk_epoch, sa.sk_flags + S);
+          const float* slot = sa.sk_ws + (int64_t)j * SLOT;
 #pragma unroll
           for (int a = 0; a < MI; ++a)
 #pragma unroll
             for (int b = 0; b < NI; ++b)
 #pragma unroll
-              for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<f32x4*>(slot + ((((a * NI + b) * 4 + q) * NT) + tid) * 4) =
-                    f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-          sk_publish(sa.sk_flags + s_, sa.sk_epoch);
-        } else {
-          if (ke < nkw) {                      // head of a shared tile (last segment of this block): collect the rest
-            int rem = nkw - ke;
-            for (int j = s_ - 1; rem > 0 && j >= 0; --j) {
-              const int itj = S - 1 - j;
-              const int len = (int)(run_lo(itj + 1) - run_lo(itj));
-              if (len == 0) continue;
-              sk_wait(sa.sk_flags + j, sa.sk_epoch, sa.sk_flags + S);
-              const float* slot = sa.sk_ws + (int64_t)j * SLOT;
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(slot + ((((a * NI + b) * 4 + q) * NT) + tid) * 4);
 #pragma unroll
-              for (int a = 0; a < MI; ++a)
-#pragma unroll
-                for (int b = 0; b < NI; ++b)
-#pragma unroll
-                  for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(slot + ((((a * NI + b) * 4 + q) * NT) + tid) * 4);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[a][b][4 * q + c] += v[c];
-                  }
-              rem -= len < rem ? len : rem;
-            }
-          }
-          epilogue();
+                for (int c = 0; c < 4; ++c) acc[a][b][4 * q + c] += v[c];
+              }
+          rem -= len < rem ? len : rem;
         }
-        i += ke - kb;
       }
-      return;
+      epilogue();
     }
+    if (!(SK && sk)) break;
+    it_i += (unsigned)(ke - kb);
+    if (it_i >= it_hi) break;
   }
-  mainloop();
-  epilogue();
 }
 
 template <int BM, int BN, int WM, int WN, int PL, bool DB = true, int FMT = 0, int PFD = 1, bool PIPE = false>
@@ -675,10 +683,20 @@ inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t
     const int full = T / n_cu * n_cu, rem = T - full;
     const int idle_ok = full > 0 ? n_cu * 13 / 16 : n_cu * 11 / 16;    // only when >= 3/16 (5/16 for a single round) of the CUs would idle
     if (!no_sk && sa.sk_ws && groups == 1 && sa2.wide_epi && rem > 0 && rem <= idle_ok && (int64_t)rem * nkw >= 2 * n_cu &&
-        n_cu <= 256) {
+        n_cu <= 256 && nkw <= 4096) {
       sa2.sk_first = full;
       sa2.sk_blocks = n_cu;
       grid.x = full + n_cu;
+      // the stream-K kernel is its own instantiation with one register set of prefetch (PFD = 1): with two, the segment
+      // loop's extra state spilled 116 VGPRs
+      static unsigned long long attr_sk = 0;
+      if (!(attr_sk & dev_bit)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT, 1, PIPE, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_sk |= dev_bit;
+      }
+      hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT, 1, PIPE, true>), grid, dim3(WM * WN * 64), lds, st, sa2);
+      return;
     }
   }
   hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT, PFD, PIPE>), grid, dim3(WM * WN * 64), lds, st, sa2);

@@ -152,8 +152,8 @@ def test_gemm_stream_k_tail(eng, M, N, K, act):
     W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
     b = torch.randn(N, device="cuda", generator=g)
     R = torch.randn(M, N, device="cuda", generator=g)
-    Y1 = eng.debug_gemm(A, W, b, R, act, cache_weights=True).clone()
-    Y2 = eng.debug_gemm(A, W, b, R, act, cache_weights=True)
+    Y1 = eng.debug_gemm(A, W, b, R, act).clone()
+    Y2 = eng.debug_gemm(A, W, b, R, act)
     assert torch.equal(Y1, Y2)
     x = A.double() @ W.double().t() + b.double()
     x = [x, torch.relu(x), torch.nn.functional.gelu(x)][act] + R.double()
