@@ -92,27 +92,33 @@ struct SplitGemmArgs {
   unsigned sk_epoch = 0;
 };
 
-// ---- stream-K hand-off (MI355X_MICROARCH.md, "Valid forms"): plain stores -> block barrier -> lane-0 agent release ->
-// vmcnt(0) -> relaxed agent flag store;  consumer: relaxed poll (bounded) -> agent acquire -> block barrier -> plain loads.
+// ---- stream-K hand-off (MI355X_MICROARCH.md, "publish-large" / "Valid forms"): the partial tile is written with
+// write-through (sc1) 16-byte stores and read back with sc1 loads, the flag is a relaxed agent-scope atomic behind a
+// drained vmcnt.  No release / acquire fences: an agent release writes back the XCD's whole L2 -- which is full of the
+// output rows the data-parallel blocks of the same launch have just stored -- once per publishing block.
+__device__ __forceinline__ void sk_store16(float* p, const f32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 sk_load16(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
 __device__ __forceinline__ void sk_publish(unsigned* flag, unsigned epoch) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's write-through stores have reached memory
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void sk_wait(const unsigned* flag, unsigned epoch, unsigned* err) {
   if (threadIdx.x == 0) {
     int spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > 400000) {      // ~0.1 s: never hang the device; the launch is then reported as failed by the host check
+      if (++spins > 400000) {      // ~0.1 s: never hang the device; the error flag marks the launch as failed
         __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
 }
@@ -616,8 +622,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
         for (int b = 0; b < NI; ++b)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<f32x4*>(slot + ((((a * NI + b) * 4 + q) * NT) + tid) * 4) =
-                f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+            sk_store16(slot + ((((a * NI + b) * 4 + q) * NT) + tid) * 4,
+                       f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]});
       sk_publish(sa.sk_flags + s_, sa.sk_epoch);
     } else {
       if (SK && sk && ke < nkw) {              // head of a shared tile (last segment of this block): collect the rest
@@ -628,15 +634,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
           sk_wait(sa.sk_flags + j, sa.sk_epoch, sa.sk_flags + S);
           const float* slot = sa.sk_ws + (int64_t)j * SLOT;
 #pragma unroll
-          for (int a = 0; a < MI; ++a)
+          for (int a = 0; a < MI; ++a) {       // one accumulator row block (8 x 16 bytes per lane) in flight at a time
+            f32x4 pv[NI][4];
 #pragma unroll
             for (int b = 0; b < NI; ++b)
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(slot + ((((a * NI + b) * 4 + q) * NT) + tid) * 4);
+              for (int q = 0; q < 4; ++q) pv[b][q] = sk_load16(slot + ((((a * NI + b) * 4 + q) * NT) + tid) * 4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[a][b][4 * q + c] += v[c];
-              }
+            for (int b = 0; b < NI; ++b)
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[a][b][4 * q + c] += pv[b][q][c];
+          }
           rem -= len < rem ? len : rem;
         }
       }
