@@ -683,7 +683,12 @@ inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t
     // stream-K tail: when the last round of tiles would leave a good part of the chip idle, those tiles are shared by one
     // block per CU instead (see the kernel).  Measured quantisation: 25472 x 512 x 512 (398 tiles) took as long as
     // 32768 x 512 x 512 (512 tiles), 104 us.
-    static const bool no_sk = getenv("LINETR_NO_STREAMK") != nullptr;   // tuning aid
+    // OFF by default (LINETR_STREAMK=1 turns it on, read per launch so that the tests can exercise it): the stream-K
+    // kernel is correct and deterministic (tests/test_gpu_gemm.py) but as built it LOSES -- 25472x512x512 110 us vs 92 us,
+    // 25472x768x256 114 us vs 82 us -- because the segment loop's extra state spills 60 VGPRs and 70 SGPRs next to the
+    // 256-register pipelined main loop, which slows the data-parallel tiles of the same launch as well.  Kept as the
+    // starting point for a leaner version.
+    const bool no_sk = getenv("LINETR_STREAMK") == nullptr;
     static int n_cu = 0;
     if (!n_cu) {
       int dev = 0;
