@@ -303,6 +303,22 @@ def forward(sd: dict, data: dict, image_shape=(480, 640), n_heads: int = 4) -> d
     return data
 
 
+def forward_batch(sd: dict, data: dict, image_shape=(480, 640), n_heads: int = 4) -> dict:
+    """The same forward on a dict whose tensors carry a batch axis B >= 1 with a fixed number of sub-lines per image --
+    the way train.py:163-164 calls the model on the dataset builder's fixed-size samples (util_lines.py:670-766).
+    Images are independent (the signature attention runs per batch element, line_transformer.py:132-154), so this is
+    forward() image by image; line_desc comes back as [B,256,N]."""
+    B = data["sublines"].shape[0]
+    keys = ("sublines", "pnt_sublines", "desc_sublines", "score_sublines", "mask_sublines", "resp_sublines", "angle_sublines")
+    descs = []
+    for b in range(B):
+        one = {k: data[k][b:b + 1] for k in keys}
+        one["klines"] = data["klines"][b:b + 1]
+        descs.append(forward(sd, one, image_shape, n_heads)["line_desc"])
+    data["line_desc"] = torch.cat(descs, dim=0)
+    return data
+
+
 # --------------------------------------------------------------------------------------------
 # a19-a21: matcher (NumPy, like the reference)
 # --------------------------------------------------------------------------------------------

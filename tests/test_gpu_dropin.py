@@ -355,3 +355,30 @@ def test_matching_wraps_the_host_superpoint(monkeypatch):
     assert "dense_descriptor_nhwc0" in a and "dense_descriptor_nhwc0" not in b
     assert torch.equal(a["matches_l"], b["matches_l"]) and torch.equal(a["klines0"].cpu(), b["klines0"].cpu())
     assert (a["line_desc1"] - b["line_desc1"]).abs().max().item() < 1e-6
+
+
+def test_training_time_batched_forward_golden():
+    """8(f) row 4: LineTransformer.forward on a dict with a batch axis (B = 3, fixed 40 sub-lines per image, 12
+    line-descriptive layers) exactly as train.py:163-164 feeds the model with the dataset builder's fixed-size samples
+    (util_lines.py:670-766); expected descriptors frozen from the real reference (tests/golden/make_golden_train.py).
+    Forward only -- the loss / backward are out of scope."""
+    g = load("train_batch")
+    hw = tuple(int(v) for v in g["hw"])
+    n_fix, nl = int(g["n_fix"]), int(g["n_desc_layers"])
+    from models.line_transformer import LineTransformer
+    m = LineTransformer({**LT_CFG, "n_line_descriptive_layers": nl}).eval()
+    m.load_state_dict(synth.to_torch_state_dict(synth.calibrated_state_dict(nl)), strict=True)
+    m = m.to("cuda")
+    keys = ("sublines", "pnt_sublines", "desc_sublines", "score_sublines", "mask_sublines", "resp_sublines", "angle_sublines", "klines")
+    outs = []
+    for b in range(3):
+        dd, ds = synth.synth_dense_maps_np(int(g[f"map_seed_{b}"]), *hw)
+        sp = {"dense_descriptor": torch.from_numpy(dd).cuda(), "dense_score": torch.from_numpy(ds).cuda()}
+        outs.append(m.preprocess(synth.array_to_keylines(g[f"lines_{b}"]), (1, 1, *hw), sp))
+    batch = {k: torch.cat([o[k][:, :n_fix] for o in outs], dim=0) for k in keys}
+    res = m(batch)
+    assert res is batch and res["line_desc"].shape == (3, 256, n_fix)
+    assert np.abs(res["line_desc"].cpu().numpy() - g["line_desc"]).max() < 1e-4
+    # batch element b equals the same image pushed through alone (the signature attention is per image)
+    alone = m({k: v[1:2].clone() for k, v in batch.items() if k != "line_desc"})
+    assert (alone["line_desc"][0] - res["line_desc"][1]).abs().max().item() < 2e-6

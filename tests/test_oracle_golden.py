@@ -124,3 +124,22 @@ def test_superpoint_heads_oracle_matches_reference_fixture():
     patch = score.reshape(2, 8, 8, 12, 8).sum(axis=(2, 4))
     assert (patch <= 1 + 1e-6).all() and (patch > 0).all()
     assert np.abs(np.linalg.norm(desc, axis=1) - 1).max() < 1e-6
+
+
+def test_training_time_batched_forward():
+    """8(f) row 4: the model called as train.py:163-164 calls it -- B = 3 images, a fixed 40 sub-lines each, 12
+    line-descriptive layers -- frozen from the real reference (make_golden_train.py)."""
+    g = load("train_batch")
+    hw = tuple(int(v) for v in g["hw"])
+    n_fix, nl = int(g["n_fix"]), int(g["n_desc_layers"])
+    sd = synth.to_torch_state_dict(synth.calibrated_state_dict(nl))
+    keys = ("sublines", "pnt_sublines", "desc_sublines", "score_sublines", "mask_sublines", "resp_sublines", "angle_sublines", "klines")
+    outs = []
+    for b in range(3):
+        dd, ds = synth.synth_dense_maps_np(int(g[f"map_seed_{b}"]), *hw)
+        outs.append(O.preprocess(synth.array_to_keylines(g[f"lines_{b}"]), (1, 1, *hw), torch.from_numpy(dd), torch.from_numpy(ds),
+                                 dict(BASE_CFG)))
+    batch = {k: torch.cat([o[k][:, :n_fix] for o in outs], dim=0) for k in keys}
+    got = O.forward_batch(sd, batch, hw)["line_desc"].numpy()
+    assert got.shape == g["line_desc"].shape == (3, 256, n_fix)
+    assert np.abs(got - g["line_desc"]).max() < 2e-6
