@@ -19,16 +19,17 @@
 
 namespace lt {
 
-template <int PL, int FMT>
-__global__ __launch_bounds__(256) void gemm_split_small_kernel(SplitGemmArgs sa) {
+template <int PL, int FMT, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void gemm_split_small_kernel(SplitGemmArgs sa) {
   const GemmArgs& g = sa.g;
   constexpr int RS = PL * 64 + 16;                 // W row stride in LDS (bytes), as in gemm_split_kernel
   constexpr int AS = 36;                           // A row stride in LDS (floats): 4 * odd -> conflict-free ds_read_b128
   constexpr int A_BYTES = 32 * AS * 4, W_BYTES = 32 * RS;
   constexpr int W_PCS = PL * 4;                    // 16-byte pieces per W row and K tile
   constexpr int W_LD = (32 * W_PCS + 63) / 64;     // W load instructions per K tile
-  __shared__ __attribute__((aligned(16))) unsigned char stage[4][2][A_BYTES + W_BYTES];   // [wave][buffer]
-  __shared__ float red[4][32 * 33];
+  constexpr int NBUF = NWV == 4 ? 2 : 1;           // 8 waves: one staging buffer each (LDS), every wave has half the K tiles
+  __shared__ __attribute__((aligned(16))) unsigned char stage[NWV][NBUF][A_BYTES + W_BYTES];   // [wave][buffer]
+  __shared__ float red[NWV][32 * 33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gx = g.N / 32;
   const int m0 = (blockIdx.x / gx) * 32, n0 = (blockIdx.x % gx) * 32;
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void gemm_split_small_kernel(SplitGemmArgs sa)
   const unsigned char* Wsp = sa.Wsp + grp * sa.gWsp;
   const int K1 = g.A2 ? g.K1 : g.K;
   const int nk = g.K / 32;
-  const int kt0 = nk * wave / 4, kt1 = nk * (wave + 1) / 4;   // this wave's K tiles
+  const int kt0 = nk * wave / NWV, kt1 = nk * (wave + 1) / NWV;   // this wave's K tiles
 
   // global loads, coalesced: A rows as 8 lanes x 16 B (a K tile of a row is one 128-byte line), W rows as W_PCS lanes x 16 B
   const int a_r = lane >> 3, a_c = (lane & 7) * 4;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void gemm_split_small_kernel(SplitGemmArgs sa)
       if (kt + u < kt1) {
         // wave-private staging (no block barrier: the LDS executes one wave's instructions in order); two buffers so the
         // stores of tile u+1 do not wait behind the fragment reads of tile u
-        unsigned char* As = stage[wave][u & 1];
+        unsigned char* As = stage[wave][u % NBUF];
         unsigned char* Ws = As + A_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(As + ((a_r + 8 * i) * AS + a_c) * 4) = ra[u][i];
@@ -131,14 +132,17 @@ __global__ __launch_bounds__(256) void gemm_split_small_kernel(SplitGemmArgs sa)
   for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + frow] = acc[r];
   __syncthreads();
   const int row = tid >> 3, c4 = (tid & 7) * 4;
-  if (m0 + row < g.M) {
+  if (tid < 256 && m0 + row < g.M) {
     const float* bias = g.bias ? g.bias + grp * g.gBias : nullptr;
     float* Y = g.Y + grp * g.gY;
     f32x4 v;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int o = row * 33 + c4 + c;
-      v[c] = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];   // fixed order
+      float acc4 = red[0][o];
+#pragma unroll
+      for (int w = 1; w < NWV; ++w) acc4 += red[w][o];            // fixed order
+      v[c] = acc4;
       if (bias) v[c] += bias[n0 + c4 + c];
       if (g.act == ACT_RELU) v[c] = fmaxf(v[c], 0.f);
       else if (g.act == ACT_GELU) v[c] = 0.5f * v[c] * (1.f + erff(v[c] * 0.70710678118654752440f));
@@ -164,7 +168,10 @@ inline bool small_gemm_wins(const GemmArgs& g, int groups) {
 template <int PL, int FMT>
 inline void gemm_split_small_launch(const SplitGemmArgs& sa, int groups, hipStream_t st) {
   dim3 grid((unsigned)((sa.g.N / 32) * cdiv(sa.g.M, 32)), (unsigned)groups);
-  hipLaunchKernelGGL((gemm_split_small_kernel<PL, FMT>), grid, dim3(256), 0, st, sa);
+  // K >= 256: eight waves split K (half the loads, splits and MFMAs on every wave's critical path)
+  static const bool w4 = getenv("LINETR_SMALL_GEMM_4WAVE") != nullptr;   // tuning aid
+  if (!w4 && sa.g.K >= 256) hipLaunchKernelGGL((gemm_split_small_kernel<PL, FMT, 8>), grid, dim3(512), 0, st, sa);
+  else hipLaunchKernelGGL((gemm_split_small_kernel<PL, FMT, 4>), grid, dim3(256), 0, st, sa);
 }
 
 }  // namespace lt
