@@ -737,6 +737,9 @@ inline const char* split_tile_name(const GemmArgs& g, int groups, int pl = 3) {
   static const bool no112 = getenv("LINETR_NO_TILE112") != nullptr;   // tuning aid
   if (!no112 && pl == 2 && split16_wins(g, groups)) return "112x256";   // saves a round of blocks (lt_gemm_split16.h)
   const int64_t r128 = cdiv(g.M, 128), r64 = cdiv(g.M, 64);
+  // short K, wide N, many tiles: the single-buffered 128x128 tile (64 KB of LDS: two or three blocks per CU whose
+  // prologues / epilogues overlap each other's main loops) beats the one-block-per-CU pipeline: 25472x768x256 75.5 vs 81 us
+  if (pl == 3 && g.K <= 256 && g.N >= 768 && r128 * (g.N / 128) * groups >= 1024) return "128x128s";
   if (g.N % 256 == 0 && r128 * (g.N / 256) * groups >= 140) return "128x256";
   if (g.N % 256 != 0 && (int64_t)cdiv(g.M, 256) * (g.N / 128) * groups >= 192) return "256x128";
   if (r64 * (g.N / 64) * groups <= 768) return "64x64";
@@ -764,6 +767,7 @@ inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st
   else if (!strcmp(tile, "128x256") && g.N % 256 == 0) gemm_split_launch_t<128, 256, 2, 4, PL, true, FMT, PL == 3 ? 2 : 1, true>(sa, groups, st);
   else if (!strcmp(tile, "64x256") && g.N % 256 == 0) gemm_split_launch_t<64, 256, 1, 4, PL, true, FMT, PL == 3 ? 2 : 1, true>(sa, groups, st);
   else if (!strcmp(tile, "128x128")) gemm_split_launch_t<128, 128, 2, 2, PL, true, FMT>(sa, groups, st);
+  else if (!strcmp(tile, "128x128s")) gemm_split_launch_t<128, 128, 2, 2, PL, false, FMT>(sa, groups, st);   // single LDS buffer: 3 blocks per CU
   else if (PL == 2 && !strcmp(tile, "256x256") && g.N % 256 == 0) gemm_split_launch_t<256, 256, 4, 2, 2, true, FMT>(sa, groups, st);
   else if (!strcmp(tile, "64x64")) gemm_split_launch_t<64, 64, 2, 2, PL, true, FMT, 4>(sa, groups, st);
   else gemm_split_launch_t<64, 128, 2, 2, PL, true, FMT, 3>(sa, groups, st);

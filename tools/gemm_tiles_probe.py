@@ -5,7 +5,7 @@ import os
 import subprocess
 import sys
 
-TILES = ["128x256", "64x256", "256x128", "128x128", "64x128", "64x64"]
+TILES = ["128x256", "64x256", "256x128", "128x128", "128x128s", "64x128", "64x64"]
 SHAPES = [(9584, 256, 256), (9584, 256, 512), (9584, 512, 512), (9584, 768, 256), (9584, 1024, 256), (9584, 256, 1024),
           (4792, 256, 512), (4792, 512, 512), (4792, 768, 256), (25472, 256, 512), (25472, 512, 512), (25472, 768, 256),
           (2396, 512, 512), (2396, 768, 256), (1198, 512, 512), (1198, 768, 256)]
