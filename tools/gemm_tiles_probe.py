@@ -8,7 +8,8 @@ import sys
 TILES = ["128x256", "64x256", "256x128", "128x128", "128x128s", "64x128", "64x64"]
 SHAPES = [(9584, 256, 256), (9584, 256, 512), (9584, 512, 512), (9584, 768, 256), (9584, 1024, 256), (9584, 256, 1024),
           (4792, 256, 512), (4792, 512, 512), (4792, 768, 256), (25472, 256, 512), (25472, 512, 512), (25472, 768, 256),
-          (2396, 512, 512), (2396, 768, 256), (1198, 512, 512), (1198, 768, 256)]
+          (2396, 512, 512), (2396, 768, 256), (1198, 512, 512), (1198, 768, 256), (291208, 256, 128), (25472, 1024, 256),
+          (25472, 256, 256), (25472, 256, 1024), (25472, 256, 768)]
 
 if len(sys.argv) > 2 and sys.argv[1] == "--child":
     import torch
