@@ -28,7 +28,7 @@ struct PairTable {
   __device__ __forceinline__ PairDesc get(int i) const { return n_inline ? inl[i] : ptr[i]; }
 };
 
-constexpr int PM_ROWS = 8;          // key-line rows of Dk per block of pair_pool_kernel
+constexpr int PM_ROWS = 16;         // key-line rows of Dk per block of pair_pool_kernel
 constexpr int PM_MAX_K1 = 12000;    // seg1 table of a pair must fit the block's LDS (48 KB)
 
 // D[a][b] = max(2 - 2 * <d0[a], d1[b]>, 0), fp32 MFMA, 64x64 tile per block, K = 256.
@@ -50,17 +50,30 @@ __global__ __launch_bounds__(256) void pair_dist_kernel(const PairTable pairs,
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // rows of this thread's staging pieces; the NEXT K tile travels in registers while the current one is multiplied
+  int ra[2], rb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    ra[i] = a0 + lrow + i * 32; ra[i] = ra[i] < pd.n0 ? ra[i] : pd.n0 - 1;
+    rb[i] = b0 + lrow + i * 32; rb[i] = rb[i] < pd.n1 ? rb[i] : pd.n1 - 1;
+  }
+  f32x4 va[2], vb[2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      va[i] = *reinterpret_cast<const f32x4*>(A + (int64_t)ra[i] * D + k0 + lc4);
+      vb[i] = *reinterpret_cast<const f32x4*>(B + (int64_t)rb[i] * D + k0 + lc4);
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < D; k0 += 32) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int ra = a0 + lrow + i * 32; ra = ra < pd.n0 ? ra : pd.n0 - 1;
-      int rb = b0 + lrow + i * 32; rb = rb < pd.n1 ? rb : pd.n1 - 1;
-      *reinterpret_cast<f32x4*>(&As[(lrow + i * 32) * LS + lc4]) =
-          *reinterpret_cast<const f32x4*>(A + (int64_t)ra * D + k0 + lc4);
-      *reinterpret_cast<f32x4*>(&Bs[(lrow + i * 32) * LS + lc4]) =
-          *reinterpret_cast<const f32x4*>(B + (int64_t)rb * D + k0 + lc4);
+      *reinterpret_cast<f32x4*>(&As[(lrow + i * 32) * LS + lc4]) = va[i];
+      *reinterpret_cast<f32x4*>(&Bs[(lrow + i * 32) * LS + lc4]) = vb[i];
     }
+    if (k0 + 32 < D) fetch(k0 + 32);
     __syncthreads();
     const float* ap = &As[(wa * 32 + (lane & 31)) * LS + (lane >> 5) * 4];
     const float* bp = &Bs[(wb * 32 + (lane & 31)) * LS + (lane >> 5) * 4];
@@ -113,8 +126,19 @@ __global__ __launch_bounds__(256) void pair_pool_kernel(const PairTable pairs, c
   int* seg0 = pm_lds + pd.k1 + 1;
   const int* m0 = s2l0 + pd.off_s0;
   const int* m1 = s2l1 + pd.off_s1;
-  for (int j = tid; j <= pd.k1; j += 256) seg1[j] = j == pd.k1 ? pd.n1 : seg_lower_bound(m1, pd.n1, j);
-  if (tid <= rows) seg0[tid] = i0 + tid == pd.k0 ? pd.n0 : seg_lower_bound(m0, pd.n0, i0 + tid);
+  // segment starts: sub-lines of a key-line are contiguous and key-line ids non-decreasing, so a start is where the id
+  // changes -- one coalesced pass (a chain of dependent global loads per binary search cost ~5 us of pure latency)
+  for (int n = tid; n < pd.n1; n += 256)
+    if (n == 0 || m1[n] != m1[n - 1]) seg1[m1[n]] = n;
+  for (int n = tid; n < pd.n0; n += 256)
+    if (n == 0 || m0[n] != m0[n - 1]) {
+      const int k = m0[n] - i0;
+      if (k >= 0 && k <= rows) seg0[k] = n;
+    }
+  if (tid == 0) {
+    seg1[pd.k1] = pd.n1;
+    if (i0 + rows == pd.k0) seg0[rows] = pd.n0;
+  }
   __syncthreads();
   const float* Dp = dist + pd.off_d;
   float* Dk = dk_out + pd.off_dk + (int64_t)i0 * pd.k1;
@@ -180,7 +204,15 @@ __global__ __launch_bounds__(256) void pair_final_kernel(const PairTable pairs, 
   const int* part_arg = col_arg + pd.k1 + (int64_t)pd.chunks * pd.k1;
   for (int j = tid; j < pd.k1; j += 256) {
     float best = INFINITY; int arg = 0;
-    for (int c = 0; c < pd.chunks; ++c) {            // ascending rows: strict < keeps the first minimum
+    int c = 0;
+    for (; c + 4 <= pd.chunks; c += 4) {             // four independent loads in flight; ascending rows: strict < keeps the first
+      float v[4]; int a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { v[u] = part_val[(int64_t)(c + u) * pd.k1 + j]; a[u] = part_arg[(int64_t)(c + u) * pd.k1 + j]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (v[u] < best) { best = v[u]; arg = a[u]; }
+    }
+    for (; c < pd.chunks; ++c) {
       const float v = part_val[(int64_t)c * pd.k1 + j];
       if (v < best) { best = v; arg = part_arg[(int64_t)c * pd.k1 + j]; }
     }
