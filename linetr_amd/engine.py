@@ -452,25 +452,36 @@ class Engine:
         Returns (Dk_flat, off_dk host [P+1], match01 int32 [sum k0], off_k0 host [P+1])."""
         dims = np.ascontiguousarray(dims, dtype=np.int32)
         P = len(dims)
-        off_dk = np.zeros(P + 1, dtype=np.int64)
-        np.cumsum(dims[:, 1].astype(np.int64) * dims[:, 3].astype(np.int64), out=off_dk[1:])
-        off_k0 = np.zeros(P + 1, dtype=np.int64)
-        np.cumsum(dims[:, 1].astype(np.int64), out=off_k0[1:])
+        i64 = np.int64
+        if P == 1:                      # latency path of a single pair: no cumsums, no reductions
+            n0, k0, n1, k1 = (int(v) for v in dims[0])
+            off_dk = np.array([0, k0 * k1], dtype=i64)
+            off_k0 = np.array([0, k0], dtype=i64)
+            sum_nn, sum_k = n0 * n1, k0 + k1
+        else:
+            off_dk = np.zeros(P + 1, dtype=i64)
+            np.cumsum(dims[:, 1].astype(i64) * dims[:, 3].astype(i64), out=off_dk[1:])
+            off_k0 = np.zeros(P + 1, dtype=i64)
+            np.cumsum(dims[:, 1].astype(i64), out=off_k0[1:])
+            sum_nn = int((dims[:, 0].astype(i64) * dims[:, 2].astype(i64)).sum()) if P else 0
+            sum_k = int(dims[:, 1].sum() + dims[:, 3].sum()) if P else 0
         dk = torch.empty((max(int(off_dk[-1]), 1),), dtype=torch.float32, device=self.device)
         m01 = torch.empty((max(int(off_k0[-1]), 1),), dtype=torch.int32, device=self.device)
         if P == 0:
             return dk[:0], off_dk, m01[:0], off_k0
-        sum_nn = int((dims[:, 0].astype(np.int64) * dims[:, 2].astype(np.int64)).sum())
-        sum_k = int(dims[:, 1].sum() + dims[:, 3].sum())
-        ws = self._workspace("match", self._L.linetr_match_workspace_bytes(P, sum_nn, 0, sum_k))
-        i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
-        o0, o1, s0, s1 = i64(off_n0), i64(off_n1), i64(off_s0), i64(off_s1)
-        odk, ok0 = off_dk[:-1].copy(), off_k0[:-1].copy()
-        d = self._f32(desc_flat)
-        nat.check(self._L.linetr_match_gathered(self._h, P, nat.np_ptr(dims), d.data_ptr(), nat.np_ptr(o0), s2l_flat.data_ptr(),
-                                                nat.np_ptr(s0), d.data_ptr(), nat.np_ptr(o1), s2l_flat.data_ptr(),
-                                                nat.np_ptr(s1), float(thr), int(bool(mutual)), dk.data_ptr(),
-                                                nat.np_ptr(odk), m01.data_ptr(), nat.np_ptr(ok0), ws.data_ptr(), ws.numel(),
+        key = (P, sum_nn, sum_k)
+        if self.__dict__.get("_match_ws_key") != key:     # the workspace query is a ctypes call: cache it per shape
+            self._match_ws_key = key
+            self._match_ws_bytes = self._L.linetr_match_workspace_bytes(P, sum_nn, 0, sum_k)
+        ws = self._workspace("match", self._match_ws_bytes)
+        c64 = lambda a: np.ascontiguousarray(a, dtype=i64)
+        o0, o1, s0, s1 = c64(off_n0), c64(off_n1), c64(off_s0), c64(off_s1)
+        d = desc_flat if (desc_flat.dtype == torch.float32 and desc_flat.is_contiguous() and desc_flat.device == self.device) \
+            else self._f32(desc_flat)
+        nat.check(self._L.linetr_match_gathered(self._h, P, dims.ctypes.data, d.data_ptr(), o0.ctypes.data, s2l_flat.data_ptr(),
+                                                s0.ctypes.data, d.data_ptr(), o1.ctypes.data, s2l_flat.data_ptr(),
+                                                s1.ctypes.data, float(thr), int(bool(mutual)), dk.data_ptr(),
+                                                off_dk.ctypes.data, m01.data_ptr(), off_k0.ctypes.data, ws.data_ptr(), ws.numel(),
                                                 self._stream()))
         return dk[:int(off_dk[-1])], off_dk, m01[:int(off_k0[-1])], off_k0
 
