@@ -261,7 +261,16 @@ int run_gemm(LinetrHandle* h, hipStream_t st, const float* A, int lda, const flo
   if (it == h->split.end()) return fail(LINETR_E_ARG, "gemm: weight has no split-bf16 copy");
   SplitGemmArgs sa;
   sa.g = g;
-  sa.sk_ws = h->sk_ws; sa.sk_flags = h->sk_flags; sa.sk_epoch = ++h->sk_epoch;
+  if (getenv("LINETR_STREAMK")) {   // opt-in experiment (lt_gemm_split.h): the 32 MB workspace is only allocated when asked for
+    if (!h->sk_ws) {
+      constexpr size_t slots = 256, slot_bytes = 128 * 256 * sizeof(float);
+      LT_HIP(hipMalloc((void**)&h->sk_ws, slots * slot_bytes));
+      LT_HIP(hipMalloc((void**)&h->sk_flags, (slots + 1) * sizeof(unsigned)));
+      LT_HIP(hipMemset(h->sk_flags, 0, (slots + 1) * sizeof(unsigned)));
+      LT_HIP(hipDeviceSynchronize());
+    }
+    sa.sk_ws = h->sk_ws; sa.sk_flags = h->sk_flags; sa.sk_epoch = ++h->sk_epoch;
+  }
   if (h->precision == LINETR_PREC_BF16X3) {
     sa.Wsp = h->split_arena + it->second.off2;
     sa.gWsp = gW * 4;
@@ -612,13 +621,6 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
                          H->split_arena + kv.second.offh, kv.second.rows, kv.second.K);
     }
     LT_LAUNCH_CHECK();
-    LT_HIP(hipDeviceSynchronize());
-  }
-  {  // stream-K workspace: 256 slots of one 128x256 fp32 tile + 257 flags (zeroed once; epochs start at 1)
-    constexpr size_t slots = 256, slot_bytes = 128 * 256 * sizeof(float);
-    LT_HIP(hipMalloc((void**)&H->sk_ws, slots * slot_bytes));
-    LT_HIP(hipMalloc((void**)&H->sk_flags, (slots + 1) * sizeof(unsigned)));
-    LT_HIP(hipMemset(H->sk_flags, 0, (slots + 1) * sizeof(unsigned)));
     LT_HIP(hipDeviceSynchronize());
   }
   if (const char* e = getenv("LINETR_PRECISION")) {
@@ -1265,8 +1267,14 @@ struct PinnedRing {
     return 0;
   }
 };
-PinnedRing& staging_ring() {   // leaked: see WorkPool
-  static PinnedRing* r = new PinnedRing();
+PinnedRing& staging_ring() {   // one ring per device (its events belong to the device current at creation); leaked: see WorkPool
+  static PinnedRing* rings[64] = {};
+  static std::mutex m;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(m);
+  PinnedRing*& r = rings[dev & 63];
+  if (!r) r = new PinnedRing();
   return *r;
 }
 

@@ -740,7 +740,8 @@ inline const char* split_tile_name(const GemmArgs& g, int groups, int pl = 3) {
   // short K, wide N, many tiles: the single-buffered 128x128 tile (64 KB of LDS: two or three blocks per CU whose
   // prologues / epilogues overlap each other's main loops) beats the one-block-per-CU pipeline: 25472x768x256 75.5 vs 81 us
   // (and 291208x256x128, the word-MLP layer: 213 vs 228 us)
-  if (pl == 3 && r128 * (g.N / 128) * groups >= 1024 && ((g.K <= 256 && g.N >= 768) || g.K <= 128)) return "128x128s";
+  static const bool no128s = getenv("LINETR_NO_TILE128S") != nullptr;   // tuning aid
+  if (!no128s && pl == 3 && r128 * (g.N / 128) * groups >= 1024 && ((g.K <= 256 && g.N >= 768) || g.K <= 128)) return "128x128s";
   if (g.N % 256 == 0 && r128 * (g.N / 256) * groups >= 140) return "128x256";
   if (g.N % 256 != 0 && (int64_t)cdiv(g.M, 256) * (g.N / 128) * groups >= 192) return "256x128";
   if (r64 * (g.N / 64) * groups <= 768) return "64x64";
