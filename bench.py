@@ -309,7 +309,8 @@ PMC_KERNEL_NAMES = {   # profile class -> kernel symbol prefix in profiles/<tag>
     "gemm_bf16x6_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 3, true, 0",
     "gemm_bf16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 0",
     "gemm_f16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 1",
-    "gemm_bf16x6_32x32k4": "void lt::gemm_split_small_kernel<3, 0>",
+    "gemm_bf16x6_128x128s": "void lt::gemm_split_kernel<128, 128, 2, 2, 3, false, 0",
+    "gemm_bf16x6_32x32k4": "void lt::gemm_split_small_kernel<3, 0",
     "gemm_f32_128x128": "void lt::gemm_kernel<128, 128, 2, 2>",
     "sig_attn_bf16x6": "void lt::sig_attn_split_kernel<8>",
 }
