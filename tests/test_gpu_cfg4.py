@@ -142,3 +142,37 @@ def test_match_empty_side(eng):
     s = torch.arange(5, dtype=torch.int32, device="cuda")
     dk, off, m01 = eng.match(d, np.array([0, 5]), s, np.array([0, 5]), d[:0], np.array([0, 0]), s[:0], np.array([0, 0]), 0.8, True)
     assert (m01.cpu().numpy() == -1).all() and dk.numel() == 0
+
+
+def test_rccl_single_rank_allgather_and_global_match(eng):
+    """The collective itself on the device: torch.distributed backend 'nccl' (= RCCL on ROCm) with ONE rank -- all this box
+    has -- all-gathers the slab of a small batch and the global matcher reads the gathered buffer.  (World sizes 2 and 4
+    are covered on CPU with gloo in tests/test_distributed_cpu.py; a real multi-GPU run has never been possible here.)"""
+    import socket
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    try:
+        lines = [synth.synth_lines(900 + i, 50, 480, 640) for i in range(4)]
+        maps = [synth.synth_dense_maps(900 + i, 480, 640) for i in range(4)]
+        off = np.concatenate([[0], np.cumsum([len(l) for l in lines])]).astype(np.int32)
+        tb, ld = eng.describe_lines(np.concatenate(lines), off, torch.cat([m[0] for m in maps]).cuda(),
+                                    torch.cat([m[1] for m in maps]).cuda(), **KW)
+        slab = parallel.pack_descriptors(ld, tb.cu_n, 4, tb.N, cu_k=tb.cu_k, sub2line=tb.sub2line,
+                                         d_cu_n=tb.extra.get("d_cu_n"), d_cu_k=tb.extra.get("d_cu_k"))
+        work, gathered = parallel.allgather_descriptors(slab, async_op=True)
+        work.wait()
+        assert gathered.shape == (1, parallel.slab_rows(4, tb.N), 256) and torch.equal(gathered[0], slab)
+        gs = parallel.GatheredSet(gathered, 4, tb.N)
+        dk, off_dk, m01, off_k0 = parallel.global_match(eng, gs, [(0, 0), (0, 2)], [(0, 1), (0, 3)], 0.8, True)
+        n, k = np.diff(tb.cu_n), np.diff(tb.cu_k)
+        ref = eng.match(torch.cat([ld[tb.cu_n[0]:tb.cu_n[1]], ld[tb.cu_n[2]:tb.cu_n[3]]]), np.array([0, n[0], n[0] + n[2]]),
+                        torch.cat([tb.sub2line[tb.cu_n[0]:tb.cu_n[1]], tb.sub2line[tb.cu_n[2]:tb.cu_n[3]]]),
+                        np.array([0, k[0], k[0] + k[2]]),
+                        torch.cat([ld[tb.cu_n[1]:tb.cu_n[2]], ld[tb.cu_n[3]:tb.cu_n[4]]]), np.array([0, n[1], n[1] + n[3]]),
+                        torch.cat([tb.sub2line[tb.cu_n[1]:tb.cu_n[2]], tb.sub2line[tb.cu_n[3]:tb.cu_n[4]]]),
+                        np.array([0, k[1], k[1] + k[3]]), 0.8, True)
+        assert torch.equal(m01, ref[2]) and torch.equal(dk, ref[0])
+    finally:
+        dist.destroy_process_group()
