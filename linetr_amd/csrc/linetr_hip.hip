@@ -27,9 +27,6 @@ using namespace lt;
 
 struct SigLayer {
   const float *Wqkv, *bqkv, *W1, *b1, *W2, *b2;  // merge conv folded into W1
-  // latency path (single pair): this layer's second MLP GEMM and the NEXT layer's q/k/v projection as ONE GEMM over
-  // [z ; hid] -- rows 0..255 = [I | W2] (the residual update z'), rows 256..1023 = [Wqkv' | Wqkv' W2] (q/k/v of z')
-  const float *Wzq = nullptr, *bzq = nullptr;
 };
 
 struct ProfClass {
@@ -513,8 +510,6 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
 
   // ---- signature layers --------------------------------------------------------------------------
   H->sig.resize(cfg->n_sig_layers);
-  std::vector<std::vector<double>> keep_Wqkv(cfg->n_sig_layers), keep_bqkv(cfg->n_sig_layers), keep_W2(cfg->n_sig_layers),
-      keep_b2(cfg->n_sig_layers);
   for (int l = 0; l < cfg->n_sig_layers; ++l) {
     const std::string p = "selfattn.layers." + std::to_string(l) + ".";
     const float* Wp[3];
@@ -570,36 +565,6 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
     place_w(&S.Wqkv, Wqkv, 3 * D, D); place(&S.bqkv, bqkv);
     place_w(&S.W1, W1m, 2 * D, 2 * D); place(&S.b1, b1f);
     place_w(&S.W2, to_d(W2, (size_t)2 * D * D), D, 2 * D); place(&S.b2, to_d(b2, D));
-    keep_Wqkv[l] = Wqkv; keep_bqkv[l] = bqkv; keep_W2[l] = to_d(W2, (size_t)2 * D * D); keep_b2[l] = to_d(b2, D);
-  }
-  // z' = z + W2 hid + b2 and q/k/v' = Wqkv' z' + bqkv' are both linear in [z ; hid] (line_transformer.py:139-154,
-  // :180-183): one [1024 x 768] matrix per layer boundary, built in float64.  Used at single-pair sizes only, where a
-  // launch costs more than the 2.4x flops of this part.
-  for (int l = 0; l + 1 < cfg->n_sig_layers; ++l) {
-    const int KM = 3 * D, NM = 4 * D;
-    std::vector<double> Wm((size_t)NM * KM, 0.0), bm(NM);
-    const std::vector<double>& W2d = keep_W2[l];          // [256][512]
-    const std::vector<double>& Wq = keep_Wqkv[l + 1];     // [768][256]
-    for (int o = 0; o < D; ++o) {
-      Wm[(size_t)o * KM + o] = 1.0;
-      for (int j = 0; j < 2 * D; ++j) Wm[(size_t)o * KM + D + j] = W2d[(size_t)o * 2 * D + j];
-      bm[o] = keep_b2[l][o];
-    }
-    for (int o = 0; o < 3 * D; ++o) {
-      double* row = &Wm[(size_t)(D + o) * KM];
-      const double* wq = &Wq[(size_t)o * D];
-      for (int i = 0; i < D; ++i) row[i] = wq[i];
-      for (int j = 0; j < 2 * D; ++j) {
-        double sacc = 0.0;
-        for (int m = 0; m < D; ++m) sacc += wq[m] * W2d[(size_t)m * 2 * D + j];
-        row[D + j] = sacc;
-      }
-      double bacc = keep_bqkv[l + 1][o];
-      for (int m = 0; m < D; ++m) bacc += wq[m] * keep_b2[l][m];
-      bm[D + o] = bacc;
-    }
-    place_w(&H->sig[l].Wzq, Wm, NM, KM);
-    place(&H->sig[l].bzq, bm);
   }
   {
     const float* W = tm.get("final_proj.weight", D * D, err);
@@ -901,10 +866,8 @@ extern "C" int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int
 // =============================================================================================
 
 namespace {
-constexpr int MERGED_MAX_ROWS = 960;   // cdiv(M,64) * (1024/64) < 256: the sizes the small-M GEMM serves
 struct FwdWs {
   float *a1, *a2, *a3, *a4, *pooled, *att, *fc, *o, *f1, *f2, *l1, *l2, *l3, *l4, *lpos, *zA, *zB, *qkv, *msgp, *msg, *hid;
-  float *zq0, *zq1;   // [N,1024] = [z' | q k v'] of the merged latency path (allocated for N <= MERGED_MAX_ROWS only)
   int* cu;
   int64_t total;
 };
@@ -923,8 +886,6 @@ FwdWs fwd_layout(const LinetrModelConfig& c, int N, int64_t rows, int n_images, 
   w.zA = take((int64_t)N * D); w.zB = take((int64_t)N * D);
   w.qkv = take((int64_t)N * 3 * D); w.msgp = take((int64_t)N * D); w.msg = take((int64_t)N * D);
   w.hid = take((int64_t)N * 2 * D);
-  const int64_t nm = N <= MERGED_MAX_ROWS ? N : 0;
-  w.zq0 = take(nm * 4 * D); w.zq1 = take(nm * 4 * D);
   w.cu = (int*)take(n_images + 1);
   w.total = off;
   return w;
@@ -1059,16 +1020,10 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   }
   // ---- line signature network
   float *z = w.zA, *zn = w.zB;
-  int ldz = D;                       // row stride of z (1024 once it lives in a merged [z' | q k v'] buffer)
-  const float* qkv = w.qkv;
-  int ldq = 3 * D;
-  const bool no_merge = getenv("LINETR_NO_MERGED_QKV") != nullptr;   // tuning / test aid (read per call)
-  const bool merged = !no_merge && N <= MERGED_MAX_ROWS && h->precision != LINETR_PREC_F32 && h->sig.size() > 1;
   const int qtiles = cdiv(max_n, ATT_QT);
   for (size_t l = 0; l < h->sig.size(); ++l) {
     const SigLayer& S = h->sig[l];
-    if (l == 0 || !merged)
-      if ((e = run_gemm(h, st, z, ldz, nullptr, 0, 0, S.Wqkv, S.bqkv, nullptr, 0, w.qkv, 3 * D, N, 3 * D, D, ACT_NONE))) return e;
+    if ((e = run_gemm(h, st, z, D, nullptr, 0, 0, S.Wqkv, S.bqkv, nullptr, 0, w.qkv, 3 * D, N, 3 * D, D, ACT_NONE))) return e;
     {
       double fl = 0;
       for (int i = 0; i < n_images; ++i) { double n = h_cu[i + 1] - h_cu[i]; fl += 2.0 * 2.0 * n * n * D; }
@@ -1076,43 +1031,35 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
       static const bool force_f32_attn = getenv("LINETR_ATTN_F32") != nullptr;
       if (h->precision == LINETR_PREC_F32 || force_f32_attn) {
         ProfScope ps(h, st, "sig_attn", fl, (double)N * D * 16);
-        hipLaunchKernelGGL(sig_attn_kernel, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, qkv, cu_dev, w.msgp, ldq);
+        hipLaunchKernelGGL(sig_attn_kernel, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
       } else {
         ProfScope ps(h, st, "sig_attn_bf16x6", fl, (double)N * D * 16);
         static const bool attn4 = getenv("LINETR_ATTN_4WAVE") != nullptr;   // tuning aid: 128-query blocks
+        // few (image, head) pairs: 64-query blocks, so that a single pair still spreads over 32 CUs instead of 8
         static const bool no_small_attn = getenv("LINETR_NO_SMALL_ATTN") != nullptr;   // tuning aid
         // few (image, head) pairs: 32-query blocks whose 4 waves also split the KV range (a single pair spreads over 56 CUs
         // and the critical path is 2 KV chunks instead of 7)
         if (!attn4 && !no_small_attn && (int64_t)n_images * HEADS * cdiv(max_n, 256) < 64)
-          hipLaunchKernelGGL(sig_attn_small_kernel, dim3(n_images, HEADS, cdiv(max_n, 32)), dim3(256), 0, st, qkv, cu_dev, w.msgp, ldq);
+          hipLaunchKernelGGL(sig_attn_small_kernel, dim3(n_images, HEADS, cdiv(max_n, 32)), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
         else if (attn4 || max_n <= 128)
-          hipLaunchKernelGGL(sig_attn_split_kernel<4>, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, qkv, cu_dev, w.msgp, ldq);
+          hipLaunchKernelGGL(sig_attn_split_kernel<4>, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
         else
-          hipLaunchKernelGGL(sig_attn_split_kernel<8>, dim3(n_images, HEADS, cdiv(max_n, 256)), dim3(512), 0, st, qkv, cu_dev,
-                             w.msgp, ldq);
+          hipLaunchKernelGGL(sig_attn_split_kernel<8>, dim3(n_images, HEADS, cdiv(max_n, 256)), dim3(512), 0, st, w.qkv, cu_dev,
+                             w.msgp);
       }
       LT_LAUNCH_CHECK();
     }
-    if ((e = run_gemm(h, st, z, ldz, w.msgp, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ACT_RELU))) return e;
+    if ((e = run_gemm(h, st, z, D, w.msgp, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ACT_RELU))) return e;
     if (l + 1 == h->sig.size()) break;   // the last layer's second MLP GEMM is folded into the final projection below
-    if (merged) {
-      // single-pair sizes: [z' | q k v'] = [z ; hid] Wzq^T + bzq -- this layer's residual update and the next layer's
-      // projection in one launch (6 launches of ~8 us less per forward)
-      float* nxt = (z == w.zq0) ? w.zq1 : w.zq0;
-      if ((e = run_gemm(h, st, z, ldz, w.hid, 2 * D, D, S.Wzq, S.bzq, nullptr, 0, nxt, 4 * D, N, 4 * D, 3 * D, ACT_NONE))) return e;
-      z = nxt; ldz = 4 * D;
-      qkv = nxt + D; ldq = 4 * D;
-      continue;
-    }
     if ((e = run_gemm(h, st, w.hid, 2 * D, nullptr, 0, 0, S.W2, S.b2, z, D, zn, D, N, D, 2 * D, ACT_NONE))) return e;
     std::swap(z, zn);
   }
   NormSpec l2; l2.mode = 2;      // F.normalize(final_proj(.), dim=1)  (line_transformer.py:245-246)
   if (h->sig.empty()) {
-    if ((e = run_gemm_norm(h, st, z, ldz, nullptr, 0, 0, h->Wfin, h->bfin, nullptr, zn, d_line_desc, N, D, l2))) return e;
+    if ((e = run_gemm_norm(h, st, z, D, nullptr, 0, 0, h->Wfin, h->bfin, nullptr, zn, d_line_desc, N, D, l2))) return e;
   } else {
     // final_proj(z + W2 hid + b2) = [Wfin | Wfin W2] [z ; hid] + (Wfin b2 + bfin): one K = 768 GEMM instead of two launches
-    if ((e = run_gemm_norm(h, st, z, ldz, w.hid, 2 * D, D, h->Wfin2, h->bfin2, nullptr, zn, d_line_desc, N, 3 * D, l2))) return e;
+    if ((e = run_gemm_norm(h, st, z, D, w.hid, 2 * D, D, h->Wfin2, h->bfin2, nullptr, zn, d_line_desc, N, 3 * D, l2))) return e;
   }
   return LINETR_OK;
 }

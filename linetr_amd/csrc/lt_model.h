@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__
 // (models/line_transformer.py:132-154).  Flash-style, fp32 MFMA, no N x N matrix in memory.
 //
 // grid (image, head, q-tile of 128), block 256 = 4 wave64, wave w owns 32 query rows.
-// qkv rows (row stride ldq floats, 768 when the projection has its own buffer) = [q | k | v], each head-major (c = h*64+d; the reference's interleaved c = d*4+h is
+// qkv [N,768] = [q | k | v], each head-major (c = h*64+d; the reference's interleaved c = d*4+h is
 // undone by permuting weight rows at load time) and q pre-scaled by 1/8 (exact, power of two).
 //
 // Per 32-row kv chunk and wave:
@@ -601,7 +601,7 @@ constexpr int ATT_KT = 64;    // kv rows staged per iteration
 constexpr int ATT_KS = DH + 4;
 
 __global__ __launch_bounds__(256) void sig_attn_kernel(const float* __restrict__ qkv, const int* __restrict__ cu_sub,
-                                                       float* __restrict__ out /*[N][256] head-major*/, int ldq = 768) {
+                                                       float* __restrict__ out /*[N][256] head-major*/) {
   __shared__ __attribute__((aligned(16))) float Ks[ATT_KT * ATT_KS];
   __shared__ __attribute__((aligned(16))) float Vs[ATT_KT * DH];
   const int img = blockIdx.x, head = blockIdx.y;
@@ -612,12 +612,12 @@ __global__ __launch_bounds__(256) void sig_attn_kernel(const float* __restrict__
   const int h2 = lane >> 5, lq = lane & 31;
   const int q = q0 + wave * 32 + lq;
   const bool wave_active = q0 + wave * 32 < Ni;  // wave-uniform
-  const float* base = qkv + (int64_t)n0 * ldq;
+  const float* base = qkv + (int64_t)n0 * 768;
 
   f32x4 qf[8];
   {
     const int qr = q < Ni ? q : Ni - 1;
-    const float* qp = base + (int64_t)qr * ldq + head * DH + h2 * 4;
+    const float* qp = base + (int64_t)qr * 768 + head * DH + h2 * 4;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const f32x4*>(qp + kk * 8);
   }
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void sig_attn_kernel(const float* __restrict__
       const int kv = t0 + r;
       f32x4 kx = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
       if (kv < Ni) {
-        const float* p = base + (int64_t)kv * ldq + head * DH + sc4;
+        const float* p = base + (int64_t)kv * 768 + head * DH + sc4;
         kx = *reinterpret_cast<const f32x4*>(p + 256);
         vx = *reinterpret_cast<const f32x4*>(p + 512);
       }
@@ -756,7 +756,7 @@ __device__ __forceinline__ void v_frags_tr(unsigned base, u32x2 (&o)[3][2]) {
 template <int NW>
 __global__ __launch_bounds__(NW * 64, (NW == 8 && LT_ATTN_OCC2) ? 4 : 1) void sig_attn_split_kernel(const float* __restrict__ qkv,
                                                                  const int* __restrict__ cu_sub,
-                                                                 float* __restrict__ out /*[N][256] head-major*/, int ldq = 768) {
+                                                                 float* __restrict__ out /*[N][256] head-major*/) {
   __shared__ __attribute__((aligned(16))) unsigned char Ks[ATT_KT * ATS_RK];
   __shared__ __attribute__((aligned(16))) unsigned char Vs[ATT_KT * ATS_RV];
   const int img = blockIdx.x, head = blockIdx.y;
@@ -767,12 +767,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && LT_ATTN_OCC2) ? 4 : 1) void si
   const int h2 = lane >> 5, lq = lane & 31;
   const int q = q0 + wave * 32 + lq;
   const bool wave_active = q0 + wave * 32 < Ni;  // wave-uniform
-  const float* base = qkv + (int64_t)n0 * ldq;
+  const float* base = qkv + (int64_t)n0 * 768;
 
   bf16x8 qf[4][3];
   {
     const int qr = q < Ni ? q : Ni - 1;
-    const float* qp = base + (int64_t)qr * ldq + head * DH + h2 * 8;
+    const float* qp = base + (int64_t)qr * 768 + head * DH + h2 * 8;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + s * 16);
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && LT_ATTN_OCC2) ? 4 : 1) void si
       kreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (kv < Ni) {
-        const float* p = base + (int64_t)kv * ldq + head * DH + sc4;
+        const float* p = base + (int64_t)kv * 768 + head * DH + sc4;
         kreg[i] = *reinterpret_cast<const f32x4*>(p + 256);
         vreg[i] = *reinterpret_cast<const f32x4*>(p + 512);
       }
@@ -947,7 +947,7 @@ constexpr int ATL_RV = 3 * 64 + 8;     // V^T plane row stride (bytes): [d][3][3
 constexpr int ATL_WAVE_BYTES = 32 * ATL_RK + DH * ATL_RV;   // 12 800 + 12 800
 
 __global__ __launch_bounds__(256) void sig_attn_small_kernel(const float* __restrict__ qkv, const int* __restrict__ cu_sub,
-                                                             float* __restrict__ out /*[N][256] head-major*/, int ldq = 768) {
+                                                             float* __restrict__ out /*[N][256] head-major*/) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * ATL_WAVE_BYTES];
   const int img = blockIdx.x, head = blockIdx.y;
   const int n0 = cu_sub[img], Ni = cu_sub[img + 1] - n0;
@@ -956,14 +956,14 @@ __global__ __launch_bounds__(256) void sig_attn_small_kernel(const float* __rest
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h2 = lane >> 5, lq = lane & 31;
   const int q = q0 + lq;
-  const float* base = qkv + (int64_t)n0 * ldq;
+  const float* base = qkv + (int64_t)n0 * 768;
   unsigned char* Ks = lds + wave * ATL_WAVE_BYTES;
   unsigned char* Vt = Ks + 32 * ATL_RK;
 
   bf16x8 qf[4][3];
   {
     const int qr = q < Ni ? q : Ni - 1;
-    const float* qp = base + (int64_t)qr * ldq + head * DH + h2 * 8;
+    const float* qp = base + (int64_t)qr * 768 + head * DH + h2 * 8;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + s * 16);
@@ -996,7 +996,7 @@ __global__ __launch_bounds__(256) void sig_attn_small_kernel(const float* __rest
       kreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (kv < Ni) {
-        const float* p = base + (int64_t)kv * ldq + head * DH + sc4;
+        const float* p = base + (int64_t)kv * 768 + head * DH + sc4;
         kreg[i] = *reinterpret_cast<const f32x4*>(p + 256);
         vreg[i] = *reinterpret_cast<const f32x4*>(p + 512);
       }

@@ -258,28 +258,3 @@ def test_fused_describe_long_tokens_and_ragged_batch():
     tbd, ldd = run_native(eng, rows, dd3, ds3, hw, cfg)
     assert list(np.diff(tb3.cu_n))[1] == 0
     assert (ld3 - ldd).abs().max().item() < 5e-6
-
-
-def test_merged_residual_and_projection_gemm_single_pair(monkeypatch):
-    """Latency path: at single-pair sizes a signature layer's second MLP GEMM and the next layer's q/k/v projection run
-    as ONE GEMM over [z ; hid] (both are linear in it; weights folded in float64 at load).  Against the unmerged launch
-    sequence (LINETR_NO_MERGED_QKV=1) on the cfg2 golden pair: descriptors agree to fp32 round-off and both are within
-    1e-4 of the reference."""
-    from linetr_amd.engine import Engine
-    g = load("cfg2_pair")
-    eng = Engine(synth.calibrated_state_dict(), "cuda:0")
-    lines = [g["a_lines"], g["b_lines"]]
-    maps = [synth.synth_dense_maps(int(g[f"{t}_seed"]), 480, 640) for t in "ab"]
-    dd = torch.cat([m[0] for m in maps]).cuda()
-    ds = torch.cat([m[1] for m in maps]).cuda()
-    off = np.array([0, len(lines[0]), len(lines[0]) + len(lines[1])], np.int32)
-    kw = dict(remove_borders=8, min_length=16, max_keylines=-1, token_distance=8, max_tokens=21)
-    monkeypatch.delenv("LINETR_NO_MERGED_QKV", raising=False)
-    tb, merged = eng.describe_lines(np.concatenate(lines), off, dd, ds, **kw)
-    monkeypatch.setenv("LINETR_NO_MERGED_QKV", "1")
-    _, plain = eng.describe_lines(np.concatenate(lines), off, dd, ds, **kw)
-    assert merged.shape == plain.shape == (398, 256)
-    assert (merged - plain).abs().max().item() < 2e-6
-    for i, t in enumerate("ab"):
-        want = g[f"{t}_line_desc"][0].T
-        assert np.abs(merged[tb.cu_n[i]:tb.cu_n[i + 1]].cpu().numpy() - want).max() < 1e-4
