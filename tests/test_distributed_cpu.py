@@ -197,3 +197,36 @@ def test_homography_sampler_properties():
     assert np.abs(near - np.eye(3)).max() < 0.1
     full = synth.pixel_homography(np.random.RandomState(3), 480, 640)
     assert np.abs(full - np.eye(3)).max() > 0.01
+
+
+def test_warped_dense_maps_follow_the_homography():
+    """cfg4 generator: the dense maps of view 1 are view 0's maps seen through M (x1 ~ M x0).  At random interior points
+    the descriptor sampled from view 1 at M x0 has cosine > 0.9 with view 0's descriptor at x0 (bilinear resampling +
+    5 % noise), and the score maps agree the same way -- i.e. the warp goes in the direction the line end points do."""
+    import torch.nn.functional as F
+    from linetr_amd import synth
+    H, W = 240, 320
+    rs = np.random.RandomState(5)
+    m = synth.pixel_homography(rs, H, W, strength=0.3)
+    g = torch.Generator().manual_seed(3)
+    # smooth maps (upsampled low-resolution noise) so that bilinear resampling is meaningful
+    dd0 = F.normalize(F.interpolate(torch.randn(1, 256, H // 32, W // 32, generator=g), size=(H // 8, W // 8), mode="bilinear",
+                                    align_corners=False), dim=1)
+    ds0 = F.interpolate(torch.rand(1, 1, H // 16, W // 16, generator=g), size=(H, W), mode="bilinear", align_corners=False)[0]
+    dd1, ds1 = synth.warp_dense_maps(dd0, ds0, m, noise=0.05, seed=1)
+    assert dd1.shape == dd0.shape and ds1.shape == ds0.shape
+    assert ((dd1.norm(dim=1) - 1).abs() < 1e-5).all()
+    pts0 = np.stack([rs.uniform(40, W - 40, 200), rs.uniform(40, H - 40, 200)], axis=1)
+    pts1 = synth.warp_points(m, pts0)
+    ok = (pts1[:, 0] > 16) & (pts1[:, 0] < W - 16) & (pts1[:, 1] > 16) & (pts1[:, 1] < H - 16)
+    assert ok.sum() > 50
+
+    def sample_desc(dd, pts):          # nearest cell centre of the 1/8 map
+        cx = np.clip(np.round((pts[:, 0] - 3.5) / 8).astype(int), 0, W // 8 - 1)
+        cy = np.clip(np.round((pts[:, 1] - 3.5) / 8).astype(int), 0, H // 8 - 1)
+        return dd[0][:, cy, cx].t()
+    cos = (sample_desc(dd0, pts0[ok]) * sample_desc(dd1, pts1[ok])).sum(1)
+    assert cos.median().item() > 0.9 and (cos > 0.7).float().mean().item() > 0.9
+    s0 = ds0[0][np.round(pts0[ok][:, 1]).astype(int), np.round(pts0[ok][:, 0]).astype(int)]
+    s1 = ds1[0][np.round(pts1[ok][:, 1]).astype(int), np.round(pts1[ok][:, 0]).astype(int)]
+    assert (s0 - s1).abs().median().item() < 0.05
