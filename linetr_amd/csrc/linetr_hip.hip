@@ -14,6 +14,7 @@
 #include "lt_gemm_split.h"
 #include "lt_gemm_split16.h"
 #include "lt_gemm_small.h"
+#include "lt_mlp_fused.h"
 #include "lt_match.h"
 #include "lt_model.h"
 #include "lt_producer.h"
@@ -27,6 +28,7 @@ using namespace lt;
 
 struct SigLayer {
   const float *Wqkv, *bqkv, *W1, *b1, *W2, *b2;  // merge conv folded into W1
+  const float* W2p = nullptr;                    // W2 with K permuted inside 16-groups (lt_mlp_fused.h)
 };
 
 struct ProfClass {
@@ -311,6 +313,30 @@ int run_gemm_norm(LinetrHandle* h, hipStream_t st, const float* A, int lda, cons
   return 0;
 }
 
+// z' = z + W2 relu(W1 [z ; msg] + b1) + b2 in one launch (split-bf16 modes only)
+int run_sig_mlp(LinetrHandle* h, hipStream_t st, const float* z, const float* msg, const SigLayer& S, float* out, int M) {
+  auto i1 = h->split.find(S.W1), i2 = h->split.find(S.W2p);
+  if (i1 == h->split.end() || i2 == h->split.end()) return fail(LINETR_E_ARG, "sig_mlp: weight has no split copy");
+  SigMlpArgs a;
+  a.z = z; a.ldz = D; a.msg = msg; a.ldm = D; a.b1 = S.b1; a.b2 = S.b2; a.out = out; a.ldo = D; a.M = M;
+  const double fl = 2.0 * M * (2.0 * D * 2 * D + 2.0 * D * D), by = 4.0 * M * 3.0 * D;
+  if (h->precision == LINETR_PREC_BF16X3) {
+    a.W1sp = h->split_arena + i1->second.off2; a.W2sp = h->split_arena + i2->second.off2;
+    ProfScope ps(h, st, "sig_mlp_bf16x3", fl, by);
+    sig_mlp_fused_launch<2, 0>(a, st);
+  } else if (h->precision == LINETR_PREC_F16X3) {
+    a.W1sp = h->split_arena + i1->second.offh; a.W2sp = h->split_arena + i2->second.offh;
+    ProfScope ps(h, st, "sig_mlp_f16x3", fl, by);
+    sig_mlp_fused_launch<2, 1>(a, st);
+  } else {
+    a.W1sp = h->split_arena + i1->second.off3; a.W2sp = h->split_arena + i2->second.off3;
+    ProfScope ps(h, st, "sig_mlp_bf16x6", fl, by);
+    sig_mlp_fused_launch<3, 0>(a, st);
+  }
+  LT_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- float64 weight preparation ---------------------------------------------------------------
 
 struct TensorMap {
@@ -565,6 +591,12 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
     place_w(&S.Wqkv, Wqkv, 3 * D, D); place(&S.bqkv, bqkv);
     place_w(&S.W1, W1m, 2 * D, 2 * D); place(&S.b1, b1f);
     place_w(&S.W2, to_d(W2, (size_t)2 * D * D), D, 2 * D); place(&S.b2, to_d(b2, D));
+    {
+      std::vector<double> W2perm((size_t)2 * D * D);
+      for (int o = 0; o < D; ++o)
+        for (int k = 0; k < 2 * D; ++k) W2perm[(size_t)o * 2 * D + k] = W2[(size_t)o * 2 * D + sig_mlp_kperm(k)];
+      place_w(&S.W2p, W2perm, D, 2 * D);
+    }
   }
   {
     const float* W = tm.get("final_proj.weight", D * D, err);
@@ -1021,6 +1053,9 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   // ---- line signature network
   float *z = w.zA, *zn = w.zB;
   const int qtiles = cdiv(max_n, ATT_QT);
+  // layers but the last: W1 -> ReLU -> W2 + residual in one kernel, hidden activations in registers (lt_mlp_fused.h)
+  const bool fused_sig_mlp = h->precision != LINETR_PREC_F32 && N >= 4096 && !getenv("LINETR_NO_FUSED_SIG_MLP") &&
+                             getenv("LINETR_FUSED_SIG_MLP") != nullptr;   // opt-in while it is being measured
   for (size_t l = 0; l < h->sig.size(); ++l) {
     const SigLayer& S = h->sig[l];
     if ((e = run_gemm(h, st, z, D, nullptr, 0, 0, S.Wqkv, S.bqkv, nullptr, 0, w.qkv, 3 * D, N, 3 * D, D, ACT_NONE))) return e;
@@ -1048,6 +1083,11 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
                              w.msgp);
       }
       LT_LAUNCH_CHECK();
+    }
+    if (fused_sig_mlp && l + 1 < h->sig.size()) {
+      if ((e = run_sig_mlp(h, st, z, w.msgp, S, zn, N))) return e;
+      std::swap(z, zn);
+      continue;
     }
     if ((e = run_gemm(h, st, z, D, w.msgp, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ACT_RELU))) return e;
     if (l + 1 == h->sig.size()) break;   // the last layer's second MLP GEMM is folded into the final projection below

@@ -135,3 +135,26 @@ def test_fused_row_norm_epilogue_equals_separate_kernel(eng, monkeypatch):
     assert fused.shape == plain.shape and fused.shape[0] == 128 * 199
     assert (fused - plain).abs().max().item() <= 2e-7
     assert ((fused.norm(dim=1) - 1).abs() < 1e-5).all()
+
+
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3", "f16x3"])
+def test_fused_signature_mlp_equals_two_gemms(eng, monkeypatch, mode):
+    """W1 -> ReLU -> W2 + residual of a signature layer in ONE kernel (lt_mlp_fused.h: transposed products, hidden
+    activations in registers, W2's K index permuted to the MFMA C/D register order) against the two tiled GEMMs.  Same
+    split planes and cross terms; only the fp32 summation order inside a product differs."""
+    _, cat, off, dd, ds = batch_inputs(128)
+    eng.set_precision(mode)
+    try:
+        monkeypatch.delenv("LINETR_FUSED_SIG_MLP", raising=False)
+        monkeypatch.setenv("LINETR_NO_FUSED_SIG_MLP", "1")
+        _, plain = describe(eng, cat, off, dd, ds)
+        plain = plain.clone()
+        monkeypatch.delenv("LINETR_NO_FUSED_SIG_MLP", raising=False)
+        monkeypatch.setenv("LINETR_FUSED_SIG_MLP", "1")
+        _, fused = describe(eng, cat, off, dd, ds)
+    finally:
+        eng.set_precision("bf16x6")
+    assert fused.shape == plain.shape and fused.shape[0] == 128 * 199
+    tol = {"bf16x6": 1e-6, "bf16x3": 5e-5, "f16x3": 5e-6}[mode]
+    assert (fused - plain).abs().max().item() <= tol
+    assert ((fused.norm(dim=1) - 1).abs() < 1e-5).all()
