@@ -132,8 +132,12 @@ class WorkPool {
 
  private:
   WorkPool() {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    // one process per GPU: the ranks of a node share its cores (LOCAL_WORLD_SIZE is set by torch.distributed.run);
+    // LINETR_HOST_THREADS overrides (0 = run the pre-filter on the calling thread)
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    if (const char* lw = getenv("LOCAL_WORLD_SIZE")) hw /= (unsigned)std::max(1, atoi(lw));
     n_workers_ = (int)std::min(15u, hw > 1 ? hw / 2 : 0u);
+    if (const char* ht = getenv("LINETR_HOST_THREADS")) n_workers_ = std::max(0, std::min(63, atoi(ht) - 1));
     for (int i = 0; i < n_workers_; ++i) std::thread([this] { loop(); }).detach();
   }
   void drain() {
