@@ -34,6 +34,14 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <int PL, int FMT = 0>
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&out)[PL]) {
   float r0 = x0, r1 = x1;
+#ifdef LT_ABLATE_SPLIT   // timing experiment only (wrong numerics): one conversion, no remainders -- the VALU cost a pre-split operand would save
+  {
+    const bf16x2 h0 = __builtin_convertvector(f32x2{r0, r1}, bf16x2);
+#pragma unroll
+    for (int p = 0; p < PL; ++p) out[p] = __builtin_bit_cast(unsigned, h0);
+    return;
+  }
+#endif
 #pragma unroll
   for (int p = 0; p < PL; ++p) {
     if constexpr (FMT == 0) {
