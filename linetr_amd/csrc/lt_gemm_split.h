@@ -66,6 +66,9 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&out)[P
 
 template <int FMT>
 __device__ __forceinline__ f32x16 mfma_split(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+#ifdef LT_ABLATE_MFMA    // timing experiment only: everything but the MFMAs
+  if (blockDim.y != 7) return c;
+#endif
   if constexpr (FMT == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -560,7 +563,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] += rres[it][c];
       }
+#ifdef LT_ABLATE_STORE   // timing experiment only: the output never leaves the CU
+      if (row < g.M && blockDim.y == 7) *reinterpret_cast<f32x4*>(Y + (int64_t)row * g.ldy + gcol) = v;
+#else
       if (row < g.M) *reinterpret_cast<f32x4*>(Y + (int64_t)row * g.ldy + gcol) = v;
+#endif
     }
     return;
   }
