@@ -743,7 +743,7 @@ inline bool small_gemm_wins(const GemmArgs& g, int groups);
 // Tile choice, from the measured table tools/gemm_tiles_probe.py prints (bf16x6, MI355X, profiles/r02_tiles_probe.txt):
 //   * 8-wave 128x256 blocks (fixed-order pipeline, one block per CU) as soon as there are ~140 of them: 9584x512x512 runs
 //     43 us on 150 such blocks against 64 us on 300 128x128 blocks;
-//   * below that the 4-wave 64x64 tile (53 KB of LDS: three blocks per CU, deep register prefetch) while its grid fits the
+//   * below that the 4-wave 64x64 tile (53 KB of LDS and 156 VGPRs: three blocks per CU) while its grid fits the
 //     768 resident slots, then 64x128 (two per CU, 512 slots), then 64x256;
 //   * single-pair sizes go to the barrier-free K-split kernel (lt_gemm_small.h).
 inline const char* split_tile_name(const GemmArgs& g, int groups, int pl = 3) {
@@ -784,9 +784,11 @@ inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st
   else if (!strcmp(tile, "128x256") && g.N % 256 == 0) gemm_split_launch_t<128, 256, 2, 4, PL, true, FMT, PL == 3 ? 2 : 1, true>(sa, groups, st);
   else if (!strcmp(tile, "64x256") && g.N % 256 == 0) gemm_split_launch_t<64, 256, 1, 4, PL, true, FMT, PL == 3 ? 2 : 1, true>(sa, groups, st);
   else if (!strcmp(tile, "128x128")) gemm_split_launch_t<128, 128, 2, 2, PL, true, FMT>(sa, groups, st);
-  else if (!strcmp(tile, "128x128s")) gemm_split_launch_t<128, 128, 2, 2, PL, false, FMT>(sa, groups, st);   // single LDS buffer: 3 blocks per CU
+  else if (!strcmp(tile, "128x128s")) gemm_split_launch_t<128, 128, 2, 2, PL, false, FMT>(sa, groups, st);   // single LDS buffer; 212 VGPRs: two blocks per CU
   else if (PL == 2 && !strcmp(tile, "256x256") && g.N % 256 == 0) gemm_split_launch_t<256, 256, 4, 2, 2, true, FMT>(sa, groups, st);
-  else if (!strcmp(tile, "64x64")) gemm_split_launch_t<64, 64, 2, 2, PL, true, FMT, 4>(sa, groups, st);
+  // 64x64: three tiles of register prefetch = 156 VGPRs = THREE blocks per CU (53 KB of LDS each); with four it was 172
+  // VGPRs = two blocks: 9584 x 256 x {256, 512, 1024} 20.9 / 33.2 / 58.8 us -> 18.6 / 29.8 / 52.8 us
+  else if (!strcmp(tile, "64x64")) gemm_split_launch_t<64, 64, 2, 2, PL, true, FMT, 3>(sa, groups, st);
   else gemm_split_launch_t<64, 128, 2, 2, PL, true, FMT, 3>(sa, groups, st);
   LT_LAUNCH_CHECK();
   return 0;
