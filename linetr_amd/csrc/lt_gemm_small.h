@@ -19,7 +19,7 @@
 
 namespace lt {
 
-template <int PL, int FMT, int NWV = 4>
+template <int PL, int FMT, int NWV = 4, int NBUF = (NWV == 4 ? 2 : 1)>
 __global__ __launch_bounds__(NWV * 64) void gemm_split_small_kernel(SplitGemmArgs sa) {
   const GemmArgs& g = sa.g;
   constexpr int RS = PL * 64 + 16;                 // W row stride in LDS (bytes), as in gemm_split_kernel
@@ -27,7 +27,8 @@ __global__ __launch_bounds__(NWV * 64) void gemm_split_small_kernel(SplitGemmArg
   constexpr int A_BYTES = 32 * AS * 4, W_BYTES = 32 * RS;
   constexpr int W_PCS = PL * 4;                    // 16-byte pieces per W row and K tile
   constexpr int W_LD = (32 * W_PCS + 63) / 64;     // W load instructions per K tile
-  constexpr int NBUF = NWV == 4 ? 2 : 1;           // 8 waves: one staging buffer each (LDS), every wave has half the K tiles
+  // NBUF staging buffers per wave.  8 waves: one each (LDS), every wave has half the K tiles; 4 waves with ONE buffer is
+  // the 62 KB variant of which two blocks share a CU (grids of more than one block per CU, see the launcher)
   __shared__ __attribute__((aligned(16))) unsigned char stage[NWV][NBUF][A_BYTES + W_BYTES];   // [wave][buffer]
   __shared__ float red[NWV][32 * 33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -170,7 +171,13 @@ inline void gemm_split_small_launch(const SplitGemmArgs& sa, int groups, hipStre
   dim3 grid((unsigned)((sa.g.N / 32) * cdiv(sa.g.M, 32)), (unsigned)groups);
   // K >= 256: eight waves split K (half the loads, splits and MFMAs on every wave's critical path)
   static const bool w4 = getenv("LINETR_SMALL_GEMM_4WAVE") != nullptr;   // tuning aid
-  if (!w4 && sa.g.K >= 256) hipLaunchKernelGGL((gemm_split_small_kernel<PL, FMT, 8>), grid, dim3(512), 0, st, sa);
+  static const bool no2 = getenv("LINETR_SMALL_GEMM_NO_2PERCU") != nullptr;   // tuning aid
+  // the 8-wave block claims 121 KB of LDS = one block per CU: a grid of 257..512 blocks (q/k/v of a single pair: 312) would
+  // run two rounds; four waves with one staging buffer (62 KB) put two blocks on a CU and finish it in one
+  const int64_t blocks = (int64_t)grid.x * grid.y;
+  if (!no2 && !w4 && sa.g.K >= 256 && blocks > 256 && blocks <= 512)
+    hipLaunchKernelGGL((gemm_split_small_kernel<PL, FMT, 4, 1>), grid, dim3(256), 0, st, sa);
+  else if (!w4 && sa.g.K >= 256) hipLaunchKernelGGL((gemm_split_small_kernel<PL, FMT, 8>), grid, dim3(512), 0, st, sa);
   else hipLaunchKernelGGL((gemm_split_small_kernel<PL, FMT, 4>), grid, dim3(256), 0, st, sa);
 }
 

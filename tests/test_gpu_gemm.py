@@ -120,11 +120,13 @@ def test_fused_posenc_layers_vs_torch(rows):
 
 
 @pytest.mark.parametrize("mode,tol", [("f32", 2e-6), ("bf16x6", 2e-6), ("f16x3", 4e-6), ("bf16x3", 3e-5)])
-@pytest.mark.parametrize("M,N,K,act", [(398, 512, 512, 1), (33, 256, 1024, 2), (1, 768, 256, 0), (400, 64, 544, 3)])
+@pytest.mark.parametrize("M,N,K,act", [(398, 512, 512, 1), (33, 256, 1024, 2), (1, 768, 256, 0), (400, 64, 544, 3),
+                                       (398, 768, 256, 0), (500, 768, 512, 1)])
 def test_gemm_small_m_kernel(eng, mode, tol, M, N, K, act):
     """Single-pair sizes: the barrier-free K-split kernel (lt_gemm_small.h: 32 x 32 tiles, the block's 4 waves split K,
     fragments straight from global memory) with every epilogue piece, ragged M, K = 17 tiles (uneven split), against
-    float64.  In f32 mode the same shapes run on the tiled fp32 kernel."""
+    float64.  The last two shapes have 312 / 384 blocks: the 4-wave, one-staging-buffer variant of which two blocks share a CU.
+    In f32 mode the same shapes run on the tiled fp32 kernel."""
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     A = torch.randn(M, K, device="cuda", generator=g)
     W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
