@@ -752,12 +752,13 @@ inline const char* split_tile_name(const GemmArgs& g, int groups, int pl = 3) {
   static const bool no112 = getenv("LINETR_NO_TILE112") != nullptr;   // tuning aid
   if (!no112 && pl == 2 && split16_wins(g, groups)) return "112x256";   // saves a round of blocks (lt_gemm_split16.h)
   const int64_t r128 = cdiv(g.M, 128), r64 = cdiv(g.M, 64);
-  // short K, wide N, many tiles: the single-buffered 128x128 tile (64 KB of LDS: two or three blocks per CU whose
-  // prologues / epilogues overlap each other's main loops) beats the one-block-per-CU pipeline: 25472x768x256 75.5 vs 81 us
-  // (and 291208x256x128, the word-MLP layer: 213 vs 228 us)
+  // short K, wide N, many tiles: the single-buffered 128x128 tile (64 KB of LDS, eight waves at 102 VGPRs: two blocks =
+  // 4 waves per SIMD whose prologues / epilogues overlap each other's main loops) beats the one-block-per-CU pipeline:
+  // 25472x768x256 73 vs 80 us, 291208x256x128 (the word-MLP layer) 192 vs 225 us; in the cfg3 step its nine launches take
+  // 0.75 ms (0.85 ms with the earlier four-wave layout at 212 VGPRs = 2 waves per SIMD).  For the other shapes the two
+  // tiles are level inside the step.
   static const bool no128s = getenv("LINETR_NO_TILE128S") != nullptr;   // tuning aid
   if (!no128s && pl == 3 && r128 * (g.N / 128) * groups >= 1024 && ((g.K <= 256 && g.N >= 768) || g.K <= 128)) return "128x128s";
-  if (g.N % 256 == 0 && r128 * (g.N / 256) * groups >= 140) return "128x256";
   if (g.N % 256 != 0 && (int64_t)cdiv(g.M, 256) * (g.N / 128) * groups >= 192) return "256x128";
   if (r64 * (g.N / 64) * groups <= 768) return "64x64";
   if (r64 * (g.N / 128) * groups <= 512) return "64x128";
@@ -781,10 +782,18 @@ inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st
     if (nopipe) gemm_split_launch_t<256, 128, 4, 2, PL, true, FMT>(sa, groups, st);
     else gemm_split_launch_t<256, 128, 4, 2, PL, true, FMT, 1, true>(sa, groups, st);
   }
+  // (16 waves of 32 x 64 or 64 x 32 on this tile, without the software pipeline, run the cfg3 step within noise of this
+  // one: at one block per CU the extra waves meet at the same barriers)
   else if (!strcmp(tile, "128x256") && g.N % 256 == 0) gemm_split_launch_t<128, 256, 2, 4, PL, true, FMT, PL == 3 ? 2 : 1, true>(sa, groups, st);
   else if (!strcmp(tile, "64x256") && g.N % 256 == 0) gemm_split_launch_t<64, 256, 1, 4, PL, true, FMT, PL == 3 ? 2 : 1, true>(sa, groups, st);
   else if (!strcmp(tile, "128x128")) gemm_split_launch_t<128, 128, 2, 2, PL, true, FMT>(sa, groups, st);
-  else if (!strcmp(tile, "128x128s")) gemm_split_launch_t<128, 128, 2, 2, PL, false, FMT>(sa, groups, st);   // single LDS buffer; 212 VGPRs: two blocks per CU
+  // single LDS buffer, EIGHT waves of 64 x 32 (102 VGPRs): two blocks = 4 waves per SIMD.  With four waves of 64 x 64
+  // (212 VGPRs, 2 waves per SIMD) 25472x768x256 took 76.4 us (now 73.2), 291208x256x128 206 us (now 192)
+  else if (!strcmp(tile, "128x128s")) {
+    static const bool w4 = getenv("LINETR_TILE128S_4WAVE") != nullptr;   // tuning aid: the four-wave layout
+    if (w4) gemm_split_launch_t<128, 128, 2, 2, PL, false, FMT>(sa, groups, st);
+    else gemm_split_launch_t<128, 128, 2, 4, PL, false, FMT>(sa, groups, st);
+  }
   else if (PL == 2 && !strcmp(tile, "256x256") && g.N % 256 == 0) gemm_split_launch_t<256, 256, 4, 2, 2, true, FMT>(sa, groups, st);
   // 64x64: three tiles of register prefetch = 156 VGPRs = THREE blocks per CU (53 KB of LDS each); with four it was 172
   // VGPRs = two blocks: 9584 x 256 x {256, 512, 1024} 20.9 / 33.2 / 58.8 us -> 18.6 / 29.8 / 52.8 us
