@@ -430,7 +430,10 @@ __global__ __launch_bounds__(256) void cls_pool_fused_kernel(
 // barrier; the bilinear taps and the a4 row of token j+1 are in flight while token j is reduced.
 // Same mathematics as cls_pool_kernel up to fp32 rounding (the softmax normalisation is applied at the end).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cls_pool_online_kernel(
+#ifndef LT_POOL_WAVES_PER_EU
+#define LT_POOL_WAVES_PER_EU 3   // second __launch_bounds__ argument = waves per SIMD the register allocation must allow
+#endif
+__global__ __launch_bounds__(256, LT_POOL_WAVES_PER_EU) void cls_pool_online_kernel(
     const LinetrLineRec* __restrict__ recs, const int* __restrict__ sub2line_g, const float* __restrict__ cpnt,
     const float* __restrict__ a4, int64_t first_pad, int N, int T, const float* __restrict__ nhwc, int Hc, int Wc,
     int align_corners, ClsPoolConst cc, float* __restrict__ pooled /*[N][4][544]*/) {
