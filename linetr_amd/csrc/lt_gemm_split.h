@@ -759,6 +759,7 @@ inline const char* split_tile_name(const GemmArgs& g, int groups, int pl = 3) {
   // tiles are level inside the step.
   static const bool no128s = getenv("LINETR_NO_TILE128S") != nullptr;   // tuning aid
   if (!no128s && pl == 3 && r128 * (g.N / 128) * groups >= 1024 && ((g.K <= 256 && g.N >= 768) || g.K <= 128)) return "128x128s";
+  if (g.N % 256 == 0 && r128 * (g.N / 256) * groups >= 140) return "128x256";
   if (g.N % 256 != 0 && (int64_t)cdiv(g.M, 256) * (g.N / 128) * groups >= 192) return "256x128";
   if (r64 * (g.N / 64) * groups <= 768) return "64x64";
   if (r64 * (g.N / 128) * groups <= 512) return "64x128";
