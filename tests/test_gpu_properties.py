@@ -158,3 +158,27 @@ def test_fused_signature_mlp_equals_two_gemms(eng, monkeypatch, mode):
     tol = {"bf16x6": 1e-6, "bf16x3": 5e-5, "f16x3": 5e-6}[mode]
     assert (fused - plain).abs().max().item() <= tol
     assert ((fused.norm(dim=1) - 1).abs() < 1e-5).all()
+
+
+def test_cfg3_step_runs_on_the_intended_kernels(eng, monkeypatch):
+    """Dispatcher guard (HIP-event profile classes of one cfg3 forward): the 18 K >= 512 / N = 256 GEMMs on the pipelined
+    128x256 tile with the three row normalisations fused into their epilogues, the nine short-K / wide-N GEMMs on the
+    eight-wave 128x128 tile, attention and pooling on their split-bf16 / one-pass kernels, nothing on a fallback tile.  (A
+    dispatcher rule lost in an edit once moved the 18 launches to the 64x256 tile: correct results, 12 % slower step.)"""
+    for k in ("LINETR_GEMM_TILE", "LINETR_NO_FUSED_NORM", "LINETR_FUSED_SIG_MLP", "LINETR_NO_TILE128S", "LINETR_GEMM_NARROW_EPI"):
+        monkeypatch.delenv(k, raising=False)
+    _, cat, off, dd, ds = batch_inputs(128)
+    describe(eng, cat, off, dd, ds)
+    torch.cuda.synchronize()
+    eng.set_profiling(True)
+    try:
+        describe(eng, cat, off, dd, ds)
+        torch.cuda.synchronize()
+        prof = {e["name"]: e["calls"] for e in eng.get_profile()}
+    finally:
+        eng.set_profiling(False)
+    assert prof.get("gemm_bf16x6_128x256") == 18, prof
+    assert prof.get("gemm_bf16x6_128x128s") == 9, prof
+    assert prof.get("sig_attn_bf16x6") == 7 and prof.get("cls_pool_online") == 1, prof
+    assert "row_norm" not in prof, prof
+    assert not [k for k in prof if k.startswith("gemm_") and k not in ("gemm_bf16x6_128x256", "gemm_bf16x6_128x128s", "gemm_bf16x6_128x64")], prof
