@@ -280,6 +280,24 @@ int linetr_debug_gemm(LinetrHandle* h, const float* d_A, int32_t lda, const floa
                       const float* d_residual, float* d_Y, int32_t ldy, int32_t M, int32_t N, int32_t K,
                       int32_t act, int32_t cache_weights, void* stream);
 
+/* ---- split-tile ("ST") operands (csrc/lt_gemm_st.h) -------------------------------------------
+ * The signature network keeps its activations in HBM pre-split into three bf16 planes, in 512-byte chunks that are the
+ * LDS image of a 16-row x 16-column block (K-step-major), so that a GEMM's K steps travel by LDS-DMA.  These three entry points expose
+ * the format and the kernel to the unit tests and micro-benchmarks (no reference counterpart: the reference's
+ * nn.Conv1d(k=1) calls, models/line_transformer.py:157-183, are what the GEMM replaces).
+ * linetr_st_bytes: size of the ST image of a [rows][K] matrix (K % 16 == 0; rows are padded to a multiple of 128),
+ * -1 on bad arguments.
+ * linetr_debug_to_st / from_st: fp32 rows (row stride ld floats, multiple of 4) <-> ST image; exact both ways.
+ * linetr_debug_gemm_st: Y = act([A1 | A2] W^T + bias) (+ R), all operands ST images (d_A2 / d_bias / d_R may be NULL),
+ * result as an ST image (d_Yst) or, when d_Yst is NULL, as fp32 rows d_Y (row stride ldy).  N % 256 == 0,
+ * (K1 + K2) % 32 == 0. */
+int64_t linetr_st_bytes(int64_t rows, int32_t K);
+int linetr_debug_to_st(LinetrHandle* h, const float* d_X, int32_t ld, int32_t rows, int32_t K, void* d_st, void* stream);
+int linetr_debug_from_st(LinetrHandle* h, const void* d_st, int32_t rows, int32_t K, float* d_X, int32_t ld, void* stream);
+int linetr_debug_gemm_st(LinetrHandle* h, const void* d_A1, int32_t K1, const void* d_A2, int32_t K2, const void* d_W,
+                         const float* d_bias, const void* d_R, void* d_Yst, float* d_Y, int32_t ldy, int32_t M, int32_t N,
+                         int32_t act, void* stream);
+
 /* ---- instrumentation ------------------------------------------------------------------------ */
 
 /* Per-kernel-class HIP-event timing.  linetr_set_profiling(h,1) clears the accumulators and makes

@@ -13,6 +13,7 @@
 #include "lt_gemm.h"
 #include "lt_gemm_split.h"
 #include "lt_gemm_split16.h"
+#include "lt_gemm_st.h"
 #include "lt_gemm_small.h"
 #include "lt_mlp_fused.h"
 #include "lt_match.h"
@@ -54,7 +55,7 @@ struct LinetrHandle {
   // split-bf16 copies of every GEMM weight (2 and 3 planes), keyed by the fp32 pointer
   int precision = LINETR_PREC_BF16X6;
   unsigned char* split_arena = nullptr;
-  struct SplitW { size_t off2, off3; int64_t rows; int K; size_t offh = 0; };  // bf16x2 planes, bf16x3 planes, fp16x2 planes
+  struct SplitW { size_t off2, off3; int64_t rows; int K; size_t offh = 0; size_t offst = 0; };  // bf16x2 planes, bf16x3 planes, fp16x2 planes, ST image (lt_gemm_st.h; 0 = none)
   std::map<const float*, SplitW> split;
   std::map<const float*, unsigned char*> debug_split;  // linetr_debug_gemm(cache_weights=1)
   // side stream: work that is independent of the token-MLP GEMMs (NHWC transpose, line-position MLP) runs here and
@@ -63,6 +64,7 @@ struct LinetrHandle {
   bool side_failed = false;
   hipEvent_t ev_fork = nullptr, ev_tok = nullptr, ev_nhwc = nullptr, ev_lpos = nullptr;
   // stream-K workspace of the 128x256 GEMM (partial accumulator tiles + flags, one slot per CU; lt_gemm_split.h)
+  float* zeros = nullptr;   // 4096 zero floats: the "no bias" vector of the split-tile GEMM (lt_gemm_st.h)
   float* sk_ws = nullptr;
   unsigned* sk_flags = nullptr;
   unsigned sk_epoch = 0;
@@ -644,9 +646,12 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
       sw.off2 = total; total += align_up(w.rows * w.K * 4, 256);
       sw.off3 = total; total += align_up(w.rows * w.K * 6, 256);
       sw.offh = total; total += align_up(w.rows * w.K * 4, 256);
+      if (w.rows % 16 == 0 && w.K % 32 == 0) { total = align_up(total, 1024); sw.offst = total; total += st_bytes(w.rows, w.K); }   // ST image (rows padded to 128)
       H->split[*w.dst] = sw;
     }
     LT_HIP(hipMalloc((void**)&H->split_arena, total));
+    LT_HIP(hipMalloc((void**)&H->zeros, 4096 * sizeof(float)));
+    LT_HIP(hipMemset(H->zeros, 0, 4096 * sizeof(float)));
     for (auto& kv : H->split) {
       const int64_t n4 = kv.second.rows * kv.second.K / 4;
       hipLaunchKernelGGL(split_rows_kernel<2>, dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, 0, kv.first,
@@ -655,6 +660,11 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
                          H->split_arena + kv.second.off3, kv.second.rows, kv.second.K);
       hipLaunchKernelGGL((split_rows_kernel<2, 1>), dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, 0, kv.first,
                          H->split_arena + kv.second.offh, kv.second.rows, kv.second.K);
+      if (kv.second.offst) {
+        const int64_t thr = st_row_blocks(kv.second.rows) * (kv.second.K / 16) * 32;
+        hipLaunchKernelGGL(to_st_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, 0, kv.first, kv.second.K,
+                           (int)kv.second.rows, kv.second.K / 16, H->split_arena + kv.second.offst);
+      }
     }
     LT_LAUNCH_CHECK();
     LT_HIP(hipDeviceSynchronize());
@@ -687,6 +697,7 @@ extern "C" void linetr_destroy(LinetrHandle* h) {
     if (e) (void)hipEventDestroy(e);
   if (h->arena) (void)hipFree(h->arena);
   if (h->split_arena) (void)hipFree(h->split_arena);
+  if (h->zeros) (void)hipFree(h->zeros);
   if (h->sk_ws) (void)hipFree(h->sk_ws);
   if (h->sk_flags) (void)hipFree(h->sk_flags);
   for (auto& kv : h->debug_split) (void)hipFree(kv.second);
@@ -1582,6 +1593,45 @@ extern "C" int linetr_debug_gemm(LinetrHandle* h, const float* A, int32_t lda, c
     (void)hipFree(buf);
   }
   return e;
+}
+
+// ---- split-tile (ST) format and GEMM (lt_gemm_st.h), for the unit tests and micro-benchmarks
+extern "C" int64_t linetr_st_bytes(int64_t rows, int32_t K) { return (K % 16 || rows < 0) ? -1 : st_bytes(rows, K); }
+
+extern "C" int linetr_debug_to_st(LinetrHandle* h, const float* d_X, int32_t ld, int32_t rows, int32_t K, void* d_st,
+                                  void* stream) {
+  if (!h || !d_X || !d_st || K % 16 || ld < K || ld % 4 || rows < 1) return fail(LINETR_E_ARG, "debug_to_st: bad argument");
+  LT_HIP(hipSetDevice(h->device));
+  const int64_t thr = st_row_blocks(rows) * (K / 16) * 32;
+  hipLaunchKernelGGL(to_st_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_X, ld, rows, K / 16,
+                     (unsigned char*)d_st);
+  LT_LAUNCH_CHECK();
+  return LINETR_OK;
+}
+
+extern "C" int linetr_debug_from_st(LinetrHandle* h, const void* d_st, int32_t rows, int32_t K, float* d_X, int32_t ld,
+                                    void* stream) {
+  if (!h || !d_X || !d_st || K % 16 || ld < K || ld % 4 || rows < 1) return fail(LINETR_E_ARG, "debug_from_st: bad argument");
+  LT_HIP(hipSetDevice(h->device));
+  const int64_t thr = st_row_blocks(rows) * (K / 16) * 32;
+  hipLaunchKernelGGL(from_st_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned char*)d_st, rows, K / 16, d_X, ld);
+  LT_LAUNCH_CHECK();
+  return LINETR_OK;
+}
+
+extern "C" int linetr_debug_gemm_st(LinetrHandle* h, const void* d_A1, int32_t K1, const void* d_A2, int32_t K2,
+                                    const void* d_W, const float* d_bias, const void* d_R, void* d_Yst, float* d_Y,
+                                    int32_t ldy, int32_t M, int32_t N, int32_t act, void* stream) {
+  if (!h || !d_A1 || !d_W || (!d_Yst && !d_Y) || K1 % 16 || K2 % 16 || N > 4096)
+    return fail(LINETR_E_ARG, "debug_gemm_st: bad argument");
+  LT_HIP(hipSetDevice(h->device));
+  StGemmArgs a;
+  a.A1 = (const unsigned char*)d_A1; a.nk1 = K1 / 16;
+  a.A2 = (const unsigned char*)d_A2; a.nk2 = d_A2 ? K2 / 16 : 0;
+  a.W = (const unsigned char*)d_W; a.bias = d_bias ? d_bias : h->zeros; a.R = (const unsigned char*)d_R;
+  a.Yst = (unsigned char*)d_Yst; a.Y = d_Y; a.ldy = ldy; a.M = M; a.N = N; a.act = act;
+  return gemm_st_launch(a, (hipStream_t)stream);
 }
 
 #ifdef LT_MLP_STAMPS

@@ -570,6 +570,30 @@ class Engine:
                                             int(act), int(cache_weights), self._stream()))
         return Y
 
+    # ------------------------------------------------------------------ split-tile operands (lt_gemm_st.h)
+    def to_st(self, X):
+        """fp32 [rows, K] -> ST image (uint8 tensor); K % 32 == 0."""
+        X = self._f32(X)
+        rows, K = X.shape
+        out = torch.empty(int(self._L.linetr_st_bytes(rows, K)), dtype=torch.uint8, device=self.device)
+        nat.check(self._L.linetr_debug_to_st(self._h, X.data_ptr(), X.stride(0), rows, K, out.data_ptr(), self._stream()))
+        return out
+
+    def from_st(self, st, rows, K):
+        X = torch.empty((rows, K), dtype=torch.float32, device=self.device)
+        nat.check(self._L.linetr_debug_from_st(self._h, st.data_ptr(), rows, K, X.data_ptr(), K, self._stream()))
+        return X
+
+    def gemm_st(self, A1, K1, W, M, N, A2=None, K2=0, bias=None, residual=None, act=0, out_st=None, out=None):
+        """act([A1 | A2] W^T + bias) (+ residual) on ST images; returns the ST image `out_st` or the fp32 matrix `out`."""
+        b = self._f32(bias) if bias is not None else None
+        nat.check(self._L.linetr_debug_gemm_st(
+            self._h, A1.data_ptr(), K1, A2.data_ptr() if A2 is not None else None, K2, W.data_ptr(),
+            b.data_ptr() if b is not None else None, residual.data_ptr() if residual is not None else None,
+            out_st.data_ptr() if out_st is not None else None, out.data_ptr() if out is not None else None,
+            out.stride(0) if out is not None else 0, M, N, int(act), self._stream()))
+        return out_st if out_st is not None else out
+
     # ------------------------------------------------------------------ profiling
     def set_profiling(self, on: bool):
         nat.check(self._L.linetr_set_profiling(self._h, int(on)))
