@@ -43,7 +43,7 @@ from linetr_amd.engine import Engine  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA
 HBM_PEAK_GBS = 8000.0
-PROFILE_TAG = "r02"             # profiles/<tag>_pmc_traffic.json, profiles/<tag>_gemm_pmc.json
+PROFILE_TAG = "r03"             # profiles/<tag>_<workload>_pmc_traffic.json, profiles/<tag>_<workload>_gemm_pmc.json
 
 WORKLOADS = {
     # name: (H, W, lines/image, len_lo, len_hi, max_tokens, default pairs per GPU)
@@ -309,26 +309,29 @@ PMC_KERNEL_NAMES = {   # profile class -> kernel symbol prefix in profiles/<tag>
     "gemm_bf16x6_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 3, true, 0",
     "gemm_bf16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 0",
     "gemm_f16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 1",
-    "gemm_bf16x6_128x128s": "void lt::gemm_split_kernel<128, 128, 2, 2, 3, false, 0",
+    "gemm_bf16x6_128x128s": "void lt::gemm_split_kernel<128, 128, 2, 4, 3, false, 0",
+    "gemm_bf16x6_64x64": "void lt::gemm_split_kernel<64, 64, 2, 2, 3, true, 0",
+    "gemm_bf16x6_64x128": "void lt::gemm_split_kernel<64, 128, 2, 2, 3, true, 0",
     "gemm_bf16x6_32x32k4": "void lt::gemm_split_small_kernel<3, 0",
     "gemm_f32_128x128": "void lt::gemm_kernel<128, 128, 2, 2>",
     "sig_attn_bf16x6": "void lt::sig_attn_split_kernel<8>",
 }
 
 
-def _profile_json(name):
-    for tag in (PROFILE_TAG, "r01"):
-        path = os.path.join(ROOT, "profiles", f"{tag}_{name}.json")
-        if os.path.exists(path):
-            return json.load(open(path)), tag
+def _profile_json(name, workload):
+    """committed counter pass of THIS workload and THIS round's binary only (profiles/<tag>_<workload>_<name>.json);
+    a pass of another workload or an older binary is not evidence for this line."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{workload}_{name}.json")
+    if os.path.exists(path):
+        return json.load(open(path)), os.path.relpath(path, ROOT)
     return None, None
 
 
-def pmc_traffic(kernel_class):
+def pmc_traffic(kernel_class, workload):
     """HBM-side bytes per launch of `kernel_class` from the committed rocprofv3 PMC pass (FETCH_SIZE/WRITE_SIZE in
     KiB, separate --pmc runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads
-    on gfx950).  None if no PMC data is committed for this kernel."""
-    data, _ = _profile_json("pmc_traffic")
+    on gfx950).  None if no PMC data is committed for this kernel and workload."""
+    data, _ = _profile_json("pmc_traffic", workload)
     name = PMC_KERNEL_NAMES.get(kernel_class)
     if not name or not data:
         return None
@@ -338,36 +341,46 @@ def pmc_traffic(kernel_class):
     return (2.0 * rec["FETCH_SIZE_KiB_avg"] + rec["WRITE_SIZE_KiB_avg"]) * 1024.0
 
 
-def pmc_mfma_busy(kernel_class):
+def pmc_mfma_busy(kernel_class, workload):
     """SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE) of the dominant kernel from the committed PMC
-    pass (profiles/<tag>_gemm_pmc.json, written by tools/pmc_kernels.sh), or None."""
-    data, tag = _profile_json("gemm_pmc")
+    pass of the same workload (profiles/<tag>_<workload>_gemm_pmc.json, written by tools/pmc_kernels.sh), or None."""
+    data, src = _profile_json("gemm_pmc", workload)
     name = PMC_KERNEL_NAMES.get(kernel_class)
     if not name or not data:
         return None
     rec = next((v for k, v in data.get("kernels", {}).items() if k.startswith(name)), None)
     if not rec or "mfma_busy" not in rec:
         return None
-    return {"mfma_busy": rec["mfma_busy"], "source": f"profiles/{tag}_gemm_pmc.json"}
+    return {"mfma_busy": rec["mfma_busy"], "mfma_busy_source": src}
 
 
-def roofline_of(dom, prof_steps, tot_ms):
-    """roofline object of the dominant kernel (largest summed HIP-event time over the profiled steps)."""
+def mfma_terms(kernel_class):
+    """bf16 / fp16 MFMA products executed per fp32 product of this kernel class (None: exact-fp32 MFMA or no MFMA)."""
+    return 6 if "bf16x6" in kernel_class else 3 if ("bf16x3" in kernel_class or "f16x3" in kernel_class) else None
+
+
+def roofline_of(dom, prof_steps, tot_ms, workload):
+    """roofline object of the dominant kernel (largest summed HIP-event time over the profiled steps).
+    For a split-precision MFMA kernel `frac` is the fraction of the pipe it actually executes on: the bf16 MFMA products it
+    issues (6 or 3 per fp32 product) against the 2.5 PFLOP/s dense bf16 peak; the ratio to the fp32 matrix peak (what an
+    exact-fp32 kernel could reach at most) is kept as `frac_of_fp32_matrix_peak`."""
     common = {"kernel": dom["name"], "avg_launch_us": round(dom["ms"] / dom["calls"] * 1e3, 2),
               "launches_per_step": dom["calls"] // prof_steps, "share_of_gpu_time": round(dom["ms"] / tot_ms, 3)}
-    traffic = pmc_traffic(dom["name"])
+    traffic = pmc_traffic(dom["name"], workload)
     if dom["flops"] > 0:
-        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12      # algorithmic fp32 flops (2*M*N*K of each launch) / time
-        r = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-             "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-             "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["calls"]),
-             "peak_note": "157.3 TF = dense fp32 matrix peak (the contract of the kernel is fp32 in / fp32 out)"}
-        if "bf16x" in dom["name"] or "f16x3" in dom["name"]:
-            terms = 6 if "bf16x6" in dom["name"] else 3
-            r.update({"mfma_flops_per_algorithmic_flop": terms,
-                      "bf16_pipe_frac": round(ach * terms / BF16_MFMA_PEAK_TFLOPS, 4),
-                      "pipe_note": f"each fp32 product = {terms} bf16 MFMA products; {terms}*achieved / 2.5 PF dense bf16 peak"})
-        busy = pmc_mfma_busy(dom["name"])
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12      # executed fp32-equivalent flops (2*M*N*K of each launch) / time
+        terms = mfma_terms(dom["name"])
+        if terms:
+            r = {"bound": "mfma", "achieved": round(ach * terms, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(ach * terms / BF16_MFMA_PEAK_TFLOPS, 4),
+                 "achieved_note": f"bf16 MFMA flops issued: {terms} products per fp32 product x 2MNK / time, against the dense bf16 peak",
+                 "fp32_equivalent_tflops": round(ach, 2), "frac_of_fp32_matrix_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                 "mfma_flops_per_algorithmic_flop": terms}
+        else:
+            r = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "achieved_note": "exact-fp32 MFMA: 2MNK / time against the fp32 matrix peak"}
+        r.update({"traffic": traffic, "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["calls"])})
+        busy = pmc_mfma_busy(dom["name"], workload)
         if busy:
             r.update(busy)
     else:
@@ -375,6 +388,24 @@ def roofline_of(dom, prof_steps, tot_ms):
         r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic}
     return {**common, **r}
+
+
+def whole_step_executed(prof, prof_steps, ms_per_step):
+    """flops the kernels of one step actually execute (sum of every launch's own 2MNK etc.) and the fraction of the pipe
+    the whole step keeps busy; counts every MFMA class with its own product count."""
+    gf, pipe = 0.0, 0.0
+    for e in prof:
+        f = e["flops"] / prof_steps
+        gf += f
+        t = mfma_terms(e["name"])
+        pipe += f * t if t else 0.0
+    sec = ms_per_step * 1e-3
+    return {"executed_gflop_per_step": round(gf / 1e9, 1),
+            "executed_tflops_fp32_equivalent": round(gf / sec / 1e12, 1),
+            "bf16_mfma_tflops_issued": round(pipe / sec / 1e12, 1),
+            "frac_of_bf16_mfma_peak": round(pipe / sec / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+            "note": "sum over the step's launches of the flops each kernel executes (2MNK per GEMM, 4 n^2 d per attention), "
+                    "split-precision classes counted with their 6 (or 3) bf16 products, divided by the timed step"}
 
 
 def profile_steps(eng, fn, prof_steps=3):
@@ -394,11 +425,15 @@ def breakdown_of(prof, prof_steps):
                         "tflops": round(e["flops"] / max(e["ms"], 1e-9) / 1e9, 1) if e["flops"] else None} for e in prof}
 
 
-def sub_workload(eng, name, device, settle_s):
+def sub_workload(eng, name, device, settle_s, repeat=1, brief=False):
     """cfg2 / cfg5 sub-object of the N = 1 line: the same step on another BASELINE.json configuration (own inputs,
-    own short settle), with its dominant kernel."""
+    own short settle), with its dominant kernel.  repeat > 1: the workload's default batch repeated that many times
+    (BASELINE.json names no batch size for cfg5; the default of 8 pairs leaves two thirds of the CUs without a GEMM tile)."""
     H, W, n_lines, lo, hi, T, pairs = WORKLOADS[name]
     lines, _dd, nhwc, ds, hw, T = make_inputs(name, pairs, 0, device, eng)
+    del _dd
+    if repeat > 1:
+        lines, nhwc, ds, pairs = lines * repeat, nhwc.repeat(repeat, 1, 1, 1), ds.repeat(repeat, 1, 1), pairs * repeat
     pipe = Pipeline(eng, lines, nhwc, ds, hw, T, 1, pairs)
     sync = torch.cuda.synchronize
     settle(pipe.step, sync, min_s=settle_s, max_s=max(settle_s * 3, 1.0))
@@ -410,7 +445,12 @@ def sub_workload(eng, name, device, settle_s):
            "ms_per_step": round(elapsed / steps * 1e3, 4), "ms_per_step_median": round(float(np.median(per_step)), 4),
            "host_ms_per_step": round(float(np.median(host_ms)), 4), "gpu_ms_per_step_profiled": round(tot / 3, 4),
            "launches_per_step": int(sum(e["calls"] for e in prof) // 3),
-           "roofline": roofline_of(prof[0], 3, tot), "kernels": breakdown_of(prof, 3)}
+           "roofline": roofline_of(prof[0], 3, tot, name if repeat == 1 else f"{name}x{repeat}"),
+           "whole_step": whole_step_executed(prof, 3, elapsed / steps * 1e3), "kernels": breakdown_of(prof, 3)}
+    if brief:
+        for k in ("kernels", "host_ms_per_step", "gpu_ms_per_step_profiled"):
+            out.pop(k, None)
+        out["inputs"] = f"the {pairs // repeat}-pair set repeated {repeat}x"
     if pairs == 1:      # single pair: strict latency (submit, wait, repeat) of describe and of describe + match
         margs = pipe.match_args(tb, ld)
         lat, lat_m = [], []
@@ -602,6 +642,25 @@ def run_cfg4(args, eng, device, rank, world, dist):
 
 # =====================================================================================================================
 
+def self_launch(n):
+    """Re-run this command under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1, a free port)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and not os.environ.get("LINETR_BENCH_ONE_DEVICE"):
+        print(f"bench.py: --gpus {n} but only {have} HIP device(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print("# self-launch: " + " ".join(cmd), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -623,6 +682,11 @@ def main():
     ap.add_argument("--candidates", type=int, default=4, help="cfg4: gathered candidate images matched per query image")
     ap.add_argument("--homography-strength", type=float, default=1.0, help="cfg4: 1 = the yaml's recipe, <1 milder views")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the same command
+        # line the driver's torch.distributed.run invocation uses) and hand back rank 0's JSON line through stdout
+        raise SystemExit(self_launch(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -698,8 +762,18 @@ def main():
         pipe.prefilter_only()
     host_prefilter_ms = (time.perf_counter() - t0) / 10 * 1e3
 
-    gathered_ok, global_match = None, None
+    gathered_ok, global_match, gather_ms = None, None, None
     if world > 1 and _g is not None:
+        # the collective alone (not part of `value`'s clock, which overlaps it with the next step's compute)
+        slab = pipe.pack(tb, ld)
+        for _ in range(2):
+            parallel.allgather_descriptors(slab, async_op=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            parallel.allgather_descriptors(slab, async_op=False)
+        torch.cuda.synchronize()
+        gather_ms = round((time.perf_counter() - t0) / 5 * 1e3, 4)
         # every rank's slab of the last all-gather carries that rank's descriptors; then GLOBAL matching on the gathered set:
         # this rank's side-0 images against the side-1 images of the NEXT rank's pairs (descriptors this rank never computed)
         gs = parallel.GatheredSet(_g, pipe.n_img_cap, pipe.rows_cap)
@@ -753,7 +827,7 @@ def main():
         pipe.step()                       # bring the clocks back up after the light matcher section
     prof_steps = 3
     prof, tot_ms = profile_steps(eng, pipe.describe, prof_steps)
-    roofline = roofline_of(prof[0], prof_steps, tot_ms)
+    roofline = roofline_of(prof[0], prof_steps, tot_ms, args.workload)
     n_img = 2 * pairs
     alg_flops_step = sum(algorithmic_flops_per_image(int(n), T) for n in np.diff(tb.cu_n))
 
@@ -769,7 +843,9 @@ def main():
         "config": {"workload": f"{args.workload}: {pairs} pairs/GPU of {W}x{H}, {n_lines} lines/image -> "
                                f"{int(tb.N / n_img)} sub-lines x {T} tokens, d_model=256, seeded weights",
                    "pairs_per_gpu": pairs, "descriptors_per_step": int(n_desc_step),
-                   "dense_layout": args.dense_layout,
+                   "dense_layout": args.dense_layout + (" (channel-last map as the repo's producer linetr_superpoint_heads emits it; the step "
+                                                        "fed with the reference's NCHW map is ms_per_step_fed_nchw / value_fed_nchw)"
+                                                        if args.dense_layout == "nhwc" else ""),
                    "collective": "all_gather(line_desc + counts + key-line maps)" if world > 1 else "none"},
         "ms_per_step_median": round(float(np.median(per_step)), 4), "ms_per_step_p10": round(float(np.percentile(per_step, 10)), 4),
         "ms_per_step_p90": round(float(np.percentile(per_step, 90)), 4),
@@ -779,10 +855,15 @@ def main():
         "host_ms_per_step": round(float(np.median(host_ms)), 4), "host_prefilter_ms": round(host_prefilter_ms, 4),
         "settle": {"seconds_min": args.settle_s, "windows": len(settle_hist), "first_ms": round(settle_hist[0], 4),
                    "last3_ms": [round(v, 4) for v in settle_hist[-3:]]},
-        "gathered_rows_checked": gathered_ok, "global_match": global_match,
+        "gathered_rows_checked": gathered_ok, "global_match": global_match, "gather_ms": gather_ms,
+        "collective_backend": (None if world == 1 else os.environ.get("LINETR_BENCH_BACKEND", "nccl")),
+        "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and hasattr(torch.cuda, "nccl") else None),
         "pair_match_ms": round(pair_match_ms, 4), "pair_match_latency_ms": round(pair_match_latency_ms, 4),
         "matches_per_step": n_matches,
-        "whole_step_algorithmic_tflops": round(alg_flops_step / (ms_per_step * 1e-3) / 1e12, 2),
+        "whole_step": {**whole_step_executed(prof, prof_steps, ms_per_step),
+                       "survey_algorithmic_gflop_per_step": round(alg_flops_step / 1e9, 1),
+                       "survey_note": "SURVEY 8(d)'s formula counts the reference's graph; exact algebra (K-projection fold, "
+                                      "V / W5 after pooling, padding key with multiplicity) executes less -- not a roofline input"},
         "gpu_ms_per_step_profiled": round(tot_ms / prof_steps, 3),
         "roofline": roofline, "kernels": breakdown_of(prof, prof_steps),
     }
@@ -798,6 +879,7 @@ def main():
             pipe.describe(odd, other)
         torch.cuda.synchronize()
         out[f"ms_per_step_fed_{other}"] = round((time.perf_counter() - t0) / 10 * 1e3, 4)
+        out[f"value_fed_{other}"] = round(n_desc_step / out[f"ms_per_step_fed_{other}"] * 1e3, 1)
         out["producer"] = producer_section(eng, H, W, n_img)
     if world == 1 and not args.no_alt_precisions:   # the same step in the other MFMA modes (few steps each), for reference
         alt = {}
@@ -821,6 +903,8 @@ def main():
         for name in ("cfg2", "cfg5"):
             if name != args.workload:
                 out[name] = sub_workload(eng, name, device, min(args.settle_s, 0.6))
+        if "cfg5" in out:      # chip-filling batches of the long-line workload beside the 8-pair point
+            out["cfg5"]["larger_batches"] = [sub_workload(eng, "cfg5", device, 0.4, repeat=r, brief=True) for r in (4, 8)]
         if "cfg2" in out:      # the single-pair figures of the metric, also at top level
             out["pair_latency_ms"] = out["cfg2"]["ms_per_step"]
             out["pair_latency_sync_ms"] = out["cfg2"]["pair_latency_sync_ms"]

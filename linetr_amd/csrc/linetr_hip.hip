@@ -18,6 +18,7 @@
 #include "lt_mlp_fused.h"
 #include "lt_match.h"
 #include "lt_model.h"
+#include "lt_attn_st.h"
 #include "lt_producer.h"
 #include "lt_token.h"
 
@@ -915,6 +916,7 @@ extern "C" int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int
 namespace {
 struct FwdWs {
   float *a1, *a2, *a3, *a4, *pooled, *att, *fc, *o, *f1, *f2, *l1, *l2, *l3, *l4, *lpos, *zA, *zB, *qkv, *msgp, *msg, *hid;
+  unsigned char *zsA, *zsB, *qkvs, *msgs, *hids;   // split-tile images of the signature network's activations (lt_gemm_st.h)
   int* cu;
   int64_t total;
 };
@@ -933,6 +935,9 @@ FwdWs fwd_layout(const LinetrModelConfig& c, int N, int64_t rows, int n_images, 
   w.zA = take((int64_t)N * D); w.zB = take((int64_t)N * D);
   w.qkv = take((int64_t)N * 3 * D); w.msgp = take((int64_t)N * D); w.msg = take((int64_t)N * D);
   w.hid = take((int64_t)N * 2 * D);
+  auto take_st = [&](int cols) { unsigned char* p = (unsigned char*)(base + off); off += align_up(st_bytes(N, cols), 1024); return p; };
+  off = align_up(off, 1024);
+  w.zsA = take_st(D); w.zsB = take_st(D); w.qkvs = take_st(3 * D); w.msgs = take_st(D); w.hids = take_st(2 * D);
   w.cu = (int*)take(n_images + 1);
   w.total = off;
   return w;
@@ -972,6 +977,61 @@ int mlp123_rows_per_wave(int64_t rows) {
   if (env) return atoi(env);
   const int64_t waves = 256 * 4;
   return (int)std::max<int64_t>(cdiv((int)cdiv((int)rows, (int)waves), 32) * 32, 32);
+}
+
+// Signature network on split-tile operands: z -> [q|k|v] -> attention -> W1 [z ; message] -> W2 + z, seven times, then the
+// final projection (with the last W2 folded in) and the L2 normalisation.  models/line_transformer.py:132-183, 245-246.
+int sig_network_st(LinetrHandle* h, hipStream_t st, FwdWs& w, const int32_t* h_cu, const int* cu_dev, int n_images, int N,
+                   int max_n, float* d_line_desc) {
+  auto wst = [&](const float* W) -> const unsigned char* {
+    auto it = h->split.find(W);
+    return (it == h->split.end() || !it->second.offst) ? nullptr : h->split_arena + it->second.offst;
+  };
+  auto gemm = [&](const unsigned char* A1, int K1, const unsigned char* A2, int K2, const float* W, const float* bias,
+                  const unsigned char* R, unsigned char* Yst, float* Y, int Nout, int act) -> int {
+    StGemmArgs a;
+    a.A1 = A1; a.nk1 = K1 / 16; a.A2 = A2; a.nk2 = A2 ? K2 / 16 : 0;
+    a.W = wst(W); a.bias = bias ? bias : h->zeros; a.R = R; a.Yst = Yst; a.Y = Y; a.ldy = D; a.M = N; a.N = Nout; a.act = act;
+    if (!a.W) return fail(LINETR_E_ARG, "sig_network_st: weight has no split-tile image");
+    const double K = K1 + (A2 ? K2 : 0);
+    ProfScope ps(h, st, "gemm_st_bf16x6", 2.0 * N * Nout * K, 6.0 * ((double)N * K + (double)Nout * K + (double)N * Nout));
+    return gemm_st_launch(a, st);
+  };
+  if (st_bytes(N, 3 * D) >= (int64_t)1 << 32) return fail(LINETR_E_ARG, "sig_network_st: batch too large (q/k/v image >= 4 GiB)");
+  int e;
+  {
+    ProfScope ps(h, st, "to_st", 0, (double)N * D * 10);
+    const int64_t thr = st_row_blocks(N) * (D / 16) * 32;
+    hipLaunchKernelGGL(to_st_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, st, w.zA, D, N, D / 16, w.zsA);
+    LT_LAUNCH_CHECK();
+  }
+  unsigned char *z = w.zsA, *zn = w.zsB;
+  double attn_fl = 0;
+  for (int i = 0; i < n_images; ++i) { const double n = h_cu[i + 1] - h_cu[i]; attn_fl += 2.0 * 2.0 * n * n * D; }
+  for (size_t l = 0; l < h->sig.size(); ++l) {
+    const SigLayer& S = h->sig[l];
+    if ((e = gemm(z, D, nullptr, 0, S.Wqkv, S.bqkv, nullptr, w.qkvs, nullptr, 3 * D, ACT_NONE))) return e;
+    {
+      ProfScope ps(h, st, "sig_attn_st", attn_fl, (double)N * D * 24);
+      static const bool occ1 = getenv("LINETR_ATTN_ST_OCC1") != nullptr;   // tuning aid: one block per CU, 256 VGPRs
+      if (occ1) hipLaunchKernelGGL(sig_attn_st_kernel<1>, dim3(n_images, HEADS, cdiv(max_n, 256)), dim3(512), 0, st, w.qkvs, cu_dev,
+                                   n_images, N, w.msgs);
+      else hipLaunchKernelGGL(sig_attn_st_kernel<2>, dim3(n_images, HEADS, cdiv(max_n, 256)), dim3(512), 0, st, w.qkvs, cu_dev,
+                              n_images, N, w.msgs);
+      LT_LAUNCH_CHECK();
+    }
+    if ((e = gemm(z, D, w.msgs, D, S.W1, S.b1, nullptr, w.hids, nullptr, 2 * D, ACT_RELU))) return e;
+    if (l + 1 == h->sig.size()) break;   // the last layer's second MLP GEMM is folded into the final projection
+    if ((e = gemm(w.hids, 2 * D, nullptr, 0, S.W2, S.b2, z, zn, nullptr, D, ACT_NONE))) return e;
+    std::swap(z, zn);
+  }
+  // final_proj(z + W2 hid + b2) = [Wfin | Wfin W2] [z ; hid] + (Wfin b2 + bfin), then F.normalize
+  if ((e = gemm(z, D, w.hids, 2 * D, h->Wfin2, h->bfin2, nullptr, nullptr, w.zB, D, ACT_NONE))) return e;
+  ProfScope ps(h, st, "row_norm", 0, (double)N * D * 8);
+  hipLaunchKernelGGL(row_norm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, w.zB, N, 1, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, 0.f, d_line_desc);
+  LT_LAUNCH_CHECK();
+  return LINETR_OK;
 }
 
 int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const float* sublines, const float* resp,
@@ -1066,6 +1126,13 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     if ((e = run_gemm_norm(h, st, w.f1, c.d_inner, nullptr, 0, 0, h->Wf2, h->bf2, w.o, w.f2, w.zA, N, c.d_inner, ns))) return e;
   }
   // ---- line signature network
+  // LINETR_SIG_PATH=st (experiment): activations stay in HBM as split-tile images and every K step travels by LDS-DMA
+  // (lt_gemm_st.h, lt_attn_st.h).  Measured at cfg3 on one box: the ST GEMMs are 5-7 % faster than the register-staged
+  // ones in isolation, but inside the step the 6-byte activations cost more at the kernel boundaries (the L2 write-back of
+  // 273 MB instead of 182 MB of fresh activations per layer) than the main loops save: 2.92 vs 2.69 ms per step.
+  static const char* sig_path = getenv("LINETR_SIG_PATH");
+  if (h->precision == LINETR_PREC_BF16X6 && !h->sig.empty() && sig_path && !strcmp(sig_path, "st"))
+    return sig_network_st(h, st, w, h_cu, cu_dev, n_images, N, max_n, d_line_desc);
   float *z = w.zA, *zn = w.zB;
   const int qtiles = cdiv(max_n, ATT_QT);
   // layers but the last: W1 -> ReLU -> W2 + residual in one kernel, hidden activations in registers (lt_mlp_fused.h)
@@ -1334,14 +1401,14 @@ PinnedRing& staging_ring() {   // one ring per device (its events belong to the 
 }
 
 // ints of argmin scratch one pair needs (layout in lt_match.h)
-int64_t pair_scratch_ints(int k0, int k1) { return 2 * (int64_t)k0 + k1 + 2 * (int64_t)cdiv(std::max(k0, 1), PM_ROWS) * k1 + 8; }
+int64_t pair_scratch_ints(int k0, int k1) { return 2 * (int64_t)k0 + 2 * (int64_t)k1 + 1 + 2 * (int64_t)cdiv(std::max(k0, 1), PM_ROWS) * k1 + 8; }
 }  // namespace
 
 extern "C" int64_t linetr_match_workspace_bytes(int32_t n_pairs, int64_t sum_n0n1, int64_t sum_k0k1, int64_t sum_k) {
   (void)sum_k0k1;
-  // scratch bound: sum over pairs of pair_scratch_ints(k0,k1) <= 3 sum_k + 2 (sum_k0k1 / PM_ROWS + sum_k) + 8 P, and
+  // scratch bound: sum over pairs of pair_scratch_ints(k0,k1) <= 4 sum_k + 2 (sum_k0k1 / PM_ROWS + sum_k) + 9 P, and
   // k0 k1 <= n0 n1
-  const int64_t scratch = 5 * sum_k + 2 * (sum_n0n1 / PM_ROWS + 1) + 8 * (int64_t)n_pairs;
+  const int64_t scratch = 6 * sum_k + 2 * (sum_n0n1 / PM_ROWS + 1) + 9 * (int64_t)n_pairs;
   return align_up((int64_t)n_pairs * sizeof(PairDesc), 256) + align_up(sum_n0n1 * 4, 256) + align_up(scratch * 4, 256) + 256;
 }
 
@@ -1398,7 +1465,6 @@ extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* 
     max_k1 = std::max(max_k1, d.k1); max_chunks = std::max(max_chunks, d.chunks);
     flops += 2.0 * d.n0 * d.n1 * D;
   }
-  if (max_k1 > PM_MAX_K1) return fail(LINETR_E_ARG, "match: more than %d key-lines in one image", PM_MAX_K1);
   if (ws_bytes < linetr_match_workspace_bytes(P, od, 0, sum_k)) return fail(LINETR_E_WORKSPACE, "match: workspace too small");
   char* base = (char*)d_ws;
   PairDesc* d_pd = (PairDesc*)base;
@@ -1419,8 +1485,10 @@ extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* 
   {
     ProfScope ps(h, st, "pair_match", 0, 0);
     if (max_k1 > 0) {
-      hipLaunchKernelGGL(pair_pool_kernel, dim3(max_chunks, P), dim3(256), (size_t)(max_k1 + PM_ROWS + 2) * sizeof(int), st,
-                         tab, d_s2l0, d_s2l1, d_dist, d_dk, d_scr);
+      const int seg1_global = max_k1 > PM_MAX_K1;    // the reference has no limit (max_keylines / max_keypoints = -1)
+      hipLaunchKernelGGL(pair_pool_kernel, dim3(max_chunks, P), dim3(256),
+                         (size_t)((seg1_global ? 0 : max_k1) + PM_ROWS + 2) * sizeof(int), st, tab, d_s2l0, d_s2l1, d_dist, d_dk,
+                         d_scr, seg1_global);
       LT_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(pair_final_kernel, dim3(P), dim3(256), 0, st, tab, thr, mutual, d_match01, d_scr);
@@ -1475,7 +1543,6 @@ extern "C" int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_
                                     int32_t mutual, int32_t* d_match01, void* d_ws, int64_t ws_bytes, void* stream) {
   if (n0 < 0 || n1 < 0) return fail(LINETR_E_ARG, "match_distmat: bad argument");
   if (n0 == 0) return LINETR_OK;
-  if (n1 > PM_MAX_K1) return fail(LINETR_E_ARG, "match_distmat: more than %d columns", PM_MAX_K1);
   hipStream_t st = (hipStream_t)stream;
   if (h) LT_HIP(hipSetDevice(h->device));
   // scratch: PairDesc | identity maps | Dk copy | argmin ints
@@ -1499,9 +1566,10 @@ extern "C" int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_
   if (n1 > 0) LT_HIP(hipMemcpyAsync(base + o_id1, iota, n1 * 4, hipMemcpyHostToDevice, st));
   if (int e = staging_ring().commit(slot, st)) return e;
   if (n1 > 0) {
-    hipLaunchKernelGGL(pair_pool_kernel, dim3(pd->chunks, 1), dim3(256), (size_t)(n1 + PM_ROWS + 2) * sizeof(int), st, tab,
-                       (const int*)(base + o_id0), (const int*)(base + o_id1), d_dist, (float*)(base + o_dk),
-                       (int*)(base + o_scr));
+    const int seg1_global = n1 > PM_MAX_K1;
+    hipLaunchKernelGGL(pair_pool_kernel, dim3(pd->chunks, 1), dim3(256), (size_t)((seg1_global ? 0 : n1) + PM_ROWS + 2) * sizeof(int),
+                       st, tab, (const int*)(base + o_id0), (const int*)(base + o_id1), d_dist, (float*)(base + o_dk),
+                       (int*)(base + o_scr), seg1_global);
     LT_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(pair_final_kernel, dim3(1), dim3(256), 0, st, tab, thr, mutual, d_match01, (int*)(base + o_scr));

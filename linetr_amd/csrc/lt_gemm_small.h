@@ -124,6 +124,9 @@ __global__ __launch_bounds__(NWV * 64) void gemm_split_small_kernel(SplitGemmArg
               acc = mfma_split<FMT>(af[pa], bf[pb], acc);
             }
         }
+        // compiler-only: with one staging buffer the stores of tile u+1 reuse this region and must stay behind the
+        // fragment reads of tile u (other lanes' data)
+        __builtin_amdgcn_wave_barrier();
       }
     }
   }

@@ -108,7 +108,9 @@ struct SplitGemmArgs {
 // drained vmcnt.  No release / acquire fences: an agent release writes back the XCD's whole L2 -- which is full of the
 // output rows the data-parallel blocks of the same launch have just stored -- once per publishing block.
 __device__ __forceinline__ void sk_store16(float* p, const f32x4& v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  // the trailing s_nop: hipcc does not pad an asm store, and its next instruction may otherwise overwrite the data
+  // registers before the store has read them (cdna_hip_programming.md 5.7)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ f32x4 sk_load16(const float* p) {
   f32x4 v;
@@ -566,7 +568,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
 #ifdef LT_ABLATE_STORE   // timing experiment only: the output never leaves the CU
       if (row < g.M && blockDim.y == 7) *reinterpret_cast<f32x4*>(Y + (int64_t)row * g.ldy + gcol) = v;
 #else
-      if (row < g.M) *reinterpret_cast<f32x4*>(Y + (int64_t)row * g.ldy + gcol) = v;
+      // write-through (sc1) stores: the fresh activations leave the XCD's L2 while the launch is still running instead of
+      // being written back behind it (same-box A/B at cfg3: 9.72 -> 9.82 M descriptors/s, twice)
+      if (row < g.M) sk_store16(Y + (int64_t)row * g.ldy + gcol, v);
 #endif
     }
     return;
@@ -775,6 +779,13 @@ inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st
     return fail(LINETR_E_ARG, "gemm_split: unsupported shape M=%d N=%d K=%d", g.M, g.N, g.K);
   static const char* tile_env = getenv("LINETR_GEMM_TILE");  // tuning aid: force a tile
   const char* tile = tile_env ? tile_env : split_tile_name(g, groups, PL);
+  // the launcher is authoritative about the fused row normalisation: only the 128x256 tile with the LDS epilogue owns
+  // complete rows of an N = 256 problem; anything else would silently skip the normalisation
+  if (g.norm != 0) {
+    static const bool narrow_env = getenv("LINETR_GEMM_NARROW_EPI") != nullptr;
+    if (strcmp(tile, "128x256") != 0 || g.N != 256 || narrow_env || g.ldy % 4 != 0 || (g.R && g.ldr % 4 != 0))
+      return fail(LINETR_E_ARG, "gemm_split: fused row normalisation asked of tile %s (N=%d): dispatcher bug", tile, g.N);
+  }
   if (!strcmp(tile, "32x32k4")) gemm_split_small_launch<PL, FMT>(sa, groups, st);
   else if (!strcmp(tile, "112x256")) gemm_split16_launch<PL, FMT>(sa, st);
   else if (g.N % 128 != 0 || !strcmp(tile, "128x64")) gemm_split_launch_t<128, 64, 4, 1, PL, true, FMT>(sa, groups, st);

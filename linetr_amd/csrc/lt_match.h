@@ -29,7 +29,7 @@ struct PairTable {
 };
 
 constexpr int PM_ROWS = 16;         // key-line rows of Dk per block of pair_pool_kernel
-constexpr int PM_MAX_K1 = 12000;    // seg1 table of a pair must fit the block's LDS (48 KB)
+constexpr int PM_MAX_K1 = 12000;    // up to here the seg1 table of a pair lives in the block's LDS (48 KB); beyond, in the workspace
 
 // D[a][b] = max(2 - 2 * <d0[a], d1[b]>, 0), fp32 MFMA, 64x64 tile per block, K = 256.
 // grid (tiles_b, tiles_a, pair)
@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void pair_dist_kernel(const PairTable pairs,
 //   pair_final_kernel  grid (pairs): column partials combined in chunk order (first index wins), threshold + mutual check.
 // Deterministic: fixed summation order, no atomics; np.argmin's first-minimum rule on rows and columns.
 // Sub-lines of a key-line are contiguous and key-line ids are non-decreasing, so a segment start is a lower bound.
-// Scratch ints of a pair at off_seg: row_arg[k0] | row_min[k0] | col_arg[k1] | part_val[chunks][k1] | part_arg[chunks][k1]
+// Scratch ints of a pair at off_seg: row_arg[k0] | row_min[k0] | col_arg[k1] | part_val[chunks][k1] | part_arg[chunks][k1] | seg1[k1+1]
+// (seg1: only used when an image has more than PM_MAX_K1 key-lines / key-points and the table does not fit the LDS)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int seg_lower_bound(const int* __restrict__ m, int n, int key) {
   int lo = 0, hi = n;
@@ -115,15 +116,16 @@ __device__ __forceinline__ int seg_lower_bound(const int* __restrict__ m, int n,
 
 __global__ __launch_bounds__(256) void pair_pool_kernel(const PairTable pairs, const int* __restrict__ s2l0,
                                                         const int* __restrict__ s2l1, const float* __restrict__ dist,
-                                                        float* __restrict__ dk_out, int* __restrict__ scratch) {
-  extern __shared__ int pm_lds[];                    // seg1[k1+1] | seg0[PM_ROWS+1]
+                                                        float* __restrict__ dk_out, int* __restrict__ scratch, int seg1_global) {
+  extern __shared__ int pm_lds[];                    // seg1[k1+1] | seg0[PM_ROWS+1]   (seg1_global: seg0 only)
   const PairDesc pd = pairs.get(blockIdx.y);
   const int chunk = blockIdx.x;
   if (chunk >= pd.chunks || pd.k1 <= 0) return;
   const int tid = threadIdx.x;
   const int i0 = chunk * PM_ROWS, rows = min(PM_ROWS, pd.k0 - i0);
-  int* seg1 = pm_lds;
-  int* seg0 = pm_lds + pd.k1 + 1;
+  // large images: every block of the pair builds the (identical) seg1 table in the pair's scratch region instead
+  int* seg1 = seg1_global ? scratch + pd.off_seg + 2 * (int64_t)pd.k0 + pd.k1 + 2 * (int64_t)pd.chunks * pd.k1 : pm_lds;
+  int* seg0 = seg1_global ? pm_lds : pm_lds + pd.k1 + 1;
   const int* m0 = s2l0 + pd.off_s0;
   const int* m1 = s2l1 + pd.off_s1;
   // segment starts: sub-lines of a key-line are contiguous and key-line ids non-decreasing, so a start is where the id

@@ -178,7 +178,14 @@ class LineTransformer(nn.Module):
     def _weights_version(self):
         """Changes whenever a parameter / buffer is modified in place (optimizer step, p.data.copy_, fine-tuning): the
         native engine holds a folded COPY of the weights and must be rebuilt then."""
-        return sum(int(t._version) for t in list(self.parameters()) + list(self.buffers()))
+        key = []
+        for t in list(self.parameters()) + list(self.buffers()):
+            try:
+                v = int(t._version)
+            except RuntimeError:          # inference tensors (built / loaded under torch.inference_mode()) keep no counter
+                v = -1
+            key.append((t.data_ptr(), v))     # data_ptr: `p.data = new_tensor` rebinds storage without touching _version
+        return tuple(key)
 
     # the native handle is a ctypes pointer: never pickled / deep-copied, rebuilt on first use instead
     def __getstate__(self):

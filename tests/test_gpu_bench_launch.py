@@ -1,0 +1,37 @@
+"""GPU: `python bench.py --gpus 2` with no launcher around it must start two ranks by itself and print ONE JSON line
+for the two-rank job.  On the single-GPU test box both ranks share cuda:0 and the collective runs over gloo
+(LINETR_BENCH_ONE_DEVICE / LINETR_BENCH_BACKEND test hooks): the plumbing is what is checked, not the numbers."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _run(extra):
+    env = dict(os.environ, LINETR_BENCH_ONE_DEVICE="1", LINETR_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--settle-s", "0.2", *extra], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_default_workload_self_launch():
+    d = _run(["--pairs", "4"])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["descriptors_per_step"] > 2 * 4 * 2 * 150      # both ranks' descriptors are counted
+    assert d["gathered_rows_checked"] is True and d["gather_ms"] > 0 and d["collective_backend"] == "gloo"
+    assert d["global_match"]["matches"] > 0
+
+
+def test_cfg4_self_launch():
+    d = _run(["--workload", "cfg4", "--pairs-total", "16", "--pairs", "4"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"

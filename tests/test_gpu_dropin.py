@@ -75,6 +75,25 @@ def test_linetransformer_quirks_and_empty():
         m.preprocess(bad, (1, 1, *hw), sp)
 
 
+def test_module_built_under_inference_mode_and_rebound_weights():
+    """Inference tensors keep no version counter (reading `_version` raises): a module built, loaded and run under
+    torch.inference_mode() must work, and re-binding a parameter's storage (p.data = ...) must rebuild the native engine."""
+    g = load("tiny_validmask")
+    dd, ds, hw = tiny_maps(g)
+    with torch.inference_mode():
+        m = make_lt()
+        sp = {"dense_descriptor": dd.cuda(), "dense_score": ds.cuda()}
+        pre = m.preprocess(synth.array_to_keylines(g["lines"]), (1, 1, *hw), sp)
+        ref = m(pre)["line_desc"].clone()
+    m2 = make_lt()
+    pre2 = m2.preprocess(synth.array_to_keylines(g["lines"]), (1, 1, *hw), sp)
+    assert torch.equal(m2(pre2)["line_desc"], ref)
+    p = m2.final_proj.weight
+    p.data = -p.data.clone()                       # new storage, version counter untouched
+    flipped = m2(pre2)["line_desc"]
+    assert not torch.allclose(flipped, ref, atol=1e-3)
+
+
 class FakeSuperPoint(torch.nn.Module):
     """Synthetic SuperPoint stand-in: seeded dense maps + random unit point descriptors."""
     config = {"nn_threshold": 0.7}

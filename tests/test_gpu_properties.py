@@ -182,3 +182,24 @@ def test_cfg3_step_runs_on_the_intended_kernels(eng, monkeypatch):
     assert prof.get("sig_attn_bf16x6") == 7 and prof.get("cls_pool_online") == 1, prof
     assert "row_norm" not in prof, prof
     assert not [k for k in prof if k.startswith("gemm_") and k not in ("gemm_bf16x6_128x256", "gemm_bf16x6_128x128s", "gemm_bf16x6_128x64")], prof
+
+
+def test_matcher_beyond_the_lds_segment_table():
+    """An image with more key-points than fit the matcher's LDS segment table (12 000): the reference has no limit
+    (max_keypoints = -1, models/superpoint.py; nn_matcher.py:33-42), the kernels switch to a table in the workspace.
+    Both entry points against the oracle's NumPy restatement."""
+    from linetr_amd import nn_matcher as NM
+    from oracle import linetr_oracle as O
+    rs = np.random.RandomState(11)
+    n0, n1 = 70, 12001
+    d0 = rs.standard_normal((256, n0)).astype(np.float32)
+    d1 = rs.standard_normal((256, n1)).astype(np.float32)
+    d0 /= np.linalg.norm(d0, axis=0, keepdims=True)
+    d1 /= np.linalg.norm(d1, axis=0, keepdims=True)
+    d1[:, 11990:12001] = d0[:, 5:16]                      # planted mutual matches in the last columns
+    mat, dist = NM.nn_matcher(d0, d1, 0.8, True)
+    _, want_d = O.point_nn(d0, d1, 0.8, True)
+    assert np.abs(dist - want_d).max() < 1e-5
+    assert np.array_equal(mat, O.mutual_nn(dist, 0.8, True))      # same argmin rules on the SAME float32 distances
+    assert mat[0][5:16, 11990:12001].trace() == 11
+    assert np.array_equal(NM.nn_matcher_distmat(dist, 0.8, True), O.mutual_nn(dist, 0.8, True))
