@@ -14,6 +14,7 @@
 #include "lt_gemm_split.h"
 #include "lt_gemm_split16.h"
 #include "lt_gemm_st.h"
+#include "lt_gemm_chain.h"
 #include "lt_gemm_small.h"
 #include "lt_mlp_fused.h"
 #include "lt_match.h"
@@ -296,6 +297,54 @@ int run_gemm(LinetrHandle* h, hipStream_t st, const float* A, int lda, const flo
   sa.gWsp = gW * 6;
   ProfScope ps(h, st, gemm_class_name(g, groups, "gemm_bf16x6"), fl, by);
   return gemm_split_launch<3>(sa, groups, st);
+}
+
+// ---- row-tile-local GEMM chains (lt_gemm_chain.h) ----------------------------------------------------------------
+struct ChainBuilder {
+  LinetrHandle* h;
+  ChainArgs c;
+  double flops = 0, bytes = 0;
+  int err = 0;
+  explicit ChainBuilder(LinetrHandle* h_) : h(h_) {}
+  // Y[M,N] = norm(act(A (| A2) W^T + bias) (+ R)) (+ add2)
+  void add(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, const float* bias, const float* R,
+           float* Y, int M, int N, int K, int act, const NormSpec* ns = nullptr) {
+    if (err) return;
+    if (c.n >= CHAIN_MAX) { err = fail(LINETR_E_ARG, "gemm chain: too many stages"); return; }
+    auto it = h->split.find(W);
+    if (it == h->split.end()) { err = fail(LINETR_E_ARG, "gemm chain: weight has no split-bf16 copy"); return; }
+    SplitGemmArgs& sa = c.st[c.n++];
+    sa = SplitGemmArgs{};
+    GemmArgs& g = sa.g;
+    g = GemmArgs{};
+    g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.K1 = K1; g.W = W; g.ldw = K; g.bias = bias; g.R = R; g.ldr = N; g.Y = Y; g.ldy = N;
+    g.M = M; g.N = N; g.K = K; g.act = act;
+    if (ns) { g.norm = ns->mode; g.gamma = ns->gamma; g.beta = ns->beta; g.add2 = ns->add2; g.ldadd2 = D; g.eps = ns->eps; }
+    sa.Wsp = h->split_arena + it->second.off3;
+    sa.wide_epi = 1;
+    flops += 2.0 * M * (double)N * K;
+    bytes += 4.0 * ((double)M * K + (double)N * K + (double)M * N);
+  }
+  int run(hipStream_t st, const char* name) {
+    if (err) return err;
+    ProfScope ps(h, st, name, flops, bytes);
+    return gemm_chain_launch(c, st);
+  }
+};
+
+// A chain is one block per 128-row tile for the WHOLE chain: worth it when the row tiles fill the chip in one round (the
+// partly empty second round of a plain launch would be a whole chain long) or there are many rounds.
+bool chain_wins(const LinetrHandle* h, int rows) {
+  static const bool off = getenv("LINETR_NO_GEMM_CHAIN") != nullptr;     // A/B switch
+  if (off || h->precision != LINETR_PREC_BF16X6) return false;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  const int gy = cdiv(rows, 128);
+  return (gy >= 140 && gy <= n_cu) || gy >= 4 * n_cu;
 }
 
 // Y[M,256] = norm(epi(A W^T + bias) (+ R)) (+ add2).  The split-bf16 128x256 tile owns complete rows and normalises them
@@ -987,14 +1036,14 @@ int sig_network_st(LinetrHandle* h, hipStream_t st, FwdWs& w, const int32_t* h_c
     auto it = h->split.find(W);
     return (it == h->split.end() || !it->second.offst) ? nullptr : h->split_arena + it->second.offst;
   };
-  auto gemm = [&](const unsigned char* A1, int K1, const unsigned char* A2, int K2, const float* W, const float* bias,
+  auto gemm = [&](const char* role, const unsigned char* A1, int K1, const unsigned char* A2, int K2, const float* W, const float* bias,
                   const unsigned char* R, unsigned char* Yst, float* Y, int Nout, int act) -> int {
     StGemmArgs a;
     a.A1 = A1; a.nk1 = K1 / 16; a.A2 = A2; a.nk2 = A2 ? K2 / 16 : 0;
     a.W = wst(W); a.bias = bias ? bias : h->zeros; a.R = R; a.Yst = Yst; a.Y = Y; a.ldy = D; a.M = N; a.N = Nout; a.act = act;
     if (!a.W) return fail(LINETR_E_ARG, "sig_network_st: weight has no split-tile image");
     const double K = K1 + (A2 ? K2 : 0);
-    ProfScope ps(h, st, "gemm_st_bf16x6", 2.0 * N * Nout * K, 6.0 * ((double)N * K + (double)Nout * K + (double)N * Nout));
+    ProfScope ps(h, st, role, 2.0 * N * Nout * K, 6.0 * ((double)N * K + (double)Nout * K + (double)N * Nout));
     return gemm_st_launch(a, st);
   };
   if (st_bytes(N, 3 * D) >= (int64_t)1 << 32) return fail(LINETR_E_ARG, "sig_network_st: batch too large (q/k/v image >= 4 GiB)");
@@ -1010,7 +1059,7 @@ int sig_network_st(LinetrHandle* h, hipStream_t st, FwdWs& w, const int32_t* h_c
   for (int i = 0; i < n_images; ++i) { const double n = h_cu[i + 1] - h_cu[i]; attn_fl += 2.0 * 2.0 * n * n * D; }
   for (size_t l = 0; l < h->sig.size(); ++l) {
     const SigLayer& S = h->sig[l];
-    if ((e = gemm(z, D, nullptr, 0, S.Wqkv, S.bqkv, nullptr, w.qkvs, nullptr, 3 * D, ACT_NONE))) return e;
+    if ((e = gemm("gemm_st_bf16x6_qkv", z, D, nullptr, 0, S.Wqkv, S.bqkv, nullptr, w.qkvs, nullptr, 3 * D, ACT_NONE))) return e;
     {
       ProfScope ps(h, st, "sig_attn_st", attn_fl, (double)N * D * 24);
       static const bool occ1 = getenv("LINETR_ATTN_ST_OCC1") != nullptr;   // tuning aid: one block per CU, 256 VGPRs
@@ -1020,13 +1069,13 @@ int sig_network_st(LinetrHandle* h, hipStream_t st, FwdWs& w, const int32_t* h_c
                               n_images, N, w.msgs);
       LT_LAUNCH_CHECK();
     }
-    if ((e = gemm(z, D, w.msgs, D, S.W1, S.b1, nullptr, w.hids, nullptr, 2 * D, ACT_RELU))) return e;
+    if ((e = gemm("gemm_st_bf16x6_w1", z, D, w.msgs, D, S.W1, S.b1, nullptr, w.hids, nullptr, 2 * D, ACT_RELU))) return e;
     if (l + 1 == h->sig.size()) break;   // the last layer's second MLP GEMM is folded into the final projection
-    if ((e = gemm(w.hids, 2 * D, nullptr, 0, S.W2, S.b2, z, zn, nullptr, D, ACT_NONE))) return e;
+    if ((e = gemm("gemm_st_bf16x6_w2", w.hids, 2 * D, nullptr, 0, S.W2, S.b2, z, zn, nullptr, D, ACT_NONE))) return e;
     std::swap(z, zn);
   }
   // final_proj(z + W2 hid + b2) = [Wfin | Wfin W2] [z ; hid] + (Wfin b2 + bfin), then F.normalize
-  if ((e = gemm(z, D, w.hids, 2 * D, h->Wfin2, h->bfin2, nullptr, nullptr, w.zB, D, ACT_NONE))) return e;
+  if ((e = gemm("gemm_st_bf16x6_final", z, D, w.hids, 2 * D, h->Wfin2, h->bfin2, nullptr, nullptr, w.zB, D, ACT_NONE))) return e;
   ProfScope ps(h, st, "row_norm", 0, (double)N * D * 8);
   hipLaunchKernelGGL(row_norm_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, w.zB, N, 1, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, 0.f, d_line_desc);
@@ -1115,6 +1164,20 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   }
   if ((e = run_gemm(h, st, w.pooled, HEADS * POOLW, nullptr, 0, 0, h->Watt, h->batt, nullptr, 0, w.att, D, N, DH, POOLW,
                     ACT_NONE, HEADS, POOLW, (int64_t)DH * POOLW, DH, DH))) return e;
+  const bool chain = chain_wins(h, N) && !h->sig.empty();
+  float *z = w.zA, *zn = w.zB;
+  if (chain) {
+    if (ts.use_side) LT_HIP(hipStreamWaitEvent(st, h->ev_lpos, 0));
+    // [fc + LN] -> [w_1, GELU] -> [w_2 + residual + LN (+ line position)] -> [q/k/v of signature layer 0]: one launch
+    ChainBuilder cb(h);
+    NormSpec ns1; ns1.mode = 1; ns1.gamma = h->ln1g; ns1.beta = h->ln1b; ns1.eps = 1e-6f;
+    NormSpec ns2; ns2.mode = 1; ns2.gamma = h->ln2g; ns2.beta = h->ln2b; ns2.add2 = w.lpos; ns2.eps = 1e-6f;
+    cb.add(w.att, D, nullptr, 0, 0, h->Wfc, h->bfc, nullptr, w.o, N, D, D, ACT_NONE, &ns1);
+    cb.add(w.o, D, nullptr, 0, 0, h->Wf1, h->bf1, nullptr, w.f1, N, c.d_inner, D, ACT_GELU);
+    cb.add(w.f1, c.d_inner, nullptr, 0, 0, h->Wf2, h->bf2, w.o, w.zA, N, D, c.d_inner, ACT_NONE, &ns2);
+    cb.add(w.zA, D, nullptr, 0, 0, h->sig[0].Wqkv, h->sig[0].bqkv, nullptr, w.qkv, N, 3 * D, D, ACT_NONE);
+    if ((e = cb.run(st, "gemm_chain_bf16x6_cls"))) return e;
+  } else {
   {  // o = LN(fc(att) + cls)  (line_attention.py:36-40; the CLS residual sits in the bias)
     NormSpec ns; ns.mode = 1; ns.gamma = h->ln1g; ns.beta = h->ln1b; ns.eps = 1e-6f;
     if ((e = run_gemm_norm(h, st, w.att, D, nullptr, 0, 0, h->Wfc, h->bfc, nullptr, w.fc, w.o, N, D, ns))) return e;
@@ -1125,22 +1188,23 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     NormSpec ns; ns.mode = 1; ns.gamma = h->ln2g; ns.beta = h->ln2b; ns.add2 = w.lpos; ns.eps = 1e-6f;
     if ((e = run_gemm_norm(h, st, w.f1, c.d_inner, nullptr, 0, 0, h->Wf2, h->bf2, w.o, w.f2, w.zA, N, c.d_inner, ns))) return e;
   }
+  }
   // ---- line signature network
   // LINETR_SIG_PATH=st (experiment): activations stay in HBM as split-tile images and every K step travels by LDS-DMA
   // (lt_gemm_st.h, lt_attn_st.h).  Measured at cfg3 on one box: the ST GEMMs are 5-7 % faster than the register-staged
   // ones in isolation, but inside the step the 6-byte activations cost more at the kernel boundaries (the L2 write-back of
   // 273 MB instead of 182 MB of fresh activations per layer) than the main loops save: 2.92 vs 2.69 ms per step.
   static const char* sig_path = getenv("LINETR_SIG_PATH");
-  if (h->precision == LINETR_PREC_BF16X6 && !h->sig.empty() && sig_path && !strcmp(sig_path, "st"))
+  if (!chain && h->precision == LINETR_PREC_BF16X6 && !h->sig.empty() && sig_path && !strcmp(sig_path, "st"))
     return sig_network_st(h, st, w, h_cu, cu_dev, n_images, N, max_n, d_line_desc);
-  float *z = w.zA, *zn = w.zB;
   const int qtiles = cdiv(max_n, ATT_QT);
   // layers but the last: W1 -> ReLU -> W2 + residual in one kernel, hidden activations in registers (lt_mlp_fused.h)
   const bool fused_sig_mlp = h->precision != LINETR_PREC_F32 && N >= 4096 && !getenv("LINETR_NO_FUSED_SIG_MLP") &&
                              getenv("LINETR_FUSED_SIG_MLP") != nullptr;   // opt-in while it is being measured
   for (size_t l = 0; l < h->sig.size(); ++l) {
     const SigLayer& S = h->sig[l];
-    if ((e = run_gemm(h, st, z, D, nullptr, 0, 0, S.Wqkv, S.bqkv, nullptr, 0, w.qkv, 3 * D, N, 3 * D, D, ACT_NONE))) return e;
+    if (!chain)
+      if ((e = run_gemm(h, st, z, D, nullptr, 0, 0, S.Wqkv, S.bqkv, nullptr, 0, w.qkv, 3 * D, N, 3 * D, D, ACT_NONE))) return e;
     {
       double fl = 0;
       for (int i = 0; i < n_images; ++i) { double n = h_cu[i + 1] - h_cu[i]; fl += 2.0 * 2.0 * n * n * D; }
@@ -1165,6 +1229,27 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
                              w.msgp);
       }
       LT_LAUNCH_CHECK();
+    }
+    if (chain) {
+      ChainBuilder cb(h);
+      static const bool w1_alone = getenv("LINETR_CHAIN_W1_ALONE") != nullptr;     // A/B: W1 as its own launch (all 256 CUs)
+      if (w1_alone && l + 1 < h->sig.size()) {
+        if ((e = run_gemm(h, st, z, D, w.msgp, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ACT_RELU))) return e;
+      } else
+      cb.add(z, D, w.msgp, D, D, S.W1, S.b1, nullptr, w.hid, N, 2 * D, 2 * D, ACT_RELU);
+      if (l + 1 < h->sig.size()) {
+        // W1 -> W2 + residual -> the NEXT layer's q/k/v projection
+        cb.add(w.hid, 2 * D, nullptr, 0, 0, S.W2, S.b2, z, zn, N, D, 2 * D, ACT_NONE);
+        cb.add(zn, D, nullptr, 0, 0, h->sig[l + 1].Wqkv, h->sig[l + 1].bqkv, nullptr, w.qkv, N, 3 * D, D, ACT_NONE);
+        if ((e = cb.run(st, "gemm_chain_bf16x6_sig"))) return e;
+        std::swap(z, zn);
+        continue;
+      }
+      // last layer: W1 -> [final projection with W2 folded in] -> L2 normalisation
+      NormSpec nl2; nl2.mode = 2;
+      cb.add(z, D, w.hid, 2 * D, D, h->Wfin2, h->bfin2, nullptr, d_line_desc, N, D, 3 * D, ACT_NONE, &nl2);
+      if ((e = cb.run(st, "gemm_chain_bf16x6_final"))) return e;
+      return LINETR_OK;
     }
     if (fused_sig_mlp && l + 1 < h->sig.size()) {
       if ((e = run_sig_mlp(h, st, z, w.msgp, S, zn, N))) return e;
