@@ -280,7 +280,9 @@ int linetr_debug_gemm(LinetrHandle* h, const float* d_A, int32_t lda, const floa
                       const float* d_residual, float* d_Y, int32_t ldy, int32_t M, int32_t N, int32_t K,
                       int32_t act, int32_t cache_weights, void* stream);
 
-/* ---- split-tile ("ST") operands (csrc/lt_gemm_st.h) -------------------------------------------
+#ifdef LINETR_EXPERIMENTS
+/* ---- split-tile ("ST") operands (csrc/lt_gemm_st.h): experiments build only --------------------
+ * (liblinetr_hip_experiments.so, `python -m linetr_amd.build --experiments`; measured and not shipped)
  * The signature network keeps its activations in HBM pre-split into three bf16 planes, in 512-byte chunks that are the
  * LDS image of a 16-row x 16-column block (K-step-major), so that a GEMM's K steps travel by LDS-DMA.  These three entry points expose
  * the format and the kernel to the unit tests and micro-benchmarks (no reference counterpart: the reference's
@@ -297,6 +299,7 @@ int linetr_debug_from_st(LinetrHandle* h, const void* d_st, int32_t rows, int32_
 int linetr_debug_gemm_st(LinetrHandle* h, const void* d_A1, int32_t K1, const void* d_A2, int32_t K2, const void* d_W,
                          const float* d_bias, const void* d_R, void* d_Yst, float* d_Y, int32_t ldy, int32_t M, int32_t N,
                          int32_t act, void* stream);
+#endif  /* LINETR_EXPERIMENTS */
 
 /* ---- instrumentation ------------------------------------------------------------------------ */
 

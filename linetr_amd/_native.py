@@ -11,6 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblinetr_hip.so")
+# the same sources built with -DLINETR_EXPERIMENTS: tuning switches + the kernels that were measured and lost (tools/, tests)
+EXPERIMENTS_LIB_PATH = os.path.join(_HERE, "csrc", "liblinetr_hip_experiments.so")
 
 E_ASSERT = -4
 
@@ -43,18 +45,19 @@ class ProfileEntry(C.Structure):
                 ("bytes", C.c_double)]
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    """Load the in-tree shared library (built by ``python -m linetr_amd.build`` / __graft_entry__.build())."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def lib(path=None):
+    """Load the in-tree shared library (built by ``python -m linetr_amd.build`` / __graft_entry__.build()).
+    `path`: another build of the same sources (EXPERIMENTS_LIB_PATH, a tools/ variant); default = the product library,
+    or $LINETR_LIB when set."""
     # torch ships its own libamdhip64; importing it first makes liblinetr_hip.so bind to the SAME HIP runtime
     # (one context, shared streams and device pointers) instead of a second copy from /opt/rocm.
     import torch  # noqa: F401
-    path = os.environ.get("LINETR_LIB", LIB_PATH)   # tuning aid: load an experimental build of the same library
+    path = os.path.abspath(path or os.environ.get("LINETR_LIB", LIB_PATH))
+    if path in _libs:
+        return _libs[path]
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: the HIP extension has not been built (run `python -m linetr_amd.build`). "
@@ -94,23 +97,27 @@ def lib():
     L.linetr_get_precision.argtypes = [vp]
     L.linetr_debug_posenc.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp]
     L.linetr_debug_gemm.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
-    L.linetr_st_bytes.argtypes = [i64, i32]
-    L.linetr_st_bytes.restype = i64
-    L.linetr_debug_to_st.argtypes = [vp, vp, i32, i32, i32, vp, vp]
-    L.linetr_debug_from_st.argtypes = [vp, vp, i32, i32, vp, i32, vp]
-    L.linetr_debug_gemm_st.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    if hasattr(L, "linetr_debug_gemm_st"):      # experiments build only (include/linetr_hip.h, LINETR_EXPERIMENTS)
+        L.linetr_st_bytes.argtypes = [i64, i32]
+        L.linetr_st_bytes.restype = i64
+        L.linetr_debug_to_st.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+        L.linetr_debug_from_st.argtypes = [vp, vp, i32, i32, vp, i32, vp]
+        L.linetr_debug_gemm_st.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.linetr_set_profiling.argtypes = [vp, i32]
     L.linetr_get_profile.argtypes = [vp, C.POINTER(ProfileEntry), i32, C.POINTER(i32)]
     if L.linetr_abi_version() != 2:
         raise RuntimeError("liblinetr_hip.so ABI version mismatch")
-    _lib = L
+    _libs[path] = L
     return L
 
 
 EXPORTS = ["linetr_abi_version", "linetr_last_error", "linetr_create", "linetr_destroy", "linetr_prefilter",
            "linetr_prefilter_batch", "linetr_pack_lines", "linetr_tokenize_workspace_bytes", "linetr_tokenize", "linetr_forward_workspace_bytes",
            "linetr_forward", "linetr_describe_workspace_bytes", "linetr_describe", "linetr_match_workspace_bytes", "linetr_match", "linetr_match_gathered", "linetr_match_points",
-           "linetr_match_distmat", "linetr_match_distmat_workspace_bytes", "linetr_superpoint_heads", "linetr_set_precision", "linetr_get_precision", "linetr_debug_posenc", "linetr_debug_gemm", "linetr_st_bytes", "linetr_debug_to_st", "linetr_debug_from_st", "linetr_debug_gemm_st", "linetr_set_profiling", "linetr_get_profile"]
+           "linetr_match_distmat", "linetr_match_distmat_workspace_bytes", "linetr_superpoint_heads", "linetr_set_precision", "linetr_get_precision", "linetr_debug_posenc", "linetr_debug_gemm", "linetr_set_profiling", "linetr_get_profile"]
+
+
+EXPERIMENT_EXPORTS = ["linetr_st_bytes", "linetr_debug_to_st", "linetr_debug_from_st", "linetr_debug_gemm_st"]
 
 
 class NativeError(RuntimeError):

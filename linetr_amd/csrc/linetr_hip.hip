@@ -13,13 +13,19 @@
 #include "lt_gemm.h"
 #include "lt_gemm_split.h"
 #include "lt_gemm_split16.h"
+#ifdef LINETR_EXPERIMENTS
 #include "lt_gemm_st.h"
 #include "lt_gemm_chain.h"
+#endif
 #include "lt_gemm_small.h"
+#ifdef LINETR_EXPERIMENTS
 #include "lt_mlp_fused.h"
+#endif
 #include "lt_match.h"
 #include "lt_model.h"
+#ifdef LINETR_EXPERIMENTS
 #include "lt_attn_st.h"
+#endif
 #include "lt_producer.h"
 #include "lt_token.h"
 
@@ -87,7 +93,7 @@ namespace {
 // (8.9 M vs 8.4 M descriptors/s; NCHW-fed 8.27 M vs 7.94 M).  LINETR_SIDE_STREAM=1 turns the fork back on for
 // experiments; it still only applies to large batches (for a single pair the event waits cost more than they hide).
 bool side_stream_ready(LinetrHandle* h, int n_sublines) {
-  static const bool on = getenv("LINETR_SIDE_STREAM") != nullptr && getenv("LINETR_NO_SIDE_STREAM") == nullptr;
+  static const bool on = LT_XENV("LINETR_SIDE_STREAM") != nullptr && LT_XENV("LINETR_NO_SIDE_STREAM") == nullptr;
   if (!on || n_sublines < 8192) return false;
   if (h->side) return true;
   if (h->side_failed) return false;
@@ -223,7 +229,7 @@ struct ProfScope {
 const char* gemm_class_name(const GemmArgs& g, int groups, const char* kind) {
   const char* tile;
   if (strcmp(kind, "gemm_f32") != 0) {
-    static const char* tile_env = getenv("LINETR_GEMM_TILE");
+    static const char* tile_env = LT_XENV("LINETR_GEMM_TILE");
     tile = tile_env ? tile_env : split_tile_name(g, groups, strcmp(kind, "gemm_bf16x6") == 0 ? 3 : 2);
   } else if (g.N % 128 != 0) tile = "128x64";
   else {
@@ -231,7 +237,7 @@ const char* gemm_class_name(const GemmArgs& g, int groups, const char* kind) {
     tile = big >= 384 ? "128x128" : "64x128";
   }
   // LINETR_PROFILE_SHAPES=1: one profile class per GEMM shape (tuning aid)
-  static const bool by_shape = getenv("LINETR_PROFILE_SHAPES") != nullptr;
+  static const bool by_shape = LT_XENV("LINETR_PROFILE_SHAPES") != nullptr;
   static std::map<std::string, std::string> names;
   char buf[160];
   if (by_shape) snprintf(buf, sizeof buf, "%s_%s[M=%d,N=%d,K=%d,g=%d]", kind, tile, g.M, g.N, g.K, groups);
@@ -271,7 +277,8 @@ int run_gemm(LinetrHandle* h, hipStream_t st, const float* A, int lda, const flo
   if (it == h->split.end()) return fail(LINETR_E_ARG, "gemm: weight has no split-bf16 copy");
   SplitGemmArgs sa;
   sa.g = g;
-  if (getenv("LINETR_STREAMK")) {   // opt-in experiment (lt_gemm_split.h): the 32 MB workspace is only allocated when asked for
+#ifdef LINETR_EXPERIMENTS
+  if (LT_XENV("LINETR_STREAMK")) {   // opt-in experiment (lt_gemm_split.h): the 32 MB workspace is only allocated when asked for
     if (!h->sk_ws) {
       constexpr size_t slots = 256, slot_bytes = 128 * 256 * sizeof(float);
       LT_HIP(hipMalloc((void**)&h->sk_ws, slots * slot_bytes));
@@ -281,6 +288,7 @@ int run_gemm(LinetrHandle* h, hipStream_t st, const float* A, int lda, const flo
     }
     sa.sk_ws = h->sk_ws; sa.sk_flags = h->sk_flags; sa.sk_epoch = ++h->sk_epoch;
   }
+#endif
   if (h->precision == LINETR_PREC_BF16X3) {
     sa.Wsp = h->split_arena + it->second.off2;
     sa.gWsp = gW * 4;
@@ -299,6 +307,7 @@ int run_gemm(LinetrHandle* h, hipStream_t st, const float* A, int lda, const flo
   return gemm_split_launch<3>(sa, groups, st);
 }
 
+#ifdef LINETR_EXPERIMENTS
 // ---- row-tile-local GEMM chains (lt_gemm_chain.h) ----------------------------------------------------------------
 struct ChainBuilder {
   LinetrHandle* h;
@@ -335,8 +344,9 @@ struct ChainBuilder {
 // A chain is one block per 128-row tile for the WHOLE chain: worth it when the row tiles fill the chip in one round (the
 // partly empty second round of a plain launch would be a whole chain long) or there are many rounds.
 bool chain_wins(const LinetrHandle* h, int rows) {
-  static const bool off = getenv("LINETR_NO_GEMM_CHAIN") != nullptr;     // A/B switch
-  if (off || h->precision != LINETR_PREC_BF16X6) return false;
+  // opt-in (read per call): measured at cfg3, 2.70 vs 2.60 ms per step -- a chain keeps 199 of the 256 CUs busy for all of its
+  // stages and the per-tile prologue / epilogue cost, not the launch, is what a GEMM of this size pays
+  if (LT_XENV("LINETR_GEMM_CHAIN") == nullptr || h->precision != LINETR_PREC_BF16X6) return false;
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
@@ -347,14 +357,15 @@ bool chain_wins(const LinetrHandle* h, int rows) {
   return (gy >= 140 && gy <= n_cu) || gy >= 4 * n_cu;
 }
 
+#endif  // LINETR_EXPERIMENTS
 // Y[M,256] = norm(epi(A W^T + bias) (+ R)) (+ add2).  The split-bf16 128x256 tile owns complete rows and normalises them
 // in its epilogue (one launch and one [M,256] round trip less); every other case runs the GEMM into `tmp` and then
 // row_norm_kernel.  Same arithmetic either way.
 int run_gemm_norm(LinetrHandle* h, hipStream_t st, const float* A, int lda, const float* A2, int lda2, int K1,
                   const float* W, const float* bias, const float* R, float* tmp, float* Y, int M, int K,
                   const NormSpec& ns) {
-  const bool no_fuse = getenv("LINETR_NO_FUSED_NORM") != nullptr;   // tuning / test aid (read per call)
-  bool fuse = !no_fuse && h->precision != LINETR_PREC_F32 && !getenv("LINETR_GEMM_TILE") && !getenv("LINETR_GEMM_NARROW_EPI");
+  const bool no_fuse = LT_XENV("LINETR_NO_FUSED_NORM") != nullptr;   // tuning / test aid (read per call)
+  bool fuse = !no_fuse && h->precision != LINETR_PREC_F32 && !LT_XENV("LINETR_GEMM_TILE") && !LT_XENV("LINETR_GEMM_NARROW_EPI");
   if (fuse) {
     GemmArgs g{};
     g.M = M; g.N = D; g.K = K; g.lda = lda; g.ldy = D; g.ldr = D; g.R = R; g.A2 = A2; g.lda2 = lda2; g.K1 = K1;
@@ -369,6 +380,7 @@ int run_gemm_norm(LinetrHandle* h, hipStream_t st, const float* A, int lda, cons
   return 0;
 }
 
+#ifdef LINETR_EXPERIMENTS
 // z' = z + W2 relu(W1 [z ; msg] + b1) + b2 in one launch (split-bf16 modes only)
 int run_sig_mlp(LinetrHandle* h, hipStream_t st, const float* z, const float* msg, const SigLayer& S, float* out, int M) {
   auto i1 = h->split.find(S.W1), i2 = h->split.find(S.W2p);
@@ -393,6 +405,7 @@ int run_sig_mlp(LinetrHandle* h, hipStream_t st, const float* z, const float* ms
   return 0;
 }
 
+#endif  // LINETR_EXPERIMENTS
 // ---- float64 weight preparation ---------------------------------------------------------------
 
 struct TensorMap {
@@ -647,12 +660,14 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
     place_w(&S.Wqkv, Wqkv, 3 * D, D); place(&S.bqkv, bqkv);
     place_w(&S.W1, W1m, 2 * D, 2 * D); place(&S.b1, b1f);
     place_w(&S.W2, to_d(W2, (size_t)2 * D * D), D, 2 * D); place(&S.b2, to_d(b2, D));
+#ifdef LINETR_EXPERIMENTS
     {
       std::vector<double> W2perm((size_t)2 * D * D);
       for (int o = 0; o < D; ++o)
         for (int k = 0; k < 2 * D; ++k) W2perm[(size_t)o * 2 * D + k] = W2[(size_t)o * 2 * D + sig_mlp_kperm(k)];
       place_w(&S.W2p, W2perm, D, 2 * D);
     }
+#endif
   }
   {
     const float* W = tm.get("final_proj.weight", D * D, err);
@@ -696,7 +711,9 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
       sw.off2 = total; total += align_up(w.rows * w.K * 4, 256);
       sw.off3 = total; total += align_up(w.rows * w.K * 6, 256);
       sw.offh = total; total += align_up(w.rows * w.K * 4, 256);
+#ifdef LINETR_EXPERIMENTS
       if (w.rows % 16 == 0 && w.K % 32 == 0) { total = align_up(total, 1024); sw.offst = total; total += st_bytes(w.rows, w.K); }   // ST image (rows padded to 128)
+#endif
       H->split[*w.dst] = sw;
     }
     LT_HIP(hipMalloc((void**)&H->split_arena, total));
@@ -710,11 +727,13 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
                          H->split_arena + kv.second.off3, kv.second.rows, kv.second.K);
       hipLaunchKernelGGL((split_rows_kernel<2, 1>), dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, 0, kv.first,
                          H->split_arena + kv.second.offh, kv.second.rows, kv.second.K);
+#ifdef LINETR_EXPERIMENTS
       if (kv.second.offst) {
         const int64_t thr = st_row_blocks(kv.second.rows) * (kv.second.K / 16) * 32;
         hipLaunchKernelGGL(to_st_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, 0, kv.first, kv.second.K,
                            (int)kv.second.rows, kv.second.K / 16, H->split_arena + kv.second.offst);
       }
+#endif
     }
     LT_LAUNCH_CHECK();
     LT_HIP(hipDeviceSynchronize());
@@ -984,9 +1003,13 @@ FwdWs fwd_layout(const LinetrModelConfig& c, int N, int64_t rows, int n_images, 
   w.zA = take((int64_t)N * D); w.zB = take((int64_t)N * D);
   w.qkv = take((int64_t)N * 3 * D); w.msgp = take((int64_t)N * D); w.msg = take((int64_t)N * D);
   w.hid = take((int64_t)N * 2 * D);
+#ifdef LINETR_EXPERIMENTS
   auto take_st = [&](int cols) { unsigned char* p = (unsigned char*)(base + off); off += align_up(st_bytes(N, cols), 1024); return p; };
   off = align_up(off, 1024);
   w.zsA = take_st(D); w.zsB = take_st(D); w.qkvs = take_st(3 * D); w.msgs = take_st(D); w.hids = take_st(2 * D);
+#else
+  w.zsA = w.zsB = w.qkvs = w.msgs = w.hids = nullptr;
+#endif
   w.cu = (int*)take(n_images + 1);
   w.total = off;
   return w;
@@ -1014,7 +1037,7 @@ struct TokenStage {            // how the token stage (word MLP + CLS pooling) i
 };
 
 bool fused_mlp_enabled(const LinetrModelConfig& c) {
-  static const bool off = getenv("LINETR_NO_FUSED_MLP") != nullptr;   // tuning aid: the three-launch chain
+  static const bool off = LT_XENV("LINETR_NO_FUSED_MLP") != nullptr;   // tuning aid: the three-launch chain
   return !off && c.enc_channels[1] == 64 && c.enc_channels[2] == 128;
 }
 
@@ -1022,12 +1045,13 @@ bool fused_mlp_enabled(const LinetrModelConfig& c) {
 // so one wave fits a SIMD (1024 on the chip) and workgroup dispatch is slow for such fat blocks (~10 blocks/us
 // measured): give every wave one long run of rows -- a single round of <= 256 blocks -- rather than many short ones.
 int mlp123_rows_per_wave(int64_t rows) {
-  static const char* env = getenv("LINETR_MLP_RPW");   // tuning aid
+  static const char* env = LT_XENV("LINETR_MLP_RPW");   // tuning aid
   if (env) return atoi(env);
   const int64_t waves = 256 * 4;
   return (int)std::max<int64_t>(cdiv((int)cdiv((int)rows, (int)waves), 32) * 32, 32);
 }
 
+#ifdef LINETR_EXPERIMENTS
 // Signature network on split-tile operands: z -> [q|k|v] -> attention -> W1 [z ; message] -> W2 + z, seven times, then the
 // final projection (with the last W2 folded in) and the L2 normalisation.  models/line_transformer.py:132-183, 245-246.
 int sig_network_st(LinetrHandle* h, hipStream_t st, FwdWs& w, const int32_t* h_cu, const int* cu_dev, int n_images, int N,
@@ -1062,7 +1086,7 @@ int sig_network_st(LinetrHandle* h, hipStream_t st, FwdWs& w, const int32_t* h_c
     if ((e = gemm("gemm_st_bf16x6_qkv", z, D, nullptr, 0, S.Wqkv, S.bqkv, nullptr, w.qkvs, nullptr, 3 * D, ACT_NONE))) return e;
     {
       ProfScope ps(h, st, "sig_attn_st", attn_fl, (double)N * D * 24);
-      static const bool occ1 = getenv("LINETR_ATTN_ST_OCC1") != nullptr;   // tuning aid: one block per CU, 256 VGPRs
+      const bool occ1 = LT_XENV("LINETR_ATTN_ST_OCC1") != nullptr;   // tuning aid: one block per CU, 256 VGPRs
       if (occ1) hipLaunchKernelGGL(sig_attn_st_kernel<1>, dim3(n_images, HEADS, cdiv(max_n, 256)), dim3(512), 0, st, w.qkvs, cu_dev,
                                    n_images, N, w.msgs);
       else hipLaunchKernelGGL(sig_attn_st_kernel<2>, dim3(n_images, HEADS, cdiv(max_n, 256)), dim3(512), 0, st, w.qkvs, cu_dev,
@@ -1083,6 +1107,7 @@ int sig_network_st(LinetrHandle* h, hipStream_t st, FwdWs& w, const int32_t* h_c
   return LINETR_OK;
 }
 
+#endif  // LINETR_EXPERIMENTS
 int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const float* sublines, const float* resp,
                  const float* angle_sub, const int32_t* h_cu, const int* cu_dev, int n_images, int N, int T,
                  float* d_line_desc, FwdWs& w) {
@@ -1140,12 +1165,18 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   }
   // ---- CLS-row attention pooling + value/last-MLP projection
   if (ts.cpnt) {
-    static const bool two_pass = getenv("LINETR_POOL_TWO_PASS") != nullptr;  // tuning aid: the LDS two-pass variant
+#ifdef LINETR_EXPERIMENTS
+    static const bool two_pass = LT_XENV("LINETR_POOL_TWO_PASS") != nullptr;  // tuning aid: the LDS two-pass variant
+#else
+    constexpr bool two_pass = false;
+#endif
     if (!two_pass) {
       ProfScope ps(h, st, "cls_pool_online", 2.0 * rows * (2.0 * HEADS * D * 2), (double)rows * D * 4 * 5);
       hipLaunchKernelGGL(cls_pool_online_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, ts.recs, ts.sub2line_g, ts.cpnt,
                          w.a4, ts.first_pad, N, T, ts.nhwc, ts.Hc, ts.Wc, ts.align_corners, h->pool, w.pooled);
-    } else {
+    }
+#ifdef LINETR_EXPERIMENTS
+    else {
       ProfScope ps(h, st, "cls_pool_fused", 2.0 * rows * (2.0 * HEADS * D * 2), (double)rows * D * 4 * 5);
       const size_t lds = ((size_t)(T + 1) * D + HEADS * (T + 2)) * sizeof(float);
       if (lds > 160 * 1024) return fail(LINETR_E_ARG, "describe: max_tokens too large for the fused pooling kernel");
@@ -1155,6 +1186,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
       hipLaunchKernelGGL(cls_pool_fused_kernel, dim3(N), dim3(256), lds, st, ts.recs, ts.sub2line_g, ts.cpnt, w.a4,
                          ts.first_pad, T, ts.nhwc, ts.Hc, ts.Wc, ts.align_corners, h->pool, w.pooled);
     }
+#endif
     LT_LAUNCH_CHECK();
   } else {
     ProfScope ps(h, st, "cls_pool", 2.0 * rows * (2.0 * HEADS * D * 2), (double)rows * D * 8);
@@ -1164,8 +1196,13 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   }
   if ((e = run_gemm(h, st, w.pooled, HEADS * POOLW, nullptr, 0, 0, h->Watt, h->batt, nullptr, 0, w.att, D, N, DH, POOLW,
                     ACT_NONE, HEADS, POOLW, (int64_t)DH * POOLW, DH, DH))) return e;
+#ifdef LINETR_EXPERIMENTS
   const bool chain = chain_wins(h, N) && !h->sig.empty();
+#else
+  constexpr bool chain = false;
+#endif
   float *z = w.zA, *zn = w.zB;
+#ifdef LINETR_EXPERIMENTS
   if (chain) {
     if (ts.use_side) LT_HIP(hipStreamWaitEvent(st, h->ev_lpos, 0));
     // [fc + LN] -> [w_1, GELU] -> [w_2 + residual + LN (+ line position)] -> [q/k/v of signature layer 0]: one launch
@@ -1177,7 +1214,9 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     cb.add(w.f1, c.d_inner, nullptr, 0, 0, h->Wf2, h->bf2, w.o, w.zA, N, D, c.d_inner, ACT_NONE, &ns2);
     cb.add(w.zA, D, nullptr, 0, 0, h->sig[0].Wqkv, h->sig[0].bqkv, nullptr, w.qkv, N, 3 * D, D, ACT_NONE);
     if ((e = cb.run(st, "gemm_chain_bf16x6_cls"))) return e;
-  } else {
+  } else
+#endif
+  {
   {  // o = LN(fc(att) + cls)  (line_attention.py:36-40; the CLS residual sits in the bias)
     NormSpec ns; ns.mode = 1; ns.gamma = h->ln1g; ns.beta = h->ln1b; ns.eps = 1e-6f;
     if ((e = run_gemm_norm(h, st, w.att, D, nullptr, 0, 0, h->Wfc, h->bfc, nullptr, w.fc, w.o, N, D, ns))) return e;
@@ -1194,13 +1233,17 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   // (lt_gemm_st.h, lt_attn_st.h).  Measured at cfg3 on one box: the ST GEMMs are 5-7 % faster than the register-staged
   // ones in isolation, but inside the step the 6-byte activations cost more at the kernel boundaries (the L2 write-back of
   // 273 MB instead of 182 MB of fresh activations per layer) than the main loops save: 2.92 vs 2.69 ms per step.
-  static const char* sig_path = getenv("LINETR_SIG_PATH");
+#ifdef LINETR_EXPERIMENTS
+  const char* sig_path = LT_XENV("LINETR_SIG_PATH");      // read per call (tests switch it)
   if (!chain && h->precision == LINETR_PREC_BF16X6 && !h->sig.empty() && sig_path && !strcmp(sig_path, "st"))
     return sig_network_st(h, st, w, h_cu, cu_dev, n_images, N, max_n, d_line_desc);
+#endif
   const int qtiles = cdiv(max_n, ATT_QT);
   // layers but the last: W1 -> ReLU -> W2 + residual in one kernel, hidden activations in registers (lt_mlp_fused.h)
-  const bool fused_sig_mlp = h->precision != LINETR_PREC_F32 && N >= 4096 && !getenv("LINETR_NO_FUSED_SIG_MLP") &&
-                             getenv("LINETR_FUSED_SIG_MLP") != nullptr;   // opt-in while it is being measured
+#ifdef LINETR_EXPERIMENTS
+  const bool fused_sig_mlp = h->precision != LINETR_PREC_F32 && N >= 4096 && !LT_XENV("LINETR_NO_FUSED_SIG_MLP") &&
+                             LT_XENV("LINETR_FUSED_SIG_MLP") != nullptr;   // opt-in: measured slower
+#endif
   for (size_t l = 0; l < h->sig.size(); ++l) {
     const SigLayer& S = h->sig[l];
     if (!chain)
@@ -1209,15 +1252,15 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
       double fl = 0;
       for (int i = 0; i < n_images; ++i) { double n = h_cu[i + 1] - h_cu[i]; fl += 2.0 * 2.0 * n * n * D; }
       // exact-fp32 MFMA attention in f32 mode, fp32-faithful split-bf16 (6 products) otherwise
-      static const bool force_f32_attn = getenv("LINETR_ATTN_F32") != nullptr;
+      static const bool force_f32_attn = LT_XENV("LINETR_ATTN_F32") != nullptr;
       if (h->precision == LINETR_PREC_F32 || force_f32_attn) {
         ProfScope ps(h, st, "sig_attn", fl, (double)N * D * 16);
         hipLaunchKernelGGL(sig_attn_kernel, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
       } else {
         ProfScope ps(h, st, "sig_attn_bf16x6", fl, (double)N * D * 16);
-        static const bool attn4 = getenv("LINETR_ATTN_4WAVE") != nullptr;   // tuning aid: 128-query blocks
+        static const bool attn4 = LT_XENV("LINETR_ATTN_4WAVE") != nullptr;   // tuning aid: 128-query blocks
         // few (image, head) pairs: 64-query blocks, so that a single pair still spreads over 32 CUs instead of 8
-        static const bool no_small_attn = getenv("LINETR_NO_SMALL_ATTN") != nullptr;   // tuning aid
+        static const bool no_small_attn = LT_XENV("LINETR_NO_SMALL_ATTN") != nullptr;   // tuning aid
         // few (image, head) pairs: 32-query blocks whose 4 waves also split the KV range (a single pair spreads over 56 CUs
         // and the critical path is 2 KV chunks instead of 7)
         if (!attn4 && !no_small_attn && (int64_t)n_images * HEADS * cdiv(max_n, 256) < 64)
@@ -1230,9 +1273,10 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
       }
       LT_LAUNCH_CHECK();
     }
+#ifdef LINETR_EXPERIMENTS
     if (chain) {
       ChainBuilder cb(h);
-      static const bool w1_alone = getenv("LINETR_CHAIN_W1_ALONE") != nullptr;     // A/B: W1 as its own launch (all 256 CUs)
+      const bool w1_alone = LT_XENV("LINETR_CHAIN_W1_ALONE") != nullptr;     // A/B: W1 as its own launch (all 256 CUs)
       if (w1_alone && l + 1 < h->sig.size()) {
         if ((e = run_gemm(h, st, z, D, w.msgp, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ACT_RELU))) return e;
       } else
@@ -1256,6 +1300,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
       std::swap(z, zn);
       continue;
     }
+#endif
     if ((e = run_gemm(h, st, z, D, w.msgp, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ACT_RELU))) return e;
     if (l + 1 == h->sig.size()) break;   // the last layer's second MLP GEMM is folded into the final projection below
     if ((e = run_gemm(h, st, w.hid, 2 * D, nullptr, 0, 0, S.W2, S.b2, z, D, zn, D, N, D, 2 * D, ACT_NONE))) return e;
@@ -1677,7 +1722,7 @@ extern "C" int linetr_superpoint_heads(LinetrHandle* h, const float* d_score_log
   if (d_dense_desc_nhwc || d_dense_desc_nchw) {
     const double by = (double)B * HW * D * 4.0 * (1 + (d_dense_desc_nhwc ? 1 : 0) + (d_dense_desc_nchw ? 1 : 0));
     ProfScope ps(h, st, "sp_desc_head", 3.0 * B * HW * D, by);
-    static const int cells = getenv("LINETR_SP_CELLS") ? atoi(getenv("LINETR_SP_CELLS")) : 32;   // tuning aid
+    static const int cells = LT_XENV("LINETR_SP_CELLS") ? atoi(LT_XENV("LINETR_SP_CELLS")) : 32;   // tuning aid
     if (cells == 64) hipLaunchKernelGGL(sp_desc_head_kernel<64>, grid, dim3(256), 0, st, d_desc_raw, d_dense_desc_nhwc, d_dense_desc_nchw, HW);
     else hipLaunchKernelGGL(sp_desc_head_kernel<32>, dim3((unsigned)cdiv(HW, 32), (unsigned)B), dim3(256), 0, st, d_desc_raw, d_dense_desc_nhwc, d_dense_desc_nchw, HW);
     LT_LAUNCH_CHECK();
@@ -1748,6 +1793,7 @@ extern "C" int linetr_debug_gemm(LinetrHandle* h, const float* A, int32_t lda, c
   return e;
 }
 
+#ifdef LINETR_EXPERIMENTS
 // ---- split-tile (ST) format and GEMM (lt_gemm_st.h), for the unit tests and micro-benchmarks
 extern "C" int64_t linetr_st_bytes(int64_t rows, int32_t K) { return (K % 16 || rows < 0) ? -1 : st_bytes(rows, K); }
 
@@ -1787,6 +1833,7 @@ extern "C" int linetr_debug_gemm_st(LinetrHandle* h, const void* d_A1, int32_t K
   return gemm_st_launch(a, (hipStream_t)stream);
 }
 
+#endif  // LINETR_EXPERIMENTS
 #ifdef LT_MLP_STAMPS
 extern "C" int linetr_debug_mlp_stamps(unsigned long long* out) {   // debug build only (tools/mlp_stamps.py)
   LT_HIP(hipDeviceSynchronize());

@@ -23,6 +23,17 @@ constexpr int WAVE = 64;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// The shipped library (liblinetr_hip.so) is built WITHOUT LINETR_EXPERIMENTS: no tuning switches, none of the kernels that
+// were measured and lost (stream-K tail, fused signature MLP, split-tile / LDS-DMA path, GEMM chains, side stream, two-pass
+// pooling, four-wave tiles).  `python -m linetr_amd.build --experiments` builds liblinetr_hip_experiments.so from the same
+// sources with everything in, for tools/ and tests/test_gpu_experiments.py.  LT_XENV is getenv there and a constant null
+// pointer in the product, so every switch folds away.
+#ifdef LINETR_EXPERIMENTS
+#define LT_XENV(name) getenv(name)
+#else
+#define LT_XENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 inline thread_local std::string g_err;
 
 inline int fail(int code, const char* fmt, ...) {

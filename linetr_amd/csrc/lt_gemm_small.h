@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_split_small_kernel(SplitGemmArg
 
 // dispatched when even 64 x 64 tiles would leave most CUs without a block
 inline bool small_gemm_wins(const GemmArgs& g, int groups) {
-  static const bool off = getenv("LINETR_NO_SMALL_GEMM") != nullptr;   // tuning aid
+  static const bool off = LT_XENV("LINETR_NO_SMALL_GEMM") != nullptr;   // tuning aid
   if (off || g.N % 32 != 0 || g.K % 32 != 0 || g.K < 128) return false;
   if (g.lda % 4 != 0 || g.ldy % 4 != 0 || (g.R && g.ldr % 4 != 0) || (g.A2 && (g.lda2 % 4 != 0 || g.K1 % 32 != 0))) return false;
   return (int64_t)cdiv(g.M, 64) * (g.N / 64) * groups < 256;
@@ -173,8 +173,8 @@ template <int PL, int FMT>
 inline void gemm_split_small_launch(const SplitGemmArgs& sa, int groups, hipStream_t st) {
   dim3 grid((unsigned)((sa.g.N / 32) * cdiv(sa.g.M, 32)), (unsigned)groups);
   // K >= 256: eight waves split K (half the loads, splits and MFMAs on every wave's critical path)
-  static const bool w4 = getenv("LINETR_SMALL_GEMM_4WAVE") != nullptr;   // tuning aid
-  static const bool no2 = getenv("LINETR_SMALL_GEMM_NO_2PERCU") != nullptr;   // tuning aid
+  static const bool w4 = LT_XENV("LINETR_SMALL_GEMM_4WAVE") != nullptr;   // tuning aid
+  static const bool no2 = LT_XENV("LINETR_SMALL_GEMM_NO_2PERCU") != nullptr;   // tuning aid
   // the 8-wave block claims 121 KB of LDS = one block per CU: a grid of 257..512 blocks (q/k/v of a single pair: 312) would
   // run two rounds; four waves with one staging buffer (62 KB) put two blocks on a CU and finish it in one
   const int64_t blocks = (int64_t)grid.x * grid.y;

@@ -684,7 +684,7 @@ inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t
   constexpr size_t lds_epi = (size_t)BM * BN * sizeof(float);    // every wave's TM x TN accumulator tile
   constexpr bool epi_fits = lds_epi <= 160 * 1024;
   constexpr size_t lds = (epi_fits && lds_epi > lds_main) ? lds_epi : lds_main;
-  static const bool narrow = getenv("LINETR_GEMM_NARROW_EPI") != nullptr;   // tuning aid: direct dword stores
+  static const bool narrow = LT_XENV("LINETR_GEMM_NARROW_EPI") != nullptr;   // tuning aid: direct dword stores
   SplitGemmArgs sa2 = sa;
   // the LDS epilogue needs 16-byte aligned rows (ldy / ldr multiples of 4 floats; the entry points guarantee it for
   // their own buffers, debug_gemm checks it)
@@ -698,6 +698,7 @@ inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t
   }
   dim3 grid((sa.g.N / BN) * cdiv(sa.g.M, BM), groups);
   sa2.sk_first = sa2.sk_blocks = 0;
+#ifdef LINETR_EXPERIMENTS
   if constexpr (PIPE && BM == 128 && BN == 256) {
     // stream-K tail: when the last round of tiles would leave a good part of the chip idle, those tiles are shared by one
     // block per CU instead (see the kernel).  Measured quantisation: 25472 x 512 x 512 (398 tiles) took as long as
@@ -707,7 +708,7 @@ inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t
     // 25472x768x256 114 us vs 82 us -- because the segment loop's extra state spills 60 VGPRs and 70 SGPRs next to the
     // 256-register pipelined main loop, which slows the data-parallel tiles of the same launch as well.  Kept as the
     // starting point for a leaner version.
-    const bool no_sk = getenv("LINETR_STREAMK") == nullptr;
+    const bool no_sk = LT_XENV("LINETR_STREAMK") == nullptr;
     static int n_cu = 0;
     if (!n_cu) {
       int dev = 0;
@@ -734,6 +735,7 @@ inline void gemm_split_launch_t(const SplitGemmArgs& sa, int groups, hipStream_t
       return;
     }
   }
+#endif
   hipLaunchKernelGGL((gemm_split_kernel<BM, BN, WM, WN, PL, DB, FMT, PFD, PIPE>), grid, dim3(WM * WN * 64), lds, st, sa2);
 }
 
@@ -753,7 +755,7 @@ inline bool small_gemm_wins(const GemmArgs& g, int groups);
 inline const char* split_tile_name(const GemmArgs& g, int groups, int pl = 3) {
   if (small_gemm_wins(g, groups)) return "32x32k4";   // latency-bound sizes: barrier-free K-split kernel
   if (g.N % 128 != 0) return "128x64";
-  static const bool no112 = getenv("LINETR_NO_TILE112") != nullptr;   // tuning aid
+  static const bool no112 = LT_XENV("LINETR_NO_TILE112") != nullptr;   // tuning aid
   if (!no112 && pl == 2 && split16_wins(g, groups)) return "112x256";   // saves a round of blocks (lt_gemm_split16.h)
   const int64_t r128 = cdiv(g.M, 128), r64 = cdiv(g.M, 64);
   // short K, wide N, many tiles: the single-buffered 128x128 tile (64 KB of LDS, eight waves at 102 VGPRs: two blocks =
@@ -761,7 +763,7 @@ inline const char* split_tile_name(const GemmArgs& g, int groups, int pl = 3) {
   // 25472x768x256 73 vs 80 us, 291208x256x128 (the word-MLP layer) 192 vs 225 us; in the cfg3 step its nine launches take
   // 0.75 ms (0.85 ms with the earlier four-wave layout at 212 VGPRs = 2 waves per SIMD).  For the other shapes the two
   // tiles are level inside the step.
-  static const bool no128s = getenv("LINETR_NO_TILE128S") != nullptr;   // tuning aid
+  static const bool no128s = LT_XENV("LINETR_NO_TILE128S") != nullptr;   // tuning aid
   if (!no128s && pl == 3 && r128 * (g.N / 128) * groups >= 1024 && ((g.K <= 256 && g.N >= 768) || g.K <= 128)) return "128x128s";
   if (g.N % 256 == 0 && r128 * (g.N / 256) * groups >= 140) return "128x256";
   if (g.N % 256 != 0 && (int64_t)cdiv(g.M, 256) * (g.N / 128) * groups >= 192) return "256x128";
@@ -777,12 +779,12 @@ inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st
   if (g.M <= 0) return 0;
   if (g.N % 64 != 0 || g.K % 32 != 0 || (g.A2 && g.K1 % 32 != 0))
     return fail(LINETR_E_ARG, "gemm_split: unsupported shape M=%d N=%d K=%d", g.M, g.N, g.K);
-  static const char* tile_env = getenv("LINETR_GEMM_TILE");  // tuning aid: force a tile
+  static const char* tile_env = LT_XENV("LINETR_GEMM_TILE");  // tuning aid: force a tile
   const char* tile = tile_env ? tile_env : split_tile_name(g, groups, PL);
   // the launcher is authoritative about the fused row normalisation: only the 128x256 tile with the LDS epilogue owns
   // complete rows of an N = 256 problem; anything else would silently skip the normalisation
   if (g.norm != 0) {
-    static const bool narrow_env = getenv("LINETR_GEMM_NARROW_EPI") != nullptr;
+    static const bool narrow_env = LT_XENV("LINETR_GEMM_NARROW_EPI") != nullptr;
     if (strcmp(tile, "128x256") != 0 || g.N != 256 || narrow_env || g.ldy % 4 != 0 || (g.R && g.ldr % 4 != 0))
       return fail(LINETR_E_ARG, "gemm_split: fused row normalisation asked of tile %s (N=%d): dispatcher bug", tile, g.N);
   }
@@ -790,9 +792,12 @@ inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st
   else if (!strcmp(tile, "112x256")) gemm_split16_launch<PL, FMT>(sa, st);
   else if (g.N % 128 != 0 || !strcmp(tile, "128x64")) gemm_split_launch_t<128, 64, 4, 1, PL, true, FMT>(sa, groups, st);
   else if (!strcmp(tile, "256x128")) {
-    static const bool nopipe = getenv("LINETR_GEMM_NOPIPE") != nullptr;   // tuning aid: the pre-pipelining main loop
+#ifdef LINETR_EXPERIMENTS
+    static const bool nopipe = LT_XENV("LINETR_GEMM_NOPIPE") != nullptr;   // tuning aid: the pre-pipelining main loop
     if (nopipe) gemm_split_launch_t<256, 128, 4, 2, PL, true, FMT>(sa, groups, st);
-    else gemm_split_launch_t<256, 128, 4, 2, PL, true, FMT, 1, true>(sa, groups, st);
+    else
+#endif
+    gemm_split_launch_t<256, 128, 4, 2, PL, true, FMT, 1, true>(sa, groups, st);
   }
   // (16 waves of 32 x 64 or 64 x 32 on this tile, without the software pipeline, run the cfg3 step within noise of this
   // one: at one block per CU the extra waves meet at the same barriers)
@@ -802,11 +807,16 @@ inline int gemm_split_launch(const SplitGemmArgs& sa, int groups, hipStream_t st
   // single LDS buffer, EIGHT waves of 64 x 32 (102 VGPRs): two blocks = 4 waves per SIMD.  With four waves of 64 x 64
   // (212 VGPRs, 2 waves per SIMD) 25472x768x256 took 76.4 us (now 73.2), 291208x256x128 206 us (now 192)
   else if (!strcmp(tile, "128x128s")) {
-    static const bool w4 = getenv("LINETR_TILE128S_4WAVE") != nullptr;   // tuning aid: the four-wave layout
+#ifdef LINETR_EXPERIMENTS
+    static const bool w4 = LT_XENV("LINETR_TILE128S_4WAVE") != nullptr;   // tuning aid: the four-wave layout
     if (w4) gemm_split_launch_t<128, 128, 2, 2, PL, false, FMT>(sa, groups, st);
-    else gemm_split_launch_t<128, 128, 2, 4, PL, false, FMT>(sa, groups, st);
+    else
+#endif
+    gemm_split_launch_t<128, 128, 2, 4, PL, false, FMT>(sa, groups, st);
   }
+#ifdef LINETR_EXPERIMENTS
   else if (PL == 2 && !strcmp(tile, "256x256") && g.N % 256 == 0) gemm_split_launch_t<256, 256, 4, 2, 2, true, FMT>(sa, groups, st);
+#endif
   // 64x64: three tiles of register prefetch = 156 VGPRs = THREE blocks per CU (53 KB of LDS each); with four it was 172
   // VGPRs = two blocks: 9584 x 256 x {256, 512, 1024} 20.9 / 33.2 / 58.8 us -> 18.6 / 29.8 / 52.8 us
   else if (!strcmp(tile, "64x64")) gemm_split_launch_t<64, 64, 2, 2, PL, true, FMT, 3>(sa, groups, st);

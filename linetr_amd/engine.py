@@ -63,7 +63,8 @@ class TokenBatch:
 class Engine:
     """One native model instance on one GPU."""
 
-    def __init__(self, state_dict, device="cuda:0", **model_cfg):
+    def __init__(self, state_dict, device="cuda:0", lib_path=None, **model_cfg):
+        """lib_path: another build of the library (nat.EXPERIMENTS_LIB_PATH for tools / experiment tests)."""
         cfg = {**DEFAULT_MODEL, **model_cfg}
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -71,7 +72,7 @@ class Engine:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.cfg = cfg
-        L = nat.lib()
+        L = nat.lib(lib_path)
         mc = nat.ModelConfig()
         mc.d_model, mc.n_heads, mc.d_inner = cfg["descriptor_dim"], cfg["n_heads"], cfg["d_inner"]
         mc.n_sig_layers, mc.n_desc_layers = cfg["n_sig_layers"], cfg["n_line_descriptive_layers"]

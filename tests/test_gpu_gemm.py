@@ -140,28 +140,3 @@ def test_gemm_small_m_kernel(eng, mode, tol, M, N, K, act):
     x = A.double() @ W.double().t() + b.double()
     x = [x, torch.relu(x), torch.nn.functional.gelu(x), (2 - 2 * x).clamp(min=0)][act] + R.double()
     assert ((Y.double() - x).abs().max() / x.abs().max()).item() < tol
-
-
-@pytest.mark.parametrize("M,N,K,act", [(25472, 512, 512, 1), (25472, 768, 256, 0), (9584, 512, 512, 2), (25473, 512, 256, 0),
-                                       (16500, 256, 1024, 0)])
-def test_gemm_stream_k_tail(eng, M, N, K, act, monkeypatch):
-    """(stream-K is opt-in, LINETR_STREAMK=1: measured slower than the plain launch as built, see lt_gemm_split.h.)
-    Shapes whose last round of 128x256 tiles would leave part of the chip idle: the tail tiles are shared by one block
-    per CU in (tile, K-tile) runs, partial accumulator tiles travel through the workspace (lt_gemm_split.h).  Against
-    float64 with every epilogue piece, a ragged last row tile, and twice in a row: the partition and the summation order
-    are fixed, so the result is bit-reproducible."""
-    g = torch.Generator(device="cuda").manual_seed(M + N + K)
-    A = torch.randn(M, K, device="cuda", generator=g)
-    W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
-    b = torch.randn(N, device="cuda", generator=g)
-    R = torch.randn(M, N, device="cuda", generator=g)
-    monkeypatch.setenv("LINETR_STREAMK", "1")
-    Y1 = eng.debug_gemm(A, W, b, R, act).clone()
-    Y2 = eng.debug_gemm(A, W, b, R, act)
-    monkeypatch.delenv("LINETR_STREAMK")
-    Y0 = eng.debug_gemm(A, W, b, R, act)                 # the plain launch: same products, different summation tree
-    assert torch.equal(Y1, Y2)
-    assert (Y1 - Y0).abs().max().item() < 1e-4 * max(1.0, Y0.abs().max().item())
-    x = A.double() @ W.double().t() + b.double()
-    x = [x, torch.relu(x), torch.nn.functional.gelu(x)][act] + R.double()
-    assert ((Y1.double() - x).abs().max() / x.abs().max()).item() < 2e-6

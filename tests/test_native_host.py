@@ -18,10 +18,22 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 def test_library_exports_every_declared_symbol():
     L = nat.lib()
     hdr = open(os.path.join(ROOT, "include", "linetr_hip.h")).read()
-    declared = set(re.findall(r"\b(linetr_[a-z_]+)\s*\(", hdr))
+    # the section behind LINETR_EXPERIMENTS is declared for (and exported by) the experiments build only
+    exp = re.search(r"#ifdef LINETR_EXPERIMENTS(.*?)#endif\s*/\* LINETR_EXPERIMENTS \*/", hdr, re.S)
+    assert exp, "experiments section of the header not found"
+    product_hdr = hdr.replace(exp.group(0), "")
+    declared = set(re.findall(r"\b(linetr_[a-z_]+)\s*\(", product_hdr))
     assert declared == set(nat.EXPORTS), declared ^ set(nat.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
+    declared_x = set(re.findall(r"\b(linetr_[a-z_]+)\s*\(", exp.group(1)))
+    assert declared_x == set(nat.EXPERIMENT_EXPORTS), declared_x ^ set(nat.EXPERIMENT_EXPORTS)
+    for name in declared_x:
+        assert not hasattr(L, name), f"{name} must not be in the product library"
+    if os.path.exists(nat.EXPERIMENTS_LIB_PATH):
+        LX = nat.lib(nat.EXPERIMENTS_LIB_PATH)
+        for name in declared | declared_x:
+            assert hasattr(LX, name), name
     assert L.linetr_abi_version() == 2
     assert C.sizeof(nat.LineRec) == 80
 

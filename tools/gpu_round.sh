@@ -13,7 +13,7 @@ if has bench; then
   timeout 600 python bench.py --steps 20 --warmup 5 > ${O}_bench.json 2> ${O}_bench.log; echo "bench rc=$?"; cut -c1-900 ${O}_bench.json
 fi
 if has shapes; then   # per-GEMM-shape HIP-event profile of the cfg3 step
-  LINETR_PROFILE_SHAPES=1 timeout 300 python bench.py --steps 10 --no-cpu-baseline --no-alt-precisions --no-sub-workloads > ${O}_bench_shapes.json 2> ${O}_bench_shapes.log
+  LINETR_LIB=$PWD/linetr_amd/csrc/liblinetr_hip_experiments.so LINETR_PROFILE_SHAPES=1 timeout 300 python bench.py --steps 10 --no-cpu-baseline --no-alt-precisions --no-sub-workloads > ${O}_bench_shapes.json 2> ${O}_bench_shapes.log
   python - ${O}_bench_shapes.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
@@ -67,8 +67,8 @@ if has prof; then     # rocprofv3 kernel stats, one run per workload
     rm -rf gpurun_out/prof_${tag}_$wl
   done
 fi
-if has pmc; then
-  bash tools/pmc_kernels.sh $tag
+if has pmc; then      # counters per workload: bench.py only attaches counters taken on the same workload
+  for wl in cfg3 cfg2 cfg5; do bash tools/pmc_kernels.sh $tag $wl; done
 fi
 if has cfg4; then
   timeout 600 python bench.py --workload cfg4 --steps 3 --warmup 1 --settle-s 1 > ${O}_cfg4.json 2> ${O}_cfg4.log; echo "cfg4 rc=$?"; cut -c1-1200 ${O}_cfg4.json

@@ -1,11 +1,12 @@
 #!/bin/bash
 # MFMA-busy / issue-stall / LDS counters of every kernel of one bench step (rocprofv3 --pmc, counters only, own pass),
-# plus the HBM traffic passes.  Writes gpurun_out/<tag>_gemm_pmc.json and gpurun_out/<tag>_pmc_traffic.json.
-#   usage (on the GPU box, via gpurun): bash tools/pmc_kernels.sh r02 [extra bench.py flags]
-tag=${1:-rXX}; shift
+# plus the HBM traffic passes.  Writes gpurun_out/<tag>_<workload>_gemm_pmc.json and gpurun_out/<tag>_<workload>_pmc_traffic.json
+# (the names bench.py looks up for the roofline's `traffic` / `mfma_busy`: counters of the SAME workload and binary only).
+#   usage (on the GPU box, via gpurun): bash tools/pmc_kernels.sh r03 cfg3 [extra bench.py flags]
+tag=${1:-rXX}; wl=${2:-cfg3}; shift; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-BENCH="python bench.py --steps 2 --warmup 1 --settle-s 0 --no-cpu-baseline --no-alt-precisions --no-sub-workloads $*"
+BENCH="python bench.py --workload $wl --steps 2 --warmup 1 --settle-s 0 --no-cpu-baseline --no-alt-precisions --no-sub-workloads $*"
 pass() {  # name counters...
   name=$1; shift
   timeout 600 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$name -o p -- $BENCH > gpurun_out/pmc_$name.log 2>&1
@@ -14,9 +15,9 @@ pass sq SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_
 pass sq2 SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE
 pass FETCH_SIZE FETCH_SIZE
 pass WRITE_SIZE WRITE_SIZE
-python - "$tag" <<'PY'
+python - "$tag" "$wl" <<'PY'
 import collections, csv, glob, json, sys
-tag = sys.argv[1]
+tag, wl = sys.argv[1], sys.argv[2]
 def load(name):
     f = glob.glob(f"gpurun_out/pmc_{name}/*counter_collection.csv")
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -25,7 +26,8 @@ def load(name):
     for r in csv.DictReader(open(f[0])):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
-out = {"note": "averages per launch over one rocprofv3 --pmc pass of `bench.py --steps 2` (cfg3).  mfma_busy = "
+out = {"workload": wl,
+       "note": "averages per launch over one rocprofv3 --pmc pass of `bench.py --workload " + wl + " --steps 2`.  mfma_busy = "
                "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8): SQ_VALU_MFMA_BUSY_CYCLES is summed over all "
                "SIMDs (= 32 cycles x the number of 32x32x16 MFMAs, checked against the GEMM's 6*2MNK flops) and "
                "GRBM_GUI_ACTIVE over the 8 XCDs (GRBM_GUI_ACTIVE / 8 / kernel duration = 2.2 GHz).  SQ_WAVE_CYCLES and the "
@@ -46,14 +48,14 @@ for k, rec in out["kernels"].items():
                 rec[c + "_frac_of_wave_cycles"] = round(rec[c] / rec["SQ_WAVE_CYCLES"], 4)
     if rec.get("SQ_LDS_IDX_ACTIVE"):
         rec["lds_bank_conflict_frac"] = round(rec.get("SQ_LDS_BANK_CONFLICT", 0.0) / rec["SQ_LDS_IDX_ACTIVE"], 4)
-json.dump(out, open(f"gpurun_out/{tag}_gemm_pmc.json", "w"), indent=1)
+json.dump(out, open(f"gpurun_out/{tag}_{wl}_gemm_pmc.json", "w"), indent=1)
 tr = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, cs in load(c).items():
         if c in cs:
             tr[k][c + "_KiB_avg"] = sum(cs[c]) / len(cs[c])
             tr[k]["launches"] = len(cs[c])
-json.dump(tr, open(f"gpurun_out/{tag}_pmc_traffic.json", "w"), indent=1)
+json.dump(tr, open(f"gpurun_out/{tag}_{wl}_pmc_traffic.json", "w"), indent=1)
 top = sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0) * kv[1].get("launches", 0))[:8]
 for k, v in top:
     print(k[:60], {a: v[a] for a in ("launches", "mfma_busy", "SQ_WAIT_INST_ANY_frac_of_wave_cycles", "SQ_WAIT_ANY_frac_of_wave_cycles", "lds_bank_conflict_frac") if a in v})
