@@ -104,6 +104,13 @@ __device__ __forceinline__ void halves_of(float x, float& lo, float& hi) {
   lo = __builtin_bit_cast(float, a);
   hi = __builtin_bit_cast(float, b);
 }
+// a's upper half <-> b's lower half (raw v_permlane32_swap on two different registers)
+__device__ __forceinline__ void halves_swap(float& a, float& b) {
+  unsigned x = __builtin_bit_cast(unsigned, a), y = __builtin_bit_cast(unsigned, b);
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  a = __builtin_bit_cast(float, x);
+  b = __builtin_bit_cast(float, y);
+}
 __device__ __forceinline__ float xor32_max(float x) { float a, b; halves_of(x, a, b); return fmaxf(a, b); }
 __device__ __forceinline__ float xor32_sum(float x) { float a, b; halves_of(x, a, b); return a + b; }
 

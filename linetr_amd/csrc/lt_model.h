@@ -764,12 +764,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && LT_ATTN_OCC2) ? 4 : 1) void si
   __shared__ __attribute__((aligned(16))) unsigned char Vs[ATT_KT * ATS_RV];
   const int img = blockIdx.x, head = blockIdx.y;
   const int n0 = cu_sub[img], Ni = cu_sub[img + 1] - n0;
-  const int q0 = blockIdx.z * (NW * 32);
+  // the image's queries are dealt out EVENLY over the gridDim.z blocks of its (image, head), in whole waves: 599 queries on
+  // three 256-query blocks are 7 + 7 + 5 busy waves instead of 8 + 8 + 3 (every block stages all K / V tiles either way)
+  const int per = ((Ni + (int)gridDim.z - 1) / (int)gridDim.z + 31) / 32 * 32;     // <= NW * 32
+  const int q0 = blockIdx.z * per;
   if (q0 >= Ni) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h2 = lane >> 5, lq = lane & 31;
   const int q = q0 + wave * 32 + lq;
-  const bool wave_active = q0 + wave * 32 < Ni;  // wave-uniform
+  const bool wave_active = wave * 32 < per && q0 + wave * 32 < Ni;  // wave-uniform
   const float* base = qkv + (int64_t)n0 * 768;
 
   bf16x8 qf[4][3];
@@ -925,14 +928,31 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && LT_ATTN_OCC2) ? 4 : 1) void si
       }
     }
   }
-  if (wave_active && q < Ni) {
+  if (wave_active) {
+    // O^T: a lane owns ONE query and 4-runs of d (d = 8 (r >> 2) + 4 h2 + (r & 3)).  One v_permlane32_swap per register
+    // pair hands each half-wave the other half's 4-run, so a lane ends up with 8 consecutive d and stores them as two
+    // dwordx4 (r02 stored 32 single dwords per lane: 32 rows x 4 B per instruction, a store-issue-bound tail).
     const float inv = 1.f / l;
-    float* op = out + (int64_t)(n0 + q) * D + head * DH;
+    float* op = out + (int64_t)(n0 + (q < Ni ? q : Ni - 1)) * D + head * DH + 8 * h2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int d = (r & 3) + 8 * (r >> 2) + 4 * h2;
-      op[d] = o0[r] * inv;
-      op[d + 32] = o1[r] * inv;
+    for (int dt = 0; dt < 2; ++dt) {
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = (dt == 0 ? o0[r] : o1[r]) * inv;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {        // (v[c], v[4 + c]) and (v[8 + c], v[12 + c]): upper half of the first <-> lower half of the second
+        float a0 = v[c], b0 = v[4 + c], a1 = v[8 + c], b1 = v[12 + c];
+        halves_swap(a0, b0);
+        halves_swap(a1, b1);
+        v[c] = a0; v[4 + c] = b0; v[8 + c] = a1; v[12 + c] = b1;
+      }
+      if (q < Ni) {
+        // after the swaps v[0..7] = d 32 dt + 8 h2 .. + 8 and v[8..15] = d 32 dt + 16 + 8 h2 .. + 8
+        *reinterpret_cast<f32x4*>(op + dt * 32) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(op + dt * 32 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<f32x4*>(op + dt * 32 + 16) = f32x4{v[8], v[9], v[10], v[11]};
+        *reinterpret_cast<f32x4*>(op + dt * 32 + 20) = f32x4{v[12], v[13], v[14], v[15]};
+      }
     }
   }
 }
