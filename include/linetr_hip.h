@@ -301,6 +301,15 @@ int linetr_debug_gemm_st(LinetrHandle* h, const void* d_A1, int32_t K1, const vo
                          int32_t act, void* stream);
 #endif  /* LINETR_EXPERIMENTS */
 
+/* ---- multi-GPU: the descriptor all-gather as a C entry point --------------------------------------
+ * ONE all-gather of the ranks' packed slabs (header | sub-line -> key-line map | line_desc rows; layout in
+ * linetr_amd/parallel.py, which the Python surface uses through torch.distributed) over an RCCL communicator the CALLER
+ * owns: d_out [world][slab_bytes] receives every rank's d_slab.  `nccl_comm` is an ncclComm_t.  The library does not link
+ * against RCCL: ncclAllGather is resolved at the first call from the RCCL already loaded in the process (PyTorch's or
+ * /opt/rocm's librccl.so); LINETR_E_HIP if none is loaded.  No reference counterpart (BASELINE.json cfg4); asynchronous
+ * on `stream`.  linetr_match_gathered then matches straight out of d_out. */
+int linetr_allgather_desc(void* nccl_comm, const void* d_slab, void* d_out, int64_t slab_bytes, void* stream);
+
 /* ---- instrumentation ------------------------------------------------------------------------ */
 
 /* Per-kernel-class HIP-event timing.  linetr_set_profiling(h,1) clears the accumulators and makes

@@ -103,6 +103,7 @@ def lib(path=None):
         L.linetr_debug_to_st.argtypes = [vp, vp, i32, i32, i32, vp, vp]
         L.linetr_debug_from_st.argtypes = [vp, vp, i32, i32, vp, i32, vp]
         L.linetr_debug_gemm_st.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.linetr_allgather_desc.argtypes = [vp, vp, vp, i64, vp]
     L.linetr_set_profiling.argtypes = [vp, i32]
     L.linetr_get_profile.argtypes = [vp, C.POINTER(ProfileEntry), i32, C.POINTER(i32)]
     if L.linetr_abi_version() != 2:
@@ -114,7 +115,7 @@ def lib(path=None):
 EXPORTS = ["linetr_abi_version", "linetr_last_error", "linetr_create", "linetr_destroy", "linetr_prefilter",
            "linetr_prefilter_batch", "linetr_pack_lines", "linetr_tokenize_workspace_bytes", "linetr_tokenize", "linetr_forward_workspace_bytes",
            "linetr_forward", "linetr_describe_workspace_bytes", "linetr_describe", "linetr_match_workspace_bytes", "linetr_match", "linetr_match_gathered", "linetr_match_points",
-           "linetr_match_distmat", "linetr_match_distmat_workspace_bytes", "linetr_superpoint_heads", "linetr_set_precision", "linetr_get_precision", "linetr_debug_posenc", "linetr_debug_gemm", "linetr_set_profiling", "linetr_get_profile"]
+           "linetr_match_distmat", "linetr_match_distmat_workspace_bytes", "linetr_superpoint_heads", "linetr_set_precision", "linetr_get_precision", "linetr_debug_posenc", "linetr_debug_gemm", "linetr_allgather_desc", "linetr_set_profiling", "linetr_get_profile"]
 
 
 EXPERIMENT_EXPORTS = ["linetr_st_bytes", "linetr_debug_to_st", "linetr_debug_from_st", "linetr_debug_gemm_st"]

@@ -1,5 +1,7 @@
 // liblinetr_hip.so -- host side of the C ABI declared in include/linetr_hip.h.
 // Weight preparation (float64 on the host), host pre-filter, launch sequencing, profiling.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <condition_variable>
 #include <functional>
@@ -1844,6 +1846,33 @@ extern "C" int linetr_debug_mlp_stamps(unsigned long long* out) {   // debug bui
   return LINETR_OK;
 }
 #endif
+
+// =============================================================================================
+// multi-GPU collective (C-ABI form of parallel.allgather_descriptors)
+// =============================================================================================
+
+extern "C" int linetr_allgather_desc(void* nccl_comm, const void* d_slab, void* d_out, int64_t slab_bytes, void* stream) {
+  if (!nccl_comm || !d_slab || !d_out || slab_bytes <= 0) return fail(LINETR_E_ARG, "allgather_desc: bad argument");
+  // ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t, ncclComm_t, hipStream_t)
+  typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+  static allgather_fn fn = nullptr;
+  static std::mutex mu;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!fn) {
+      void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+      for (const char* name : {"librccl.so", "librccl.so.1"}) {
+        if (sym) break;
+        if (void* lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD)) sym = dlsym(lib, "ncclAllGather");   // only an ALREADY loaded RCCL
+      }
+      fn = reinterpret_cast<allgather_fn>(sym);
+    }
+  }
+  if (!fn) return fail(LINETR_E_HIP, "allgather_desc: no RCCL (ncclAllGather) is loaded in this process");
+  const int rc = fn(d_slab, d_out, (size_t)slab_bytes, /*ncclChar*/ 0, nccl_comm, (hipStream_t)stream);
+  if (rc != 0) return fail(LINETR_E_HIP, "allgather_desc: ncclAllGather failed with ncclResult_t %d", rc);
+  return LINETR_OK;
+}
 
 // =============================================================================================
 // profiling

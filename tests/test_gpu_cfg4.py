@@ -176,3 +176,34 @@ def test_rccl_single_rank_allgather_and_global_match(eng):
         assert torch.equal(m01, ref[2]) and torch.equal(dk, ref[0])
     finally:
         dist.destroy_process_group()
+
+
+def test_native_allgather_entry_point_single_rank():
+    """linetr_allgather_desc (the C-ABI form of the descriptor all-gather) over a one-rank RCCL communicator created directly
+    on the RCCL PyTorch has loaded: the gathered buffer must equal the slab.  (More than one rank needs more than one GPU;
+    the multi-rank layout is covered by the gloo tests and by linetr_match_gathered on a four-rank layout above.)"""
+    import ctypes as C
+    import os
+
+    from linetr_amd import _native as nat
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    torch.cuda.set_device(0)
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        slab = torch.randn(1000, 256, device="cuda")
+        out = torch.zeros_like(slab)
+        st = torch.cuda.current_stream().cuda_stream
+        nat.check(nat.lib().linetr_allgather_desc(comm, slab.data_ptr(), out.data_ptr(), slab.numel() * 4, st))
+        torch.cuda.synchronize()
+        assert torch.equal(out, slab)
+    finally:
+        rccl.ncclCommDestroy(comm)
