@@ -317,9 +317,9 @@ class Engine:
 
         With n_streams > 1 the images are cut into contiguous groups that run as independent sub-batches on
         separate HIP streams (forked from / joined back into the current stream).  The descriptor network of one
-        image never looks at another image, so this is exact.  Measured on MI355X (cfg3) it does NOT pay: 1 stream
-        4.44 ms/step, 2 streams 4.71, 4 streams 6.78 -- the half-size GEMMs drop to smaller, less efficient tiles
-        and concurrent kernels contend for the same per-CU fetch path -- so the default is one stream.
+        image never looks at another image, so this is exact.  Measured on MI355X (cfg3) it does NOT pay: in r01 one stream
+        took 4.44 ms/step, two 4.71, four 6.78; in r02 two sub-batches ran a 2.71 ms median step against 2.75 but stalled
+        ~1 ms on every fourth step (two hardware queues), 8.7 vs 9.2 M descriptors/s -- so the default is one stream.
         Returns (TokenBatch, line_desc [N,256]) for the whole batch."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int32)
         B = len(offsets) - 1
