@@ -15,8 +15,8 @@
 #include "lt_gemm.h"
 #include "lt_gemm_split.h"
 #include "lt_gemm_split16.h"
-#ifdef LINETR_EXPERIMENTS
 #include "lt_gemm_st.h"
+#ifdef LINETR_EXPERIMENTS
 #include "lt_gemm_chain.h"
 #endif
 #include "lt_gemm_small.h"
@@ -25,6 +25,7 @@
 #endif
 #include "lt_match.h"
 #include "lt_model.h"
+#include "lt_attn_fused.h"
 #ifdef LINETR_EXPERIMENTS
 #include "lt_attn_st.h"
 #endif
@@ -486,11 +487,13 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
   struct Fix { const float** dst; size_t off; };
   std::vector<Fix> fix;
   auto place = [&](const float** dst, const std::vector<double>& v) { fix.push_back({dst, ar.put(v)}); };
-  struct GemmW { const float** dst; int64_t rows; int K; };
+  struct GemmW { const float** dst; int64_t rows; int K; bool st; };
   std::vector<GemmW> gemm_w;
-  auto place_w = [&](const float** dst, const std::vector<double>& v, int64_t rows, int K) {
+  // st: the weight also gets a split-tile image (lt_gemm_st.h) -- the q/k/v projections, which the fused projection +
+  // attention kernel streams by LDS-DMA (lt_attn_fused.h); in the experiments build every eligible weight gets one
+  auto place_w = [&](const float** dst, const std::vector<double>& v, int64_t rows, int K, bool st = false) {
     place(dst, v);
-    gemm_w.push_back({dst, rows, K});
+    gemm_w.push_back({dst, rows, K, st});
   };
 
   // ---- positional encoders: 4 x (conv + BN + ReLU) + linear ------------------------------------
@@ -659,7 +662,7 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
       b1f[o] = bacc;
     }
     SigLayer& S = H->sig[l];
-    place_w(&S.Wqkv, Wqkv, 3 * D, D); place(&S.bqkv, bqkv);
+    place_w(&S.Wqkv, Wqkv, 3 * D, D, true); place(&S.bqkv, bqkv);
     place_w(&S.W1, W1m, 2 * D, 2 * D); place(&S.b1, b1f);
     place_w(&S.W2, to_d(W2, (size_t)2 * D * D), D, 2 * D); place(&S.b2, to_d(b2, D));
 #ifdef LINETR_EXPERIMENTS
@@ -714,8 +717,11 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
       sw.off3 = total; total += align_up(w.rows * w.K * 6, 256);
       sw.offh = total; total += align_up(w.rows * w.K * 4, 256);
 #ifdef LINETR_EXPERIMENTS
-      if (w.rows % 16 == 0 && w.K % 32 == 0) { total = align_up(total, 1024); sw.offst = total; total += st_bytes(w.rows, w.K); }   // ST image (rows padded to 128)
+      const bool want_st = true;
+#else
+      const bool want_st = w.st;
 #endif
+      if (want_st && w.rows % 16 == 0 && w.K % 32 == 0) { total = align_up(total, 1024); sw.offst = total; total += st_bytes(w.rows, w.K); }   // ST image (rows padded to 128)
       H->split[*w.dst] = sw;
     }
     LT_HIP(hipMalloc((void**)&H->split_arena, total));
@@ -729,13 +735,11 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
                          H->split_arena + kv.second.off3, kv.second.rows, kv.second.K);
       hipLaunchKernelGGL((split_rows_kernel<2, 1>), dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, 0, kv.first,
                          H->split_arena + kv.second.offh, kv.second.rows, kv.second.K);
-#ifdef LINETR_EXPERIMENTS
       if (kv.second.offst) {
         const int64_t thr = st_row_blocks(kv.second.rows) * (kv.second.K / 16) * 32;
         hipLaunchKernelGGL(to_st_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, 0, kv.first, kv.second.K,
                            (int)kv.second.rows, kv.second.K / 16, H->split_arena + kv.second.offst);
       }
-#endif
     }
     LT_LAUNCH_CHECK();
     LT_HIP(hipDeviceSynchronize());
@@ -1248,6 +1252,25 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
 #endif
   for (size_t l = 0; l < h->sig.size(); ++l) {
     const SigLayer& S = h->sig[l];
+    // q/k/v projection + attention of an (image, head) in one launch (lt_attn_fused.h): images of up to 256 sub-lines, and
+    // enough (image, head) blocks to fill the chip; q, k, v never reach HBM
+    const bool no_fqa = LT_XENV("LINETR_NO_FUSED_QKV_ATTN") != nullptr;     // A/B switch (experiments build; read per call)
+    if (!chain && !no_fqa && h->precision == LINETR_PREC_BF16X6 && max_n <= 256 && (int64_t)n_images * HEADS >= 128) {
+      auto it = h->split.find(S.Wqkv);
+      if (it == h->split.end() || !it->second.offst) return fail(LINETR_E_ARG, "signature layer: q/k/v weight has no split-tile image");
+      double fl = 2.0 * N * 3.0 * D * D;
+      for (int i = 0; i < n_images; ++i) { double n = h_cu[i + 1] - h_cu[i]; fl += 2.0 * 2.0 * n * n * D; }
+      static unsigned long long attr_done = 0;
+      const unsigned long long dev_bit = current_device_bit();
+      if (!(attr_done & dev_bit)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sig_qkv_attn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, FQA_LDS);
+        attr_done |= dev_bit;
+      }
+      ProfScope ps(h, st, "sig_qkv_attn_bf16x6", fl, (double)N * D * 8);
+      hipLaunchKernelGGL(sig_qkv_attn_kernel<0>, dim3(n_images, HEADS), dim3(512), FQA_LDS, st, z, h->split_arena + it->second.offst,
+                         S.bqkv, cu_dev, w.msgp);
+      LT_LAUNCH_CHECK();
+    } else {
     if (!chain)
       if ((e = run_gemm(h, st, z, D, nullptr, 0, 0, S.Wqkv, S.bqkv, nullptr, 0, w.qkv, 3 * D, N, 3 * D, D, ACT_NONE))) return e;
     {
@@ -1274,6 +1297,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
                              w.msgp);
       }
       LT_LAUNCH_CHECK();
+    }
     }
 #ifdef LINETR_EXPERIMENTS
     if (chain) {

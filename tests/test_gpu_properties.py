@@ -54,6 +54,26 @@ def test_cfg3_batch_invariance_and_norms(eng):
         assert (ld1 - ld[n0:n1]).abs().max().item() < 2e-6
 
 
+def test_ragged_batch_through_the_fused_projection_attention_kernel(eng):
+    """48 images with 3 .. 257 detected lines each (2 .. 256 sub-lines: one to eight 32-row wave tiles, partly filled last
+    tiles, image boundaries that are not multiples of anything) described as ONE batch -- the batch runs the fused q/k/v
+    projection + attention kernel (lt_attn_fused.h: >= 128 (image, head) blocks, <= 256 sub-lines per image) -- against
+    every image described alone, which runs the separate projection GEMM and the small attention kernel."""
+    counts = [3, 4, 33, 34, 65, 97, 128, 129, 160, 161, 193, 200, 224, 225, 256, 257] * 3
+    lines = [synth.synth_lines(7700 + i, n, *HW) for i, n in enumerate(counts)]
+    maps = [synth.synth_dense_maps(7700 + i, *HW) for i in range(len(counts))]
+    dd = torch.cat([m[0] for m in maps]).cuda()
+    ds = torch.cat([m[1] for m in maps]).cuda()
+    off = np.concatenate([[0], np.cumsum([len(l) for l in lines])]).astype(np.int32)
+    tb, ld = describe(eng, np.concatenate(lines), off, dd, ds)
+    assert int(np.diff(tb.cu_n).max()) == 256 and int(np.diff(tb.cu_n).min()) == 2
+    assert torch.isfinite(ld).all() and (ld.norm(dim=1) - 1).abs().max().item() < 1e-5
+    for i in range(len(counts)):
+        tb1, ld1 = describe(eng, lines[i], np.array([0, len(lines[i])], np.int32), dd[i:i + 1], ds[i:i + 1])
+        n0, n1 = tb.cu_n[i], tb.cu_n[i + 1]
+        assert (ld1 - ld[n0:n1]).abs().max().item() < 2e-6, (i, counts[i])
+
+
 def test_permutation_equivariance(eng):
     lines, cat, off, dd, ds = batch_inputs(4, seed0=7100)
     tb, ld = describe(eng, cat, off, dd, ds)
@@ -125,8 +145,9 @@ def test_precision_modes_agree(eng):
 
 def test_cfg3_step_runs_on_the_intended_kernels(eng):
     """Dispatcher guard (HIP-event profile classes of one cfg3 forward): the 18 K >= 512 / N = 256 GEMMs on the pipelined
-    128x256 tile with the three row normalisations fused into their epilogues, the nine short-K / wide-N GEMMs on the
-    eight-wave 128x128 tile, attention and pooling on their split-bf16 / one-pass kernels, nothing on a fallback tile.  (A
+    128x256 tile with the three row normalisations fused into their epilogues, the two remaining short-K / wide-N GEMMs on the
+    eight-wave 128x128 tile, the seven q/k/v projections inside the fused projection + attention kernel, pooling on its
+    one-pass kernel, nothing on a fallback tile.  (A
     dispatcher rule lost in an edit once moved the 18 launches to the 64x256 tile: correct results, 12 % slower step.)"""
     _, cat, off, dd, ds = batch_inputs(128)
     describe(eng, cat, off, dd, ds)
@@ -139,8 +160,8 @@ def test_cfg3_step_runs_on_the_intended_kernels(eng):
     finally:
         eng.set_profiling(False)
     assert prof.get("gemm_bf16x6_128x256") == 18, prof
-    assert prof.get("gemm_bf16x6_128x128s") == 9, prof
-    assert prof.get("sig_attn_bf16x6") == 7 and prof.get("cls_pool_online") == 1, prof
+    assert prof.get("gemm_bf16x6_128x128s") == 2, prof             # FFN w_1 and the word-MLP's K = 128 layer
+    assert prof.get("sig_qkv_attn_bf16x6") == 7 and "sig_attn_bf16x6" not in prof and prof.get("cls_pool_online") == 1, prof
     assert "row_norm" not in prof, prof
     assert not [k for k in prof if k.startswith("gemm_") and k not in ("gemm_bf16x6_128x256", "gemm_bf16x6_128x128s", "gemm_bf16x6_128x64")], prof
 
