@@ -17,6 +17,7 @@
 #include "lt_gemm_split16.h"
 #include "lt_gemm_st.h"
 #ifdef LINETR_EXPERIMENTS
+#include "lt_gemm_ro.h"
 #include "lt_gemm_chain.h"
 #endif
 #include "lt_gemm_small.h"
@@ -304,6 +305,20 @@ int run_gemm(LinetrHandle* h, hipStream_t st, const float* A, int lda, const flo
     ProfScope ps(h, st, gemm_class_name(g, groups, "gemm_f16x3"), fl, by);
     return gemm_split_launch<2, 1>(sa, groups, st);
   }
+#ifdef LINETR_EXPERIMENTS
+  // row-owner kernel (lt_gemm_ro.h): 4-wave blocks, two per CU, operands by LDS-DMA.  Measured at cfg3: 117 TF-eq against 137 for
+  // the register-staged tiles (a two-slot ring leaves a DMA one K step to land, and the barrier comes every 48 MFMAs), so opt-in.
+  if (LT_XENV("LINETR_GEMM_RO") != nullptr && groups == 1 && N % 256 == 0 && K % 32 == 0 && it->second.offst && lda % 4 == 0 && ldy % 4 == 0 &&
+      (!A2 || (lda2 % 4 == 0 && K1 % 16 == 0)) && (!R || ldr % 4 == 0) && act != ACT_DIST && cdiv(M, 128) * (N / 256) >= 140) {
+    RoGemmArgs a;
+    a.A1 = A; a.lda1 = lda; a.nk1 = (A2 ? K1 : K) / 16; a.A2 = A2; a.lda2 = lda2; a.nk2 = A2 ? (K - K1) / 16 : 0;
+    a.Wst = h->split_arena + it->second.offst; a.bias = bias ? bias : h->zeros; a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
+    a.M = M; a.N = N; a.act = act;
+    if (fused_norm) { a.norm = fused_norm->mode; a.gamma = fused_norm->gamma; a.beta = fused_norm->beta; a.add2 = fused_norm->add2; a.ldadd2 = D; a.eps = fused_norm->eps; }
+    ProfScope ps(h, st, "gemm_bf16x6_ro128x256", fl, by);
+    return gemm_ro_launch(a, st);
+  }
+#endif
   sa.Wsp = h->split_arena + it->second.off3;
   sa.gWsp = gW * 6;
   ProfScope ps(h, st, gemm_class_name(g, groups, "gemm_bf16x6"), fl, by);
@@ -719,7 +734,7 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
 #ifdef LINETR_EXPERIMENTS
       const bool want_st = true;
 #else
-      const bool want_st = w.st;
+      const bool want_st = w.st;                          // the fused projection + attention kernel's q/k/v weights
 #endif
       if (want_st && w.rows % 16 == 0 && w.K % 32 == 0) { total = align_up(total, 1024); sw.offst = total; total += st_bytes(w.rows, w.K); }   // ST image (rows padded to 128)
       H->split[*w.dst] = sw;
