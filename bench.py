@@ -315,6 +315,7 @@ PMC_KERNEL_NAMES = {   # profile class -> kernel symbol prefix in profiles/<tag>
     "gemm_bf16x6_32x32k4": "void lt::gemm_split_small_kernel<3, 0",
     "gemm_f32_128x128": "void lt::gemm_kernel<128, 128, 2, 2>",
     "sig_attn_bf16x6": "void lt::sig_attn_split_kernel<8>",
+    "sig_qkv_attn_bf16x6": "void lt::sig_qkv_attn_kernel<0>",
 }
 
 

@@ -49,14 +49,20 @@ __device__ __forceinline__ void fr_wait(u32x2 (&o)[3][2]) {
 }
 
 // DBG (tools/ubench/fqa_bench.hip only): 1 no projection MFMAs, 2 no attention phase, 4 projection without its barriers / DMA
-// waits (wrong data, timing only), 8 no K / V staging + conversion
+// waits (wrong data, timing only), 8 no K / V staging + conversion, 16 phase time stamps (wall_clock64, 100 MHz) of wave 0
+#ifdef LT_FQA_STAMPS
+__device__ unsigned long long fqa_stamps[512][8];
+#define FQA_STAMP(k) do { if ((DBG & 16) && tid == 0) fqa_stamps[(img * 4 + head) & 511][k] = wall_clock64(); } while (0)
+#else
+#define FQA_STAMP(k) do { } while (0)
+#endif
 template <int DBG = 0>
 __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restrict__ z /*[N][256]*/,
                                                            const unsigned char* __restrict__ Wst /*ST image of Wqkv [768][256]*/,
                                                            const float* __restrict__ bqkv /*[768]*/,
                                                            const int* __restrict__ cu_sub, float* __restrict__ out /*[N][256]*/) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char fq_smem[];
-  const int img = blockIdx.x, head = blockIdx.y;
+  const int img = blockIdx.x, head = blockIdx.y;     // (an XCD-grouped 1-D order -- the four heads of an image on one L2 -- measured level)
   const int n0 = cu_sub[img], Ni = cu_sub[img + 1] - n0;
   if (Ni <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -65,6 +71,7 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
   const int q = wave * 32 + lq;                          // row of the image this lane owns (query AND key)
   const bool wave_active = wave * 32 < Ni;               // wave-uniform
   constexpr int RBW = 3 * D / 16, NK = D / 16;           // 48 row blocks of the weight image, 16 K steps
+  FQA_STAMP(0);
 
   // ---- 1. projection --------------------------------------------------------------------------------------------
   // Ring slot of a K step (34 KiB): [weights: (q | k | v) x 4 row blocks x 3 planes x 512 B = 18 KiB][activations: 256 rows x 16
@@ -123,6 +130,7 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
   wait_dma(2);                                             // steps 0 and 1 landed
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  FQA_STAMP(1);
 
   const int lfrag = ((lane >> 4) & 1) * ST_RB + (lane >> 5) * 256 + (lane & 15) * 16;
   const int zoff = FQA_W_BYTES + (wave * 32 + lq) * 64 + h2 * 32;
@@ -187,6 +195,7 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
     step(s + 1, zfB, zfA);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  FQA_STAMP(2);
 
   // ---- 2. Q to B fragments (registers), K / V pieces (registers until their half is staged) ----------------------------
   // piece g of accumulator tile i = channels 32 (i & 1) + 16 g + 8 h2 .. + 8 of this lane's row, after the half-wave swap
@@ -234,6 +243,7 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
     }
   };
 
+  FQA_STAMP(3);
   // ---- 3. attention over two halves of 128 keys ----------------------------------------------------------------------
   f32x16 o0, o1;
 #pragma unroll
@@ -343,6 +353,7 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
     if (k0 + 32 < Ni) chunk(k0 + 32, std::integral_constant<int, 32>{});
     if (k0 + 64 < Ni) chunk(k0 + 64, std::integral_constant<int, 64>{});
     if (k0 + 96 < Ni) chunk(k0 + 96, std::integral_constant<int, 96>{});
+    FQA_STAMP(4 + half);
   }
 
   // ---- 4. epilogue: O^T / l -> 8 consecutive d per lane -> dwordx4 stores ------------------------------------------------
@@ -361,6 +372,7 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
       }
     }
   }
+  FQA_STAMP(6);
 }
 
 }  // namespace lt
