@@ -27,6 +27,7 @@
 #include "lt_match.h"
 #include "lt_model.h"
 #include "lt_attn_fused.h"
+#include "lt_gemm_ws.h"
 #ifdef LINETR_EXPERIMENTS
 #include "lt_attn_st.h"
 #endif
@@ -319,6 +320,13 @@ int run_gemm(LinetrHandle* h, hipStream_t st, const float* A, int lda, const flo
     return gemm_ro_launch(a, st);
   }
 #endif
+  // every token row of the batch through a K = 128 layer: weights stay in registers, rows stream (lt_gemm_ws.h)
+  if (groups == 1 && !A2 && !R && !fused_norm && it->second.offst && gemm_ws_fits(M, N, K, lda, ldy, act) && !LT_XENV("LINETR_NO_GEMM_WS")) {
+    WsGemmArgs a;
+    a.A = A; a.lda = lda; a.Wst = h->split_arena + it->second.offst; a.bias = bias ? bias : h->zeros; a.Y = Y; a.ldy = ldy; a.M = M; a.act = act;
+    ProfScope ps(h, st, "gemm_bf16x6_ws64x256", fl, by);
+    return gemm_ws_launch(a, st);
+  }
   sa.Wsp = h->split_arena + it->second.off3;
   sa.gWsp = gW * 6;
   ProfScope ps(h, st, gemm_class_name(g, groups, "gemm_bf16x6"), fl, by);
@@ -532,7 +540,8 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
       if (err) return err;
       std::vector<double> Wf, bf;
       fold_bn(W, b, g, be, mu, va, ch[i + 1], ch[i], Wf, bf);
-      if (i == 0) place(Wdst[i], Wf); else place_w(Wdst[i], Wf, ch[i + 1], ch[i]);
+      // layer 4 (128 -> 256) also gets a split-tile image: the weight-stationary kernel of lt_gemm_ws.h reads its planes from it
+      if (i == 0) place(Wdst[i], Wf); else place_w(Wdst[i], Wf, ch[i + 1], ch[i], ch[i + 1] == WS_N && ch[i] == WS_K);
       place(bdst[i], bf);
     }
     const float* W = tm.get(pre + "12.weight", (int64_t)D * e3, err);
@@ -1815,16 +1824,22 @@ extern "C" int linetr_debug_gemm(LinetrHandle* h, const float* A, int32_t lda, c
   auto it = h->debug_split.find(W);
   unsigned char* buf = it != h->debug_split.end() ? it->second : nullptr;
   const int64_t b2 = align_up((int64_t)N * K * 4, 256), b3 = align_up((int64_t)N * K * 6, 256);
+  const bool ws = N == WS_N && K == WS_K;             // the weight-stationary kernel's shape: it reads a split-tile image
+  const int64_t bst = ws ? align_up(st_bytes(N, K), 256) : 0, off_st = align_up(b2 + b3 + b2, 1024);
   if (!buf) {
-    LT_HIP(hipMalloc((void**)&buf, b2 + b3 + b2));
+    LT_HIP(hipMalloc((void**)&buf, off_st + bst));
     const int64_t n4 = (int64_t)N * K / 4;
     hipLaunchKernelGGL(split_rows_kernel<2>, dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, st, W, buf, (int64_t)N, K);
     hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, st, W, buf + b2, (int64_t)N, K);
     hipLaunchKernelGGL((split_rows_kernel<2, 1>), dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, st, W, buf + b2 + b3, (int64_t)N, K);
+    if (ws) {
+      const int64_t thr = st_row_blocks(N) * (K / 16) * 32;
+      hipLaunchKernelGGL(to_st_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, st, W, K, N, K / 16, buf + off_st);
+    }
     LT_LAUNCH_CHECK();
     if (cache_weights) h->debug_split[W] = buf;
   }
-  h->split[W] = {0, (size_t)b2, N, K, (size_t)(b2 + b3)};
+  h->split[W] = {0, (size_t)b2, N, K, (size_t)(b2 + b3), ws ? (size_t)off_st : 0};
   unsigned char* keep = h->split_arena;
   h->split_arena = buf;  // the lookup inside run_gemm resolves relative to split_arena
   int e = run_gemm(h, st, A, lda, nullptr, 0, 0, W, bias, R, ldy, Y, ldy, M, N, K, act);

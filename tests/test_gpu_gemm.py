@@ -26,6 +26,31 @@ def test_gemm_shapes(eng, M, N, K):
     assert (Y - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M", [16384, 16449, 291208])
+@pytest.mark.parametrize("act,strided", [(0, False), (1, True)])
+def test_gemm_weight_stationary_kernel(eng, M, act, strided):
+    """the K = 128 -> 256 token layer at token-count sizes takes the weight-stationary kernel (lt_gemm_ws.h): whole tiles, a
+    ragged last tile (16 449 = 257 x 64 + 1), the cfg3 size; bias + ReLU; row-strided input and output views."""
+    g = torch.Generator(device="cuda").manual_seed(M + act)
+    Abuf = torch.randn(M, 192 if strided else 128, device="cuda", generator=g)
+    A = Abuf[:, :128]
+    W = torch.randn(256, 128, device="cuda", generator=g) / 128 ** 0.5
+    b = torch.randn(256, device="cuda", generator=g)
+    Ybuf = torch.full((M + 1, 320 if strided else 256), -7.0, device="cuda")
+    Y = eng.debug_gemm(A, W, b, act=act, out=Ybuf[:M, :256])
+    ref = A.double() @ W.double().t() + b.double()
+    if act:
+        ref = ref.clamp_min(0)
+    assert (Y - ref.float()).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
+    assert (Ybuf[M] == -7.0).all() and (not strided or (Ybuf[:, 256:] == -7.0).all())     # nothing written outside the view
+    eng.set_profiling(True)
+    eng.debug_gemm(A, W, b, act=act, out=Ybuf[:M, :256])
+    torch.cuda.synchronize()
+    names = {e["name"] for e in eng.get_profile()}
+    eng.set_profiling(False)
+    assert "gemm_bf16x6_ws64x256" in names, names
+
+
 @pytest.mark.parametrize("mode,tol", [("f32", 2e-6), ("bf16x6", 2e-6), ("f16x3", 4e-6), ("bf16x3", 3e-5)])
 def test_gemm_precision_modes(eng, mode, tol):
     """every MFMA path against a float64 reference (relative to the largest output magnitude)."""

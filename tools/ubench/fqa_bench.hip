@@ -2,7 +2,6 @@
 // sub-lines, 4 heads.  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/fqa_bench.hip -o tools/ubench/fqa_bench
 #include "../../linetr_amd/csrc/lt_common.h"
 #define LT_FQA_STAMPS 1
-#define LT_FQA_STAMPS 1
 #include "../../linetr_amd/csrc/lt_attn_fused.h"
 namespace lt {
 inline bool small_gemm_wins(const GemmArgs&, int) { return false; }
