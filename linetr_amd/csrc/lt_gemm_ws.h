@@ -12,9 +12,10 @@
 //   * the accumulators start at the bias (kept in LDS); a half-wave swap per register pair leaves a lane with two runs of 8
 //     consecutive channels of its token: ReLU and four dwordx4 stores, no LDS in the epilogue, and the epilogue of one 32-token
 //     half runs in the MFMA slots of the other.  A wave writes complete 128-byte lines.
-// cfg3 (291 208 rows, tools/ubench/ws_gemm_bench.hip): 118-122 us = 160 TF-eq, 3.7 TB/s of its 447 MB; the tiled kernel it replaces:
-// 187 us.  Ablations: no MFMAs 92 us (the memory side alone), no loads and no stores 101-108 us (MFMAs + LDS fragment reads: eight
-// waves each read the whole tile, 50 % of the LDS read bandwidth), neither 46 us.
+// cfg3 (291 208 rows, tools/ubench/ws_gemm_bench.hip): 110-114 us = 170 TF-eq, 4.0 TB/s of its 447 MB; the tiled kernel it replaces:
+// 187 us.  Ablations: no MFMAs 96 us (the memory side alone: the kernel sits 15 % above it), no loads and no stores 92 us (MFMAs + LDS
+// fragment reads: eight waves each read the whole tile, 50 % of the LDS read bandwidth), neither 31 us.  Plain stores: write-through
+// (sc1) or nontemporal ones double the time (a wave writes 32-byte runs; the L2 has to merge them into lines).
 #pragma once
 #include "lt_gemm_st.h"
 
@@ -33,7 +34,7 @@ constexpr int WS_BUF = WS_NK * (WS_TM / 16) * ST_RB;      // 49 152: [K step][16
 constexpr int WS_LDS = 2 * WS_BUF + WS_N * 4;             // + the bias vector
 
 // DBG (tools/ubench/ws_gemm_bench.hip only): 1 no output stores (kept alive behind a never-true test), 2 no row loads after the
-// first two tiles, 4 no MFMAs
+// first two tiles, 4 no MFMAs, 8 write-through (sc1) stores, 16 nontemporal stores
 template <int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(WsGemmArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char ws_smem[];
@@ -48,7 +49,10 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsGemmArgs a) {
 
   // ---- loader: thread = (token tid >> 3 of the tile, 8-wide k pieces pc and pc + 8)
   const int tt = tid >> 3, pc = tid & 7;
-  const int wr_off = ((pc >> 1) * (WS_TM / 16) + (tt >> 4)) * ST_RB + (pc & 1) * 256 + (tt & 15) * 16;
+  // Inside a 256-byte (k half) row of a chunk the 16 token slots are ROTATED by 2 (piece & 7): the 16 lanes of a store group are
+  // 2 tokens x 8 pieces, which would otherwise all hit the same two 16-byte bank groups (8-way conflicts: measured 59 % of the
+  // LDS-active cycles); a fragment read sees one piece and 16 tokens, a rotation of a conflict-free row.
+  const int wr_off = ((pc >> 1) * (WS_TM / 16) + (tt >> 4)) * ST_RB + (pc & 1) * 256 + (((tt & 15) + 2 * pc) & 15) * 16;
   constexpr int WR_HALF = 4 * (WS_TM / 16) * ST_RB;        // piece pc + 8 sits four K steps further
   f32x4 raw[4];
   auto load_tile = [&](int t) {
@@ -90,6 +94,9 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsGemmArgs a) {
   load_tile(tile + gridDim.x);
   __syncthreads();
 
+  int zfrag[4];                                            // lfrag with the token slot rotated by 2 (2 kt + k half): four variants
+#pragma unroll
+  for (int c = 0; c < 4; ++c) zfrag[c] = ((lane >> 4) & 1) * ST_RB + (lane >> 5) * 256 + (((lane & 15) + 2 * (lane >> 5) + 4 * c) & 15) * 16;
   constexpr int TW[6] = {2, 1, 0, 1, 0, 0}, TA[6] = {0, 1, 2, 0, 1, 0};     // smallest cross terms first
   const int step = gridDim.x;
   // One tile = 96 MFMA slots in a fixed order (sched_barrier after each): the 48 of tokens 0..31 (acc0), then the 48 of tokens
@@ -124,8 +131,16 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsGemmArgs a) {
       if (DBG & 1) ok = ok && acc[o] == 12345.678f;
       if (ok) {
         float* yp = a.Y + (int64_t)row * a.ldy + 32 * wave + 8 * h2 + 16 * part;
+        if (DBG & 8) {
+          sk_store16(yp, f32x4{acc[o], acc[o + 1], acc[o + 2], acc[o + 3]});
+          sk_store16(yp + 4, f32x4{acc[o + 4], acc[o + 5], acc[o + 6], acc[o + 7]});
+        } else if (DBG & 16) {
+          __builtin_nontemporal_store(f32x4{acc[o], acc[o + 1], acc[o + 2], acc[o + 3]}, reinterpret_cast<f32x4*>(yp));
+          __builtin_nontemporal_store(f32x4{acc[o + 4], acc[o + 5], acc[o + 6], acc[o + 7]}, reinterpret_cast<f32x4*>(yp + 4));
+        } else {
         *reinterpret_cast<f32x4*>(yp) = f32x4{acc[o], acc[o + 1], acc[o + 2], acc[o + 3]};
         *reinterpret_cast<f32x4*>(yp + 4) = f32x4{acc[o + 4], acc[o + 5], acc[o + 6], acc[o + 7]};
+        }
       }
     }
   };
@@ -151,11 +166,11 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsGemmArgs a) {
   };
 #pragma unroll 1
   for (int it = 0; tile < ntiles; ++it) {
-    const unsigned char* src = ws_smem + (it & 1) * WS_BUF + lfrag;
+    const unsigned char* src = ws_smem + (it & 1) * WS_BUF;
     bf16x8 z[3][3];                                        // B fragments: the K step in flight and the next TWO (LDS latency under
                                                            // eight waves' reads is longer than one K step of MFMAs)
     auto read_z1 = [&](int g, int p) {                     // g = 8 j + kt
-      z[g % 3][p] = *reinterpret_cast<const bf16x8*>(src + ((g & 7) * (WS_TM / 16) + 2 * (g >> 3)) * ST_RB + p * ST_CHUNK);
+      z[g % 3][p] = *reinterpret_cast<const bf16x8*>(src + zfrag[g & 3] + ((g & 7) * (WS_TM / 16) + 2 * (g >> 3)) * ST_RB + p * ST_CHUNK);
     };
 #pragma unroll
     for (int p = 0; p < 3; ++p) { read_z1(0, p); read_z1(1, p); }
