@@ -1203,7 +1203,8 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     if (!two_pass) {
       ProfScope ps(h, st, "cls_pool_online", 2.0 * rows * (2.0 * HEADS * D * 2), (double)rows * D * 4 * 5);
       hipLaunchKernelGGL(cls_pool_online_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, ts.recs, ts.sub2line_g, ts.cpnt,
-                         w.a4, ts.first_pad, N, T, ts.nhwc, ts.Hc, ts.Wc, ts.align_corners, h->pool, w.pooled);
+                         w.a4, ts.first_pad, N, T, ts.nhwc, ts.Hc, ts.Wc, ts.align_corners, h->pool, w.pooled,
+                         LT_XENV("LINETR_POOL_FORWARD") ? 0 : 1);
     }
 #ifdef LINETR_EXPERIMENTS
     else {

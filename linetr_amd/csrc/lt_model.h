@@ -436,10 +436,13 @@ __global__ __launch_bounds__(256) void cls_pool_fused_kernel(
 __global__ __launch_bounds__(256, LT_POOL_WAVES_PER_EU) void cls_pool_online_kernel(
     const LinetrLineRec* __restrict__ recs, const int* __restrict__ sub2line_g, const float* __restrict__ cpnt,
     const float* __restrict__ a4, int64_t first_pad, int N, int T, const float* __restrict__ nhwc, int Hc, int Wc,
-    int align_corners, ClsPoolConst cc, float* __restrict__ pooled /*[N][4][544]*/) {
+    int align_corners, ClsPoolConst cc, float* __restrict__ pooled /*[N][4][544]*/, int reverse) {
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
+  // reverse: the LAST sub-lines first -- their a4 rows are the ones the token MLP wrote most recently and are still in the
+  // Infinity Cache (a4 of a cfg3 batch is 298 MB, the cache 256 MB: walking forward finds none of it)
+  const int n_fwd = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n_fwd >= N) return;
+  const int n = reverse ? N - 1 - n_fwd : n_fwd;
   const LinetrLineRec r = recs[sub2line_g[n]];
   const int j = n - r.first_sub;
   const int n_valid = min(T, r.n_tok - j * T);
