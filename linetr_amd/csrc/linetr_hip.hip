@@ -28,6 +28,7 @@
 #include "lt_model.h"
 #include "lt_attn_fused.h"
 #include "lt_gemm_ws.h"
+#include "lt_tokmlp.h"
 #ifdef LINETR_EXPERIMENTS
 #include "lt_attn_st.h"
 #endif
@@ -541,7 +542,8 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
       std::vector<double> Wf, bf;
       fold_bn(W, b, g, be, mu, va, ch[i + 1], ch[i], Wf, bf);
       // layer 4 (128 -> 256) also gets a split-tile image: the weight-stationary kernel of lt_gemm_ws.h reads its planes from it
-      if (i == 0) place(Wdst[i], Wf); else place_w(Wdst[i], Wf, ch[i + 1], ch[i], ch[i + 1] == WS_N && ch[i] == WS_K);
+      // (the word encoder's layers 2 and 3 too: the one-kernel token MLP of lt_tokmlp.h keeps them in LDS as split-tile images)
+      if (i == 0) place(Wdst[i], Wf); else place_w(Wdst[i], Wf, ch[i + 1], ch[i], (ch[i + 1] == WS_N && ch[i] == WS_K) || enc == 0);
       place(bdst[i], bf);
     }
     const float* W = tm.get(pre + "12.weight", (int64_t)D * e3, err);
@@ -1151,6 +1153,21 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   int e;
   // ---- word positional encoder up to the last ReLU (a4); its final linear layer is applied after pooling
   const bool fused_mlp = fused_mlp_enabled(c);
+  // layers 1-4 in one kernel (lt_tokmlp.h): large batches in the default precision, the reference's channel widths
+  auto st_of = [&](const float* W) -> const unsigned char* {
+    auto it = h->split.find(W);
+    return it != h->split.end() && it->second.offst ? h->split_arena + it->second.offst : nullptr;
+  };
+  const bool tok_mlp = fused_mlp && h->precision == LINETR_PREC_BF16X6 && rows >= 16384 && e0 == 32 && e1 == 64 && e2 == 128 && e3 == 256 &&
+                       st_of(h->wW2) && st_of(h->wW3) && st_of(h->wW4) && !LT_XENV("LINETR_NO_TOKMLP");
+  if (tok_mlp) {
+    TokMlpArgs a;
+    a.pnt = ts.cpnt ? ts.cpnt : ts.pnt; a.score = ts.cpnt ? ts.cscore : ts.score; a.rows = rows; a.cx = cx; a.cy = cy; a.scale = scale;
+    a.W1 = h->wW1; a.b1 = h->wb1; a.W2st = st_of(h->wW2); a.b2 = h->wb2; a.W3st = st_of(h->wW3); a.b3 = h->wb3;
+    a.W4st = st_of(h->wW4); a.b4 = h->wb4; a.Y = w.a4; a.ldy = e3;
+    ProfScope ps(h, st, "tok_mlp_bf16x6", 2.0 * rows * (3 * e0 + e0 * e1 + e1 * e2 + e2 * e3), (double)rows * (12 + 4 * e3));
+    if ((e = tok_mlp_launch(a, st))) return e;
+  } else {
   if (fused_mlp) {   // layers 1-3 in one exact-fp32 MFMA kernel (lt_model.h)
     ProfScope ps(h, st, "mlp123", 2.0 * rows * (3 * e0 + e0 * e1 + e1 * e2), (double)rows * (12 + 4 * e2));
     const int rpw = mlp123_rows_per_wave(rows);
@@ -1169,6 +1186,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     if ((e = run_gemm(h, st, w.a2, e1, nullptr, 0, 0, h->wW3, h->wb3, nullptr, 0, w.a3, e2, (int)rows, e2, e1, ACT_RELU))) return e;
   }
   if ((e = run_gemm(h, st, w.a3, e2, nullptr, 0, 0, h->wW4, h->wb4, nullptr, 0, w.a4, e3, (int)rows, e3, e2, ACT_RELU))) return e;
+  }
   // ---- line positional encoder: independent of everything above -> side stream when available
   hipStream_t ls = ts.use_side ? h->side : st;
   if (fused_mlp) {

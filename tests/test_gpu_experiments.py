@@ -144,12 +144,13 @@ def test_gemm_st_vs_float64(eng, M, N, K1, K2, bias, res, act, st_out):
 
 @pytest.mark.parametrize("path_env", [{"LINETR_SIG_PATH": "st"}, {"LINETR_SIG_PATH": "st", "LINETR_ATTN_ST_OCC1": "1"},
                                       {"LINETR_GEMM_CHAIN": "1"}, {"LINETR_GEMM_CHAIN": "1", "LINETR_CHAIN_W1_ALONE": "1"},
-                                      {"LINETR_NO_FUSED_QKV_ATTN": "1"}, {"LINETR_NO_GEMM_WS": "1"}])
+                                      {"LINETR_NO_FUSED_QKV_ATTN": "1"}, {"LINETR_NO_GEMM_WS": "1"}, {"LINETR_NO_TOKMLP": "1"},
+                                      {"LINETR_NO_TOKMLP": "1", "LINETR_NO_GEMM_WS": "1"}])
 def test_alternative_signature_paths_equal_the_shipped_one(eng, monkeypatch, path_env):
     """cfg3 batch through the split-tile path (ST GEMMs + ST attention, activations as bf16 planes in HBM) and through the
     row-tile-local GEMM chains, against the shipped path of the same library: same products, same accumulation type."""
     _, cat, off, dd, ds = batch_inputs(128)
-    for k in ("LINETR_SIG_PATH", "LINETR_ATTN_ST_OCC1", "LINETR_GEMM_CHAIN", "LINETR_CHAIN_W1_ALONE", "LINETR_NO_FUSED_QKV_ATTN", "LINETR_NO_GEMM_WS"):
+    for k in ("LINETR_SIG_PATH", "LINETR_ATTN_ST_OCC1", "LINETR_GEMM_CHAIN", "LINETR_CHAIN_W1_ALONE", "LINETR_NO_FUSED_QKV_ATTN", "LINETR_NO_GEMM_WS", "LINETR_NO_TOKMLP"):
         monkeypatch.delenv(k, raising=False)
     _, plain = describe(eng, cat, off, dd, ds)
     plain = plain.clone()
