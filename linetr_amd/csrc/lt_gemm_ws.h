@@ -34,7 +34,8 @@ constexpr int WS_BUF = WS_NK * (WS_TM / 16) * ST_RB;      // 49 152: [K step][16
 constexpr int WS_LDS = 2 * WS_BUF + WS_N * 4;             // + the bias vector
 
 // DBG (tools/ubench/ws_gemm_bench.hip only): 1 no output stores (kept alive behind a never-true test), 2 no row loads after the
-// first two tiles, 4 no MFMAs, 8 write-through (sc1) stores, 16 nontemporal stores
+// first two tiles, 4 no MFMAs, 8 write-through (sc1) stores, 16 nontemporal stores, 32 no B-fragment reads in the
+// slot loop (wrong data, timing only)
 template <int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(WsGemmArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char ws_smem[];
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsGemmArgs a) {
         if (t == 0) { if (g < 8) acc0[kt] += __builtin_bit_cast(float, (unsigned)z[g % 3][0][0] << 16 | (unsigned)wreg[kt][0][0]); else acc1[kt] += __builtin_bit_cast(float, (unsigned)z[g % 3][1][0] << 16 | (unsigned)wreg[kt][1][0]); }
       } else if (g < 8) acc0 = mfma_split<0>(wreg[kt][TW[t]], z[g % 3][TA[t]], acc0);
       else acc1 = mfma_split<0>(wreg[kt][TW[t]], z[g % 3][TA[t]], acc1);
-      if (t < 3 && g + 2 < 16) read_z1(g + 2, t);          // into the set group g - 1 has just left
+      if (t < 3 && g + 2 < 16 && !(DBG & 32)) read_z1(g + 2, t);   // into the set group g - 1 has just left
       if (m >= 2 && m < 13) epi_step(acc1, prev_tile, 1, m - 2);
       if (m >= 30 && m < 42) split_step(m - 30, (it & 1) ^ 1);
       if (m == 44 && !(DBG & 2)) load_tile(tile + 2 * step);

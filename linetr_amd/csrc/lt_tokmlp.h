@@ -16,6 +16,11 @@
 // with a block barrier before B, before C and before D.  All products are the transposed
 // ones (weights = MFMA A operand), so an accumulator tile is [32 channels][32 tokens], a lane owns one token, and one half-wave swap
 // per register pair turns it into two 8-channel pieces of that token's row: exactly the 16-byte pieces of the next image.
+// Measured at cfg3 (291 208 rows): 140-150 us against 78 (mlp123) + 108 (K = 128 GEMM) for the pair it replaces.  A software-pipelined
+// variant (tiles of 32 rows, every image double-buffered, layer 4 of tile s - 3 / layer 3 of s - 2 on waves 4-7 / layer 2 of s - 1 on
+// waves 0-1 / layer 1 of s in ONE barrier interval) was built and measured on the same box: 165 us -- the matrix pipe is not idle
+// for lack of work here, the MFMAs alone take 80 us of layer 4's 110 at the clock the power cap allows (tools/ubench/ws_gemm_bench.hip:
+// removing every B-fragment read changes nothing), so filling the A / B / C gaps buys nothing and the extra barriers cost.
 #pragma once
 #include "lt_gemm_ws.h"
 

@@ -49,7 +49,9 @@ int main() {
     printf("ws gemm 291208 x 256 x 128, grid %d: full %.1f us (%.0f TF-eq, %.2f TB/s) | no stores %.1f | no loads %.1f | no loads, no stores %.1f | no MFMAs %.1f | "
            "no MFMAs, no stores %.1f | skeleton %.1f\n", grid, t0, 2.0 * M * 256 * 128 / t0 * 1e-6, (double)M * 1536 / t0 * 1e-6, t1, t2, t3, t4, t5, t7);
   }
-  for (int r = 0; r < 3; ++r)
+  printf("grid 512: no loads, no stores %.1f us | the same without the B-fragment reads (MFMAs + barriers + LDS stores only) %.1f | "
+         "full without fragment reads %.1f\n", run<3>(a, 512, it), run<35>(a, 512, it), run<32>(a, 512, it));
+  for (int r = 0; r < 1; ++r)
     printf("stores: plain %.1f us | write-through (sc1) %.1f | nontemporal %.1f   (grid 512)\n", run<0>(a, 512, it), run<8>(a, 512, it), run<16>(a, 512, it));
   return 0;
 }
