@@ -311,7 +311,8 @@ PMC_KERNEL_NAMES = {   # profile class -> kernel symbol prefix in profiles/<tag>
     "gemm_f16x3_256x128": "void lt::gemm_split_kernel<256, 128, 4, 2, 2, true, 1",
     "gemm_bf16x6_128x128s": "void lt::gemm_split_kernel<128, 128, 2, 4, 3, false, 0",
     "gemm_bf16x6_ws64x256": "void lt::gemm_ws_kernel<0>",
-    "tok_mlp_bf16x6": "lt::tok_mlp_kernel",
+    "tok_mlp_bf16x6": "void lt::tok_mlp_kernel<true>",
+    "line_mlp_bf16x6": "void lt::tok_mlp_kernel<false>",
     "gemm_bf16x6_64x64": "void lt::gemm_split_kernel<64, 64, 2, 2, 3, true, 0",
     "gemm_bf16x6_64x128": "void lt::gemm_split_kernel<64, 128, 2, 2, 3, true, 0",
     "gemm_bf16x6_32x32k4": "void lt::gemm_split_small_kernel<3, 0",

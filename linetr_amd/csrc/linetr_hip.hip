@@ -541,9 +541,9 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
       if (err) return err;
       std::vector<double> Wf, bf;
       fold_bn(W, b, g, be, mu, va, ch[i + 1], ch[i], Wf, bf);
-      // layer 4 (128 -> 256) also gets a split-tile image: the weight-stationary kernel of lt_gemm_ws.h reads its planes from it
-      // (the word encoder's layers 2 and 3 too: the one-kernel token MLP of lt_tokmlp.h keeps them in LDS as split-tile images)
-      if (i == 0) place(Wdst[i], Wf); else place_w(Wdst[i], Wf, ch[i + 1], ch[i], (ch[i + 1] == WS_N && ch[i] == WS_K) || enc == 0);
+      // layers 2-4 also get split-tile images: the one-kernel MLP of lt_tokmlp.h keeps layers 2 / 3 in LDS and layer 4 in registers as
+      // such, and the weight-stationary GEMM of lt_gemm_ws.h reads layer 4's planes from one
+      if (i == 0) place(Wdst[i], Wf); else place_w(Wdst[i], Wf, ch[i + 1], ch[i], true);
       place(bdst[i], bf);
     }
     const float* W = tm.get(pre + "12.weight", (int64_t)D * e3, err);
@@ -1158,15 +1158,18 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     auto it = h->split.find(W);
     return it != h->split.end() && it->second.offst ? h->split_arena + it->second.offst : nullptr;
   };
-  const bool tok_mlp = fused_mlp && h->precision == LINETR_PREC_BF16X6 && rows >= 16384 && e0 == 32 && e1 == 64 && e2 == 128 && e3 == 256 &&
-                       st_of(h->wW2) && st_of(h->wW3) && st_of(h->wW4) && !LT_XENV("LINETR_NO_TOKMLP");
+  int64_t tok_mlp_min_rows = 0;      // any size: a single pair (4 k token rows, 400 sub-lines) gains too: 42 -> 31 us for the two encoders
+  if (const char* v = LT_XENV("LINETR_TOKMLP_MIN_ROWS")) tok_mlp_min_rows = atoll(v);   // tuning aid (experiments build)
+  const bool tok_mlp_ok = fused_mlp && h->precision == LINETR_PREC_BF16X6 && e0 == 32 && e1 == 64 && e2 == 128 && e3 == 256 &&
+                          !LT_XENV("LINETR_NO_TOKMLP");
+  const bool tok_mlp = tok_mlp_ok && rows >= tok_mlp_min_rows && st_of(h->wW2) && st_of(h->wW3) && st_of(h->wW4);
   if (tok_mlp) {
     TokMlpArgs a;
-    a.pnt = ts.cpnt ? ts.cpnt : ts.pnt; a.score = ts.cpnt ? ts.cscore : ts.score; a.rows = rows; a.cx = cx; a.cy = cy; a.scale = scale;
+    a.p0 = ts.cpnt ? ts.cpnt : ts.pnt; a.p1 = ts.cpnt ? ts.cscore : ts.score; a.rows = rows; a.cx = cx; a.cy = cy; a.scale = scale;
     a.W1 = h->wW1; a.b1 = h->wb1; a.W2st = st_of(h->wW2); a.b2 = h->wb2; a.W3st = st_of(h->wW3); a.b3 = h->wb3;
     a.W4st = st_of(h->wW4); a.b4 = h->wb4; a.Y = w.a4; a.ldy = e3;
     ProfScope ps(h, st, "tok_mlp_bf16x6", 2.0 * rows * (3 * e0 + e0 * e1 + e1 * e2 + e2 * e3), (double)rows * (12 + 4 * e3));
-    if ((e = tok_mlp_launch(a, st))) return e;
+    if ((e = tok_mlp_launch(a, true, st))) return e;
   } else {
   if (fused_mlp) {   // layers 1-3 in one exact-fp32 MFMA kernel (lt_model.h)
     ProfScope ps(h, st, "mlp123", 2.0 * rows * (3 * e0 + e0 * e1 + e1 * e2), (double)rows * (12 + 4 * e2));
@@ -1189,6 +1192,15 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   }
   // ---- line positional encoder: independent of everything above -> side stream when available
   hipStream_t ls = ts.use_side ? h->side : st;
+  const bool line_mlp = tok_mlp_ok && N >= tok_mlp_min_rows && st_of(h->lW2) && st_of(h->lW3) && st_of(h->lW4);
+  if (line_mlp) {   // layers 1-4 in one kernel, as for the word encoder
+    TokMlpArgs a;
+    a.p0 = sublines; a.p1 = resp; a.p2 = angle_sub; a.rows = N; a.cx = cx; a.cy = cy; a.scale = scale;
+    a.W1 = h->lW1; a.b1 = h->lb1; a.W2st = st_of(h->lW2); a.b2 = h->lb2; a.W3st = st_of(h->lW3); a.b3 = h->lb3;
+    a.W4st = st_of(h->lW4); a.b4 = h->lb4; a.Y = w.l4; a.ldy = e3;
+    ProfScope ps(h, ls, "line_mlp_bf16x6", 2.0 * N * (5 * e0 + e0 * e1 + e1 * e2 + e2 * e3), (double)N * (28 + 4 * e3));
+    if ((e = tok_mlp_launch(a, false, ls))) return e;
+  } else {
   if (fused_mlp) {
     ProfScope ps(h, ls, "mlp123_line", 2.0 * N * (5 * e0 + e0 * e1 + e1 * e2), (double)N * (28 + 4 * e2));
     const int rpw = mlp123_rows_per_wave(N);
@@ -1206,6 +1218,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     if ((e = run_gemm(h, ls, w.l2, e1, nullptr, 0, 0, h->lW3, h->lb3, nullptr, 0, w.l3, e2, N, e2, e1, ACT_RELU))) return e;
   }
   if ((e = run_gemm(h, ls, w.l3, e2, nullptr, 0, 0, h->lW4, h->lb4, nullptr, 0, w.l4, e3, N, e3, e2, ACT_RELU))) return e;
+  }
   if ((e = run_gemm(h, ls, w.l4, e3, nullptr, 0, 0, h->lW5, h->lb5, nullptr, 0, w.lpos, D, N, D, e3, ACT_NONE))) return e;
   if (ts.use_side) {
     LT_HIP(hipEventRecord(h->ev_lpos, h->side));

@@ -1,6 +1,7 @@
-// The WordPositionalEncoder MLP up to its last ReLU in ONE kernel (bf16x6):  a4 = relu(W4 relu(W3 relu(W2 relu(W1 f + b1) + b2) + b3) + b4)
-// for every real token row of the batch, f = (x, y, score) (models/line_transformer.py:9-20, 52-73; BatchNorm folded).  The fifth,
-// linear layer is applied after the pooling.  Replaces mlp123_kernel + the weight-stationary K = 128 GEMM for
+// The WordPositionalEncoder / LinePositionalEncoder MLP up to its last ReLU in ONE kernel (bf16x6):  a4 = relu(W4 relu(W3 relu(W2 relu(W1 f + b1) + b2) + b3) + b4)
+// for every real token row of the batch, f = (x, y, score), or for every sub-line, f = (mid x, mid y, response, cos 2 theta, sin 2 theta)
+// (models/line_transformer.py:9-20, 40-73; BatchNorm folded).  The fifth, linear layer is applied after the pooling (word encoder,
+// DESIGN.md section 3) or by the next GEMM (line encoder).  Replaces mlp123_kernel + the weight-stationary K = 128 GEMM for
 // the word encoder: the 128-channel activations (512 B per token written and read back) never reach HBM, the kernel reads 12 bytes
 // and writes 1 KiB per token.
 //
@@ -16,7 +17,8 @@
 // with a block barrier before B, before C and before D.  All products are the transposed
 // ones (weights = MFMA A operand), so an accumulator tile is [32 channels][32 tokens], a lane owns one token, and one half-wave swap
 // per register pair turns it into two 8-channel pieces of that token's row: exactly the 16-byte pieces of the next image.
-// Measured at cfg3 (291 208 rows): 140-150 us against 78 (mlp123) + 108 (K = 128 GEMM) for the pair it replaces.  A software-pipelined
+// Measured at cfg3 (291 208 token rows): 140-150 us against 78 (mlp123) + 108 (K = 128 GEMM) for the pair it replaces; the line encoder
+// (25 472 rows): 29 against 16.5 + 23 us; a single pair (4 378 / 398 rows): 15.7 us each, mostly the weight prologue, against 21 us each.  A software-pipelined
 // variant (tiles of 32 rows, every image double-buffered, layer 4 of tile s - 3 / layer 3 of s - 2 on waves 4-7 / layer 2 of s - 1 on
 // waves 0-1 / layer 1 of s in ONE barrier interval) was built and measured on the same box: 165 us -- the matrix pipe is not idle
 // for lack of work here, the MFMAs alone take 80 us of layer 4's 110 at the clock the power cap allows (tools/ubench/ws_gemm_bench.hip:
@@ -27,11 +29,12 @@
 namespace lt {
 
 struct TokMlpArgs {
-  const float* pnt = nullptr;                    // [rows][2] token coordinates (pixels)
-  const float* score = nullptr;                  // [rows]
+  // WORD: p0 = token coordinates [rows][2] (pixels), p1 = scores [rows]; LINE: p0 = sub-line end points [rows][4], p1 = responses
+  // [rows], p2 = (cos 2 theta, sin 2 theta) [rows][2]  (word_feat / line_feat of lt_model.h)
+  const float* p0 = nullptr; const float* p1 = nullptr; const float* p2 = nullptr;
   int64_t rows = 0;
   float cx = 0.f, cy = 0.f, scale = 1.f;         // normalize_keylines (line_transformer.py:22-38)
-  const float* W1 = nullptr; const float* b1 = nullptr;            // [32][3], [32]
+  const float* W1 = nullptr; const float* b1 = nullptr;            // [32][3 or 5], [32]
   const unsigned char* W2st = nullptr; const float* b2 = nullptr;  // split-tile image of [64][32]
   const unsigned char* W3st = nullptr; const float* b3 = nullptr;  // of [128][64]
   const unsigned char* W4st = nullptr; const float* b4 = nullptr;  // of [256][128]
@@ -44,11 +47,13 @@ constexpr int TK_A2 = TK_A1 + 2 * TK_TB * ST_RB;           // 12 288: 4 K steps
 constexpr int TK_A3 = TK_A2 + 4 * TK_TB * ST_RB;           // 36 864: 8 K steps
 constexpr int TK_W2 = TK_A3 + 8 * TK_TB * ST_RB;           // 86 016: [2 K steps][4 row blocks] (the image's pad row blocks dropped)
 constexpr int TK_W3 = TK_W2 + 2 * 4 * ST_RB;               // 98 304: [4 K steps][8 row blocks]
-constexpr int TK_P = TK_W3 + 4 * 8 * ST_RB;                // 147 456: W1 as [32][w0 w1 w2 bias], b2, b3, b4
-constexpr int TK_P_FLOATS = 32 * 4 + 64 + 128 + 256;
-constexpr int TK_LDS = TK_P + TK_P_FLOATS * 4;             // 149 760
+constexpr int TK_P = TK_W3 + 4 * 8 * ST_RB;                // 147 456: W1 as [32][8], b2, b3, b4
+constexpr int TK_P_FLOATS = 32 * 8 + 64 + 128 + 256;        // W1 rows as [w0 .. w4, -, -, bias]
+constexpr int TK_LDS = TK_P + TK_P_FLOATS * 4;             // 150 272
 
+template <bool WORD>
 __global__ __launch_bounds__(512) void tok_mlp_kernel(TokMlpArgs a) {
+  constexpr int IN = WORD ? 3 : 5;
   extern __shared__ __attribute__((aligned(1024))) unsigned char tk_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,12 +72,12 @@ __global__ __launch_bounds__(512) void tok_mlp_kernel(TokMlpArgs a) {
   }
   for (int i = tid; i < 4 * 8 * ST_RB / 16; i += 512)
     *reinterpret_cast<u32x4*>(tk_smem + TK_W3 + i * 16) = *reinterpret_cast<const u32x4*>(a.W3st + (int64_t)i * 16);
-  if (tid < 32) {
-    prm[tid * 4 + 0] = a.W1[tid * 3 + 0]; prm[tid * 4 + 1] = a.W1[tid * 3 + 1]; prm[tid * 4 + 2] = a.W1[tid * 3 + 2];
-    prm[tid * 4 + 3] = a.b1[tid];
-  } else if (tid < 96) prm[128 + tid - 32] = a.b2[tid - 32];
-  else if (tid < 224) prm[192 + tid - 96] = a.b3[tid - 96];
-  else if (tid < 480) prm[320 + tid - 224] = a.b4[tid - 224];
+  if (tid < 256) {
+    const int k = tid >> 3, c = tid & 7;
+    prm[tid] = c < IN ? a.W1[k * IN + c] : (c == 7 ? a.b1[k] : 0.f);
+  } else if (tid < 320) prm[tid] = a.b2[tid - 256];
+  else if (tid < 448) prm[tid] = a.b3[tid - 320];
+  for (int i = tid; i < 256; i += 512) prm[448 + i] = a.b4[i];
   bf16x8 wreg[8][3];
   {
     const unsigned char* wp = a.W4st + (int64_t)(2 * wave) * ST_RB + lfrag;
@@ -82,12 +87,12 @@ __global__ __launch_bounds__(512) void tok_mlp_kernel(TokMlpArgs a) {
       for (int p = 0; p < 3; ++p) wreg[kt][p] = *reinterpret_cast<const bf16x8*>(wp + (int64_t)kt * 16 * ST_RB + p * ST_CHUNK);
   }
   // token features of the tile: waves 0-3, lane = token (each of the four waves needs all 64 tokens)
-  float fx, fy, fs;
+  float feat[IN];
   auto load_feat = [&](int t) {
     int64_t row = (int64_t)t * TK_TM + lane;
     row = row < a.rows ? row : a.rows - 1;
-    const f32x2 p = *reinterpret_cast<const f32x2*>(a.pnt + row * 2);
-    fx = p[0]; fy = p[1]; fs = a.score[row];
+    if constexpr (WORD) word_feat(a.p0, a.p1, row, a.cx, a.cy, a.scale, feat);
+    else line_feat(a.p0, a.p1, a.p2, row, a.cx, a.cy, a.scale, feat);
   };
   load_feat(tile);
   __syncthreads();
@@ -149,18 +154,20 @@ __global__ __launch_bounds__(512) void tok_mlp_kernel(TokMlpArgs a) {
   // ---- A: layer 1 on the VALU (one multiply and one add per term, bias first, like mlp123_kernel / word_mlp1_kernel), cut into
   // steps that ride in the MFMA slots of D: piece wave & 3 (8 channels) of token `lane`.  Waves 4-7 repeat the work of waves 0-3 and
   // store the same bytes: no wave-dependent branch inside the slot loop.
-  float av[8], af0, af1, af2;
+  float av[8], af[IN];
   auto a_step = [&](int e) {
 #pragma clang fp contract(off)
     if (e == 0) {
-      af0 = (fx - a.cx) / a.scale; af1 = (fy - a.cy) / a.scale; af2 = fs;
+#pragma unroll
+      for (int i = 0; i < IN; ++i) af[i] = feat[i];        // (free the registers for the next tile's loads)
     } else if (e <= 8) {
       const int c = e - 1;
-      const f32x4 w = *reinterpret_cast<const f32x4*>(prm + (8 * (wave & 3) + c) * 4);
-      float t = w[3];
-      t += w[0] * af0;
-      t += w[1] * af1;
-      t += w[2] * af2;
+      const float* wr = prm + (8 * (wave & 3) + c) * 8;
+      const f32x4 wa = *reinterpret_cast<const f32x4*>(wr), wb = *reinterpret_cast<const f32x4*>(wr + 4);
+      const float wv[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
+      float t = wv[7];                                     // bias
+#pragma unroll
+      for (int i = 0; i < IN; ++i) t += wv[i] * af[i];
       av[c] = fmaxf(t, 0.f);
     } else {
       write_piece(av, tk_smem + TK_A1 + (((wave & 3) >> 1) * TK_TB + (lane >> 4)) * ST_RB + (wave & 1) * 256 + (lane & 15) * 16);
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(512) void tok_mlp_kernel(TokMlpArgs a) {
     // ---- B: layer 2, K = 32: wave (cg = wave & 1: 32 channels, th = wave >> 1: 32 tokens), waves 0-3
     if (wave < 4) {
       const int cg = wave & 1, th = wave >> 1;
-      init_acc(acc0, prm + 128 + 32 * cg);
+      init_acc(acc0, prm + 256 + 32 * cg);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
         bf16x8 wf[3], zf[3];
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(512) void tok_mlp_kernel(TokMlpArgs a) {
     // ---- C: layer 3, K = 64: wave (cg = wave & 3, th = wave >> 2)
     {
       const int cg = wave & 3, th = wave >> 2;
-      init_acc(acc0, prm + 192 + 32 * cg);
+      init_acc(acc0, prm + 320 + 32 * cg);
       bf16x8 wf[2][3], zf[2][3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
@@ -227,11 +234,11 @@ __global__ __launch_bounds__(512) void tok_mlp_kernel(TokMlpArgs a) {
       };
 #pragma unroll
       for (int p = 0; p < 3; ++p) { read_z1(0, p); read_z1(1, p); }
-      init_acc(acc0, prm + 320 + 32 * wave);
+      init_acc(acc0, prm + 448 + 32 * wave);
 #pragma clang loop unroll(full)
       for (int m = 0; m < 96; ++m) {
         const int g = m / 6, t = m % 6, kt = g & 7;
-        if (m == 48) init_acc(acc1, prm + 320 + 32 * wave);
+        if (m == 48) init_acc(acc1, prm + 448 + 32 * wave);
         if (g < 8) acc0 = mfma_split<0>(wreg[kt][TW[t]], z[g % 3][TA[t]], acc0);
         else acc1 = mfma_split<0>(wreg[kt][TW[t]], z[g % 3][TA[t]], acc1);
         if (t < 3 && g + 2 < 16) read_z1(g + 2, t);
@@ -246,14 +253,15 @@ __global__ __launch_bounds__(512) void tok_mlp_kernel(TokMlpArgs a) {
   for (int e = 0; e < 11; ++e) epi_step(acc1, prev_tile, 1, e);
 }
 
-inline int tok_mlp_launch(const TokMlpArgs& a, hipStream_t st) {
+inline int tok_mlp_launch(const TokMlpArgs& a, bool word, hipStream_t st) {
   if (a.rows <= 0) return 0;
-  if (!a.pnt || !a.score || !a.W1 || !a.W2st || !a.W3st || !a.W4st || !a.b1 || !a.b2 || !a.b3 || !a.b4 || !a.Y || a.ldy % 4)
+  if (!a.p0 || !a.p1 || (!word && !a.p2) || !a.W1 || !a.W2st || !a.W3st || !a.W4st || !a.b1 || !a.b2 || !a.b3 || !a.b4 || !a.Y || a.ldy % 4)
     return fail(LINETR_E_ARG, "tok_mlp: missing operand");
   static unsigned long long attr_done = 0;
   const unsigned long long dev_bit = current_device_bit();
   if (!(attr_done & dev_bit)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tok_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TK_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tok_mlp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TK_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tok_mlp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TK_LDS);
     attr_done |= dev_bit;
   }
   static int n_cu = 0;
@@ -263,7 +271,9 @@ inline int tok_mlp_launch(const TokMlpArgs& a, hipStream_t st) {
     n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
   }
   const int64_t ntiles = (a.rows + TK_TM - 1) / TK_TM;
-  hipLaunchKernelGGL(tok_mlp_kernel, dim3((unsigned)std::min<int64_t>(ntiles, n_cu)), dim3(512), TK_LDS, st, a);
+  const dim3 grid((unsigned)std::min<int64_t>(ntiles, n_cu));
+  if (word) hipLaunchKernelGGL(tok_mlp_kernel<true>, grid, dim3(512), TK_LDS, st, a);
+  else hipLaunchKernelGGL(tok_mlp_kernel<false>, grid, dim3(512), TK_LDS, st, a);
   LT_LAUNCH_CHECK();
   return 0;
 }
