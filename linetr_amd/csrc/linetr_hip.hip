@@ -1233,9 +1233,14 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
 #endif
     if (!two_pass) {
       ProfScope ps(h, st, "cls_pool_online", 2.0 * rows * (2.0 * HEADS * D * 2), (double)rows * D * 4 * 5);
-      hipLaunchKernelGGL(cls_pool_online_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, ts.recs, ts.sub2line_g, ts.cpnt,
-                         w.a4, ts.first_pad, N, T, ts.nhwc, ts.Hc, ts.Wc, ts.align_corners, h->pool, w.pooled,
-                         LT_XENV("LINETR_POOL_FORWARD") ? 0 : 1);
+      // few sub-lines (a single pair): four waves per sub-line, so that the chip is covered and the token chain is a quarter as long
+      if (N <= 2048 && !LT_XENV("LINETR_POOL_NO_SPLIT"))
+        hipLaunchKernelGGL(cls_pool_online_kernel<4>, dim3(N), dim3(256), 0, st, ts.recs, ts.sub2line_g, ts.cpnt,
+                           w.a4, ts.first_pad, N, T, ts.nhwc, ts.Hc, ts.Wc, ts.align_corners, h->pool, w.pooled, 0);
+      else
+        hipLaunchKernelGGL(cls_pool_online_kernel<1>, dim3(cdiv(N, 4)), dim3(256), 0, st, ts.recs, ts.sub2line_g, ts.cpnt,
+                           w.a4, ts.first_pad, N, T, ts.nhwc, ts.Hc, ts.Wc, ts.align_corners, h->pool, w.pooled,
+                           LT_XENV("LINETR_POOL_FORWARD") ? 0 : 1);
     }
 #ifdef LINETR_EXPERIMENTS
     else {

@@ -433,14 +433,19 @@ __global__ __launch_bounds__(256) void cls_pool_fused_kernel(
 #ifndef LT_POOL_WAVES_PER_EU
 #define LT_POOL_WAVES_PER_EU 3   // second __launch_bounds__ argument = waves per SIMD the register allocation must allow
 #endif
+// SPLIT = 4 (a few hundred sub-lines: a single pair): the block's four waves share ONE sub-line, wave w taking tokens w, w + 4, ..;
+// the four partial (max, sum, pooled sums) states are merged through LDS, wave h finishing head h.  The dependent chain per wave is a
+// quarter as long (21 tokens -> 6): 24 -> 10 us at cfg2.
+template <int SPLIT>
 __global__ __launch_bounds__(256, LT_POOL_WAVES_PER_EU) void cls_pool_online_kernel(
     const LinetrLineRec* __restrict__ recs, const int* __restrict__ sub2line_g, const float* __restrict__ cpnt,
     const float* __restrict__ a4, int64_t first_pad, int N, int T, const float* __restrict__ nhwc, int Hc, int Wc,
     int align_corners, ClsPoolConst cc, float* __restrict__ pooled /*[N][4][544]*/, int reverse) {
   const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
   // reverse: the LAST sub-lines first -- their a4 rows are the ones the token MLP wrote most recently and are still in the
   // Infinity Cache (a4 of a cfg3 batch is 298 MB, the cache 256 MB: walking forward finds none of it)
-  const int n_fwd = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n_fwd = SPLIT == 1 ? blockIdx.x * 4 + wv : blockIdx.x;
   if (n_fwd >= N) return;
   const int n = reverse ? N - 1 - n_fwd : n_fwd;
   const LinetrLineRec r = recs[sub2line_g[n]];
@@ -463,6 +468,7 @@ __global__ __launch_bounds__(256, LT_POOL_WAVES_PER_EU) void cls_pool_online_ker
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
     m[h] = cc.s_cls[h] * LOG2E; l[h] = 1.f; w0[h] = 1.f;
+    if (SPLIT > 1 && wv != 0) { m[h] = -INFINITY; l[h] = 0.f; w0[h] = 0.f; }   // the CLS key belongs to wave 0's share
     db[h] = f32x4{0.f, 0.f, 0.f, 0.f};
     ab[h] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -490,12 +496,13 @@ __global__ __launch_bounds__(256, LT_POOL_WAVES_PER_EU) void cls_pool_online_ker
   };
   TapSet cur, nxt;
   f32x4 a_cur, a_nxt;
+  const int jj0 = SPLIT == 1 ? 0 : wv;
   fill_taps(0);
-  issue(0, cur, a_cur);
-  for (int jj = 0; jj < ntk; ++jj) {
-    if (jj + 1 < ntk) {  // wave-uniform
-      if (((jj + 1) & 63) == 0) fill_taps(jj + 1);
-      issue(jj + 1, nxt, a_nxt);
+  if (jj0 < ntk) issue(jj0, cur, a_cur);
+  for (int jj = jj0; jj < ntk; jj += SPLIT) {
+    if (jj + SPLIT < ntk) {  // wave-uniform
+      if (((jj + SPLIT) >> 6) != (jj >> 6)) fill_taps((jj + SPLIT) & ~63);
+      issue(jj + SPLIT, nxt, a_nxt);
     }
     const f32x4 dv = taps_finish<true>(cur);
     const float mult = jj < n_valid ? 1.f : (float)n_pad;
@@ -532,6 +539,44 @@ __global__ __launch_bounds__(256, LT_POOL_WAVES_PER_EU) void cls_pool_online_ker
     a_cur = a_nxt;
   }
   float* out = pooled + (int64_t)n * 4 * POOLW;
+  if constexpr (SPLIT > 1) {
+    // merge the four waves' states: wave h finishes head h
+    __shared__ float st_ml[4][4][4];                        // [wave][head][m, l, w0, -]
+    __shared__ f32x4 st_v[4][4][2][64];                     // [wave][head][d / a][lane]
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      if (lane == 0) { st_ml[wv][h][0] = m[h]; st_ml[wv][h][1] = l[h]; st_ml[wv][h][2] = w0[h]; }
+      st_v[wv][h][0][lane] = db[h];
+      st_v[wv][h][1][lane] = ab[h];
+    }
+    __syncthreads();
+    const int h = wv;
+    float M = st_ml[0][h][0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) M = fmaxf(M, st_ml[w][h][0]);
+    float L = 0.f, W0 = 0.f;
+    f32x4 d = {0.f, 0.f, 0.f, 0.f}, a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float sc = __builtin_amdgcn_exp2f(st_ml[w][h][0] - M);     // a wave without tokens has m = -inf: weight 0
+      L += st_ml[w][h][1] * sc;
+      W0 += st_ml[w][h][2] * sc;
+      const f32x4 dv = st_v[w][h][0][lane], av = st_v[w][h][1][lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { d[c] += dv[c] * sc; a[c] += av[c] * sc; }
+    }
+    const float inv = 1.f / L;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { d[c] *= inv; a[c] *= inv; }
+    *reinterpret_cast<f32x4*>(out + h * POOLW + lane * 4) = d;
+    *reinterpret_cast<f32x4*>(out + h * POOLW + 256 + lane * 4) = a;
+    if (lane < 8) {  // [p_h0, 0 x 31]
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      if (lane == 0) z[0] = W0 * inv;
+      *reinterpret_cast<f32x4*>(out + h * POOLW + 512 + lane * 4) = z;
+    }
+    return;
+  }
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
     const float inv = 1.f / l[h];
