@@ -1163,13 +1163,29 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   const bool tok_mlp_ok = fused_mlp && h->precision == LINETR_PREC_BF16X6 && e0 == 32 && e1 == 64 && e2 == 128 && e3 == 256 &&
                           !LT_XENV("LINETR_NO_TOKMLP");
   const bool tok_mlp = tok_mlp_ok && rows >= tok_mlp_min_rows && st_of(h->wW2) && st_of(h->wW3) && st_of(h->wW4);
+  const bool line_mlp = tok_mlp_ok && N >= tok_mlp_min_rows && st_of(h->lW2) && st_of(h->lW3) && st_of(h->lW4);
+  TokMlpArgs amw, aml;
   if (tok_mlp) {
-    TokMlpArgs a;
-    a.p0 = ts.cpnt ? ts.cpnt : ts.pnt; a.p1 = ts.cpnt ? ts.cscore : ts.score; a.rows = rows; a.cx = cx; a.cy = cy; a.scale = scale;
-    a.W1 = h->wW1; a.b1 = h->wb1; a.W2st = st_of(h->wW2); a.b2 = h->wb2; a.W3st = st_of(h->wW3); a.b3 = h->wb3;
-    a.W4st = st_of(h->wW4); a.b4 = h->wb4; a.Y = w.a4; a.ldy = e3;
+    amw.p0 = ts.cpnt ? ts.cpnt : ts.pnt; amw.p1 = ts.cpnt ? ts.cscore : ts.score; amw.rows = rows; amw.cx = cx; amw.cy = cy; amw.scale = scale;
+    amw.W1 = h->wW1; amw.b1 = h->wb1; amw.W2st = st_of(h->wW2); amw.b2 = h->wb2; amw.W3st = st_of(h->wW3); amw.b3 = h->wb3;
+    amw.W4st = st_of(h->wW4); amw.b4 = h->wb4; amw.Y = w.a4; amw.ldy = e3;
+  }
+  if (line_mlp) {
+    aml.p0 = sublines; aml.p1 = resp; aml.p2 = angle_sub; aml.rows = N; aml.cx = cx; aml.cy = cy; aml.scale = scale;
+    aml.W1 = h->lW1; aml.b1 = h->lb1; aml.W2st = st_of(h->lW2); aml.b2 = h->lb2; aml.W3st = st_of(h->lW3); aml.b3 = h->lb3;
+    aml.W4st = st_of(h->lW4); aml.b4 = h->lb4; aml.Y = w.l4; aml.ldy = e3;
+  }
+  bool line_done = false;
+  if (tok_mlp && line_mlp && !ts.use_side && tok_mlp_dual_fits(rows, N) && !LT_XENV("LINETR_NO_DUAL_MLP")) {   // small batch: one launch
+    ProfScope ps(h, st, "pos_mlp_dual_bf16x6", 2.0 * rows * (3 * e0 + e0 * e1 + e1 * e2 + e2 * e3) + 2.0 * N * (5 * e0 + e0 * e1 + e1 * e2 + e2 * e3),
+                 (double)rows * (12 + 4 * e3) + (double)N * (28 + 4 * e3));
+    if ((e = tok_mlp_launch_dual(amw, aml, st))) return e;
+    line_done = true;
+  }
+  if (line_done) {
+  } else if (tok_mlp) {
     ProfScope ps(h, st, "tok_mlp_bf16x6", 2.0 * rows * (3 * e0 + e0 * e1 + e1 * e2 + e2 * e3), (double)rows * (12 + 4 * e3));
-    if ((e = tok_mlp_launch(a, true, st))) return e;
+    if ((e = tok_mlp_launch(amw, true, st))) return e;
   } else {
   if (fused_mlp) {   // layers 1-3 in one exact-fp32 MFMA kernel (lt_model.h)
     ProfScope ps(h, st, "mlp123", 2.0 * rows * (3 * e0 + e0 * e1 + e1 * e2), (double)rows * (12 + 4 * e2));
@@ -1192,14 +1208,10 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   }
   // ---- line positional encoder: independent of everything above -> side stream when available
   hipStream_t ls = ts.use_side ? h->side : st;
-  const bool line_mlp = tok_mlp_ok && N >= tok_mlp_min_rows && st_of(h->lW2) && st_of(h->lW3) && st_of(h->lW4);
-  if (line_mlp) {   // layers 1-4 in one kernel, as for the word encoder
-    TokMlpArgs a;
-    a.p0 = sublines; a.p1 = resp; a.p2 = angle_sub; a.rows = N; a.cx = cx; a.cy = cy; a.scale = scale;
-    a.W1 = h->lW1; a.b1 = h->lb1; a.W2st = st_of(h->lW2); a.b2 = h->lb2; a.W3st = st_of(h->lW3); a.b3 = h->lb3;
-    a.W4st = st_of(h->lW4); a.b4 = h->lb4; a.Y = w.l4; a.ldy = e3;
+  if (line_done) {
+  } else if (line_mlp) {   // layers 1-4 in one kernel, as for the word encoder
     ProfScope ps(h, ls, "line_mlp_bf16x6", 2.0 * N * (5 * e0 + e0 * e1 + e1 * e2 + e2 * e3), (double)N * (28 + 4 * e3));
-    if ((e = tok_mlp_launch(a, false, ls))) return e;
+    if ((e = tok_mlp_launch(aml, false, ls))) return e;
   } else {
   if (fused_mlp) {
     ProfScope ps(h, ls, "mlp123_line", 2.0 * N * (5 * e0 + e0 * e1 + e1 * e2), (double)N * (28 + 4 * e2));

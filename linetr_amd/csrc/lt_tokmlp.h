@@ -52,16 +52,16 @@ constexpr int TK_P_FLOATS = 32 * 8 + 64 + 128 + 256;        // W1 rows as [w0 ..
 constexpr int TK_LDS = TK_P + TK_P_FLOATS * 4;             // 150 272
 
 template <bool WORD>
-__global__ __launch_bounds__(512) void tok_mlp_kernel(TokMlpArgs a) {
+__device__ __forceinline__ void tok_mlp_body(const TokMlpArgs& a, const int block, const int nblocks) {
   constexpr int IN = WORD ? 3 : 5;
   extern __shared__ __attribute__((aligned(1024))) unsigned char tk_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h2 = lane >> 5, lq = lane & 31;
   const int ntiles = (int)((a.rows + TK_TM - 1) / TK_TM);
-  int tile = blockIdx.x;
+  int tile = block;
   if (tile >= ntiles) return;
-  const int step = gridDim.x;
+  const int step = nblocks;
   const int lfrag = ((lane >> 4) & 1) * ST_RB + (lane >> 5) * 256 + (lane & 15) * 16;
   float* prm = reinterpret_cast<float*>(tk_smem + TK_P);
 
@@ -253,6 +253,16 @@ __global__ __launch_bounds__(512) void tok_mlp_kernel(TokMlpArgs a) {
   for (int e = 0; e < 11; ++e) epi_step(acc1, prev_tile, 1, e);
 }
 
+template <bool WORD>
+__global__ __launch_bounds__(512) void tok_mlp_kernel(TokMlpArgs a) { tok_mlp_body<WORD>(a, blockIdx.x, gridDim.x); }
+
+// both encoders in one launch (small batches: the two sets of blocks fit the chip side by side, one launch and one weight prologue
+// less on the critical path of a single pair): blocks [0, word_blocks) run the word encoder, the rest the line encoder
+__global__ __launch_bounds__(512) void tok_mlp_dual_kernel(TokMlpArgs aw, TokMlpArgs al, int word_blocks) {
+  if ((int)blockIdx.x < word_blocks) tok_mlp_body<true>(aw, blockIdx.x, word_blocks);
+  else tok_mlp_body<false>(al, blockIdx.x - word_blocks, gridDim.x - word_blocks);
+}
+
 inline int tok_mlp_launch(const TokMlpArgs& a, bool word, hipStream_t st) {
   if (a.rows <= 0) return 0;
   if (!a.p0 || !a.p1 || (!word && !a.p2) || !a.W1 || !a.W2st || !a.W3st || !a.W4st || !a.b1 || !a.b2 || !a.b3 || !a.b4 || !a.Y || a.ldy % 4)
@@ -274,6 +284,31 @@ inline int tok_mlp_launch(const TokMlpArgs& a, bool word, hipStream_t st) {
   const dim3 grid((unsigned)std::min<int64_t>(ntiles, n_cu));
   if (word) hipLaunchKernelGGL(tok_mlp_kernel<true>, grid, dim3(512), TK_LDS, st, a);
   else hipLaunchKernelGGL(tok_mlp_kernel<false>, grid, dim3(512), TK_LDS, st, a);
+  LT_LAUNCH_CHECK();
+  return 0;
+}
+
+// both encoders side by side: only when their blocks (one per 64-row tile) fit the chip together
+inline bool tok_mlp_dual_fits(int64_t rows_word, int64_t rows_line) {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  return rows_word > 0 && rows_line > 0 && (rows_word + TK_TM - 1) / TK_TM + (rows_line + TK_TM - 1) / TK_TM <= n_cu;
+}
+inline int tok_mlp_launch_dual(const TokMlpArgs& aw, const TokMlpArgs& al, hipStream_t st) {
+  const int64_t tw = (aw.rows + TK_TM - 1) / TK_TM, tl = (al.rows + TK_TM - 1) / TK_TM;
+  if (!tok_mlp_dual_fits(aw.rows, al.rows)) return fail(LINETR_E_ARG, "tok_mlp: the two encoders do not fit one launch");
+  if (!aw.p0 || !aw.p1 || !al.p0 || !al.p1 || !al.p2 || !aw.Y || !al.Y || aw.ldy % 4 || al.ldy % 4) return fail(LINETR_E_ARG, "tok_mlp: missing operand");
+  static unsigned long long attr_done = 0;
+  const unsigned long long dev_bit = current_device_bit();
+  if (!(attr_done & dev_bit)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tok_mlp_dual_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TK_LDS);
+    attr_done |= dev_bit;
+  }
+  hipLaunchKernelGGL(tok_mlp_dual_kernel, dim3((unsigned)(tw + tl)), dim3(512), TK_LDS, st, aw, al, (int)tw);
   LT_LAUNCH_CHECK();
   return 0;
 }
