@@ -990,7 +990,7 @@ extern "C" int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int
     ProfScope ps(h, st, "tokenize", 0, (double)N * T * 16);
     hipLaunchKernelGGL(tokenize_kernel, dim3(N), dim3(64), 0, st, d_recs, s2l_g, N, td, T, height, width,
                        d_dense_score, out.sublines, out.pnt, out.mask, out.resp, out.angle_sub, out.score, (float*)nullptr,
-                       (float*)nullptr);
+                       (float*)nullptr, 0, (int64_t)0);
     LT_LAUNCH_CHECK();
   }
   if (out.desc) {
@@ -1545,10 +1545,10 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
   }
   {
     ProfScope ps(h, st, "tokenize", 0, (double)n_real * 16);
-    hipLaunchKernelGGL(tokenize_kernel, dim3(N), dim3(64), 0, st, d_recs, dw.s2l_g, N, td, T, height, width,
-                       d_dense_score, sublines, out.pnt, out.mask, resp, angle_sub, out.score, dw.cpnt, dw.cscore);
-    hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv(n_images, 256)), dim3(256), 0, st, d_dense_score, n_images, height,
-                       width, dw.cpnt, dw.cscore, n_real);
+    // (the last cdiv(n_images, 64) blocks write the per-image padding rows of the compact token list)
+    hipLaunchKernelGGL(tokenize_kernel, dim3(N + cdiv(n_images, 64)), dim3(64), 0, st, d_recs, dw.s2l_g, N, td, T, height, width,
+                       d_dense_score, sublines, out.pnt, out.mask, resp, angle_sub, out.score, dw.cpnt, dw.cscore, n_images,
+                       (int64_t)n_real);
     LT_LAUNCH_CHECK();
   }
   if (use_side) {

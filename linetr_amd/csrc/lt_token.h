@@ -105,10 +105,20 @@ __global__ __launch_bounds__(64) void tokenize_kernel(
     int height, int width, const float* __restrict__ dense_score, float* __restrict__ sublines,
     float* __restrict__ pnt, float* __restrict__ mask, float* __restrict__ resp,
     float* __restrict__ angle_sub, float* __restrict__ score, float* __restrict__ cpnt,
-    float* __restrict__ cscore) {
+    float* __restrict__ cscore, int n_pad_images, int64_t first_pad) {
 #pragma clang fp contract(off)
   const int n = blockIdx.x;
-  if (n >= N) return;
+  if (n >= N) {
+    // blocks past the sub-lines: one shared padding token per image for the compact token list -- coordinate (0, 0), score
+    // dense_score[img][0][0] (the reference pads with zeros and gathers the score at the rounded coordinate, line_process.py:174-179)
+    const int i = (n - N) * 64 + threadIdx.x;
+    if (i < n_pad_images) {
+      cpnt[(first_pad + i) * 2 + 0] = 0.f;
+      cpnt[(first_pad + i) * 2 + 1] = 0.f;
+      cscore[first_pad + i] = dense_score[(int64_t)i * height * width];
+    }
+    return;
+  }
   const LinetrLineRec r = recs[sub2line_g[n]];
   const int j = n - r.first_sub;  // sub-line index inside its key-line
   const double epc[2] = {fmin(r.ep[0], (double)width - 0.6), fmin(r.ep[1], (double)height - 0.6)};
@@ -309,16 +319,6 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(
   const f32x4 o = sample_one(pnt[tok * 2 + 0], pnt[tok * 2 + 1], nhwc + (int64_t)img * Hc * Wc * D, Hc, Wc,
                              align_corners, lane);
   *reinterpret_cast<f32x4*>(desc + tok * D + lane * 4) = o;
-}
-
-// one shared padding token per image for the compact token list: coordinate (0,0), score dense_score[img][0][0]
-__global__ void pad_rows_kernel(const float* __restrict__ dense_score, int n_images, int height, int width,
-                                float* __restrict__ cpnt, float* __restrict__ cscore, int64_t first_pad) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_images) return;
-  cpnt[(first_pad + i) * 2 + 0] = 0.f;
-  cpnt[(first_pad + i) * 2 + 1] = 0.f;
-  cscore[first_pad + i] = dense_score[(int64_t)i * height * width];
 }
 
 }  // namespace lt
