@@ -1244,7 +1244,9 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     constexpr bool two_pass = false;
 #endif
     if (!two_pass) {
-      ProfScope ps(h, st, "cls_pool_online", 2.0 * rows * (2.0 * HEADS * D * 2), (double)rows * D * 4 * 5);
+      // algorithmic bytes: the dense map once (or the four taps of every token, whichever is less), one a4 row per token, the pooled rows out
+      const double tap_bytes = std::min((double)n_images * ts.Hc * ts.Wc * D * 4, (double)rows * D * 4 * 4);
+      ProfScope ps(h, st, "cls_pool_online", 2.0 * rows * (2.0 * HEADS * D * 2), tap_bytes + (double)rows * D * 4 + (double)N * HEADS * POOLW * 4);
       // few sub-lines (a single pair): four waves per sub-line, so that the chip is covered and the token chain is a quarter as long
       if (N <= 2048 && !LT_XENV("LINETR_POOL_NO_SPLIT"))
         hipLaunchKernelGGL(cls_pool_online_kernel<4>, dim3(N), dim3(256), 0, st, ts.recs, ts.sub2line_g, ts.cpnt,
