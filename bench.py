@@ -313,6 +313,7 @@ PMC_KERNEL_NAMES = {   # profile class -> kernel symbol prefix in profiles/<tag>
     "gemm_bf16x6_ws64x256": "void lt::gemm_ws_kernel<0>",
     "tok_mlp_bf16x6": "void lt::tok_mlp_kernel<true>",
     "line_mlp_bf16x6": "void lt::tok_mlp_kernel<false>",
+    "pos_mlp_dual_bf16x6": "lt::tok_mlp_",          # tok_mlp_seq_kernel (large batch) / tok_mlp_dual_kernel (single pair)
     "gemm_bf16x6_64x64": "void lt::gemm_split_kernel<64, 64, 2, 2, 3, true, 0",
     "gemm_bf16x6_64x128": "void lt::gemm_split_kernel<64, 128, 2, 2, 3, true, 0",
     "gemm_bf16x6_32x32k4": "void lt::gemm_split_small_kernel<3, 0",

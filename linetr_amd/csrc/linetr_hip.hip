@@ -1176,7 +1176,8 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     aml.W4st = st_of(h->lW4); aml.b4 = h->lb4; aml.Y = w.l4; aml.ldy = e3;
   }
   bool line_done = false;
-  if (tok_mlp && line_mlp && !ts.use_side && tok_mlp_dual_fits(rows, N) && !LT_XENV("LINETR_NO_DUAL_MLP")) {   // small batch: one launch
+  // both encoders in ONE launch: side by side for a small batch, one after the other inside every persistent block for a large one
+  if (tok_mlp && line_mlp && !ts.use_side && rows > 0 && N > 0 && !LT_XENV("LINETR_NO_DUAL_MLP")) {
     ProfScope ps(h, st, "pos_mlp_dual_bf16x6", 2.0 * rows * (3 * e0 + e0 * e1 + e1 * e2 + e2 * e3) + 2.0 * N * (5 * e0 + e0 * e1 + e1 * e2 + e2 * e3),
                  (double)rows * (12 + 4 * e3) + (double)N * (28 + 4 * e3));
     if ((e = tok_mlp_launch_dual(amw, aml, st))) return e;

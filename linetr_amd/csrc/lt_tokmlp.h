@@ -288,6 +288,14 @@ inline int tok_mlp_launch(const TokMlpArgs& a, bool word, hipStream_t st) {
   return 0;
 }
 
+// large batches: every persistent block walks its share of the word encoder's tiles, then its share of the line encoder's (one launch
+// instead of two; the second weight prologue costs a block ~4 us, a separate launch of the line encoder 29 us at cfg3)
+__global__ __launch_bounds__(512) void tok_mlp_seq_kernel(TokMlpArgs aw, TokMlpArgs al) {
+  tok_mlp_body<true>(aw, blockIdx.x, gridDim.x);
+  __syncthreads();                                         // the line encoder's weights replace the word encoder's in LDS
+  tok_mlp_body<false>(al, blockIdx.x, gridDim.x);
+}
+
 // both encoders side by side: only when their blocks (one per 64-row tile) fit the chip together
 inline bool tok_mlp_dual_fits(int64_t rows_word, int64_t rows_line) {
   static int n_cu = 0;
@@ -298,17 +306,27 @@ inline bool tok_mlp_dual_fits(int64_t rows_word, int64_t rows_line) {
   }
   return rows_word > 0 && rows_line > 0 && (rows_word + TK_TM - 1) / TK_TM + (rows_line + TK_TM - 1) / TK_TM <= n_cu;
 }
+// one launch for both encoders: side by side when the blocks fit the chip, otherwise one after the other inside every block
 inline int tok_mlp_launch_dual(const TokMlpArgs& aw, const TokMlpArgs& al, hipStream_t st) {
   const int64_t tw = (aw.rows + TK_TM - 1) / TK_TM, tl = (al.rows + TK_TM - 1) / TK_TM;
-  if (!tok_mlp_dual_fits(aw.rows, al.rows)) return fail(LINETR_E_ARG, "tok_mlp: the two encoders do not fit one launch");
+  if (aw.rows <= 0 || al.rows <= 0) return fail(LINETR_E_ARG, "tok_mlp: empty encoder input");
   if (!aw.p0 || !aw.p1 || !al.p0 || !al.p1 || !al.p2 || !aw.Y || !al.Y || aw.ldy % 4 || al.ldy % 4) return fail(LINETR_E_ARG, "tok_mlp: missing operand");
   static unsigned long long attr_done = 0;
   const unsigned long long dev_bit = current_device_bit();
   if (!(attr_done & dev_bit)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tok_mlp_dual_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TK_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tok_mlp_seq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TK_LDS);
     attr_done |= dev_bit;
   }
-  hipLaunchKernelGGL(tok_mlp_dual_kernel, dim3((unsigned)(tw + tl)), dim3(512), TK_LDS, st, aw, al, (int)tw);
+  if (tok_mlp_dual_fits(aw.rows, al.rows)) {
+    hipLaunchKernelGGL(tok_mlp_dual_kernel, dim3((unsigned)(tw + tl)), dim3(512), TK_LDS, st, aw, al, (int)tw);
+  } else {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    static int n_cu = 0;
+    if (!n_cu) n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    hipLaunchKernelGGL(tok_mlp_seq_kernel, dim3((unsigned)std::min<int64_t>(std::max(tw, tl), n_cu)), dim3(512), TK_LDS, st, aw, al);
+  }
   LT_LAUNCH_CHECK();
   return 0;
 }

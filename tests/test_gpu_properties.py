@@ -146,7 +146,7 @@ def test_precision_modes_agree(eng):
 def test_cfg3_step_runs_on_the_intended_kernels(eng):
     """Dispatcher guard (HIP-event profile classes of one cfg3 forward): the 17 K >= 256 / N = 256 GEMMs on the pipelined
     128x256 tile with the three row normalisations fused into their epilogues, the FFN's w_1 on the eight-wave 128x128 tile,
-    the word and the line encoder's four MLP layers in one kernel each, the seven q/k/v projections inside the fused projection + attention kernel, pooling on its
+    the word and the line encoder's four MLP layers in one launch, the seven q/k/v projections inside the fused projection + attention kernel, pooling on its
     one-pass kernel, nothing on a fallback tile.  (A
     dispatcher rule lost in an edit once moved the 18 launches to the 64x256 tile: correct results, 12 % slower step.)"""
     _, cat, off, dd, ds = batch_inputs(128)
@@ -161,8 +161,8 @@ def test_cfg3_step_runs_on_the_intended_kernels(eng):
         eng.set_profiling(False)
     assert prof.get("gemm_bf16x6_128x256") == 17, prof
     assert prof.get("gemm_bf16x6_128x128s") == 1, prof                                              # the FFN's w_1
-    # both positional encoders: layers 1-4 in one kernel each
-    assert prof.get("tok_mlp_bf16x6") == 1 and prof.get("line_mlp_bf16x6") == 1 and "mlp123" not in prof and "mlp123_line" not in prof, prof
+    # both positional encoders: layers 1-4 of both in ONE launch (every persistent block walks word tiles, then line tiles)
+    assert prof.get("pos_mlp_dual_bf16x6") == 1 and not [k for k in prof if k.startswith("mlp123") or k in ("tok_mlp_bf16x6", "line_mlp_bf16x6")], prof
     assert prof.get("sig_qkv_attn_bf16x6") == 7 and "sig_attn_bf16x6" not in prof and prof.get("cls_pool_online") == 1, prof
     assert "row_norm" not in prof, prof
     assert not [k for k in prof if k.startswith("gemm_") and k not in ("gemm_bf16x6_128x256", "gemm_bf16x6_128x128s", "gemm_bf16x6_128x64",
