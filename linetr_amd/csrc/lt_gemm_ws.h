@@ -16,6 +16,8 @@
 // 187 us.  Ablations: no MFMAs 96 us (the memory side alone: the kernel sits 15 % above it), no loads and no stores 92 us (MFMAs + LDS
 // fragment reads: eight waves each read the whole tile, 50 % of the LDS read bandwidth), neither 31 us.  Plain stores: write-through
 // (sc1) or nontemporal ones double the time (a wave writes 32-byte runs; the L2 has to merge them into lines).
+// Since lt_tokmlp.h runs all four MLP layers of both positional encoders in one kernel (its layer-4 stage IS this kernel's slot loop),
+// this GEMM is the stand-alone form: taken when the one-kernel MLP does not apply (non-reference channel widths) and by the unit tests.
 #pragma once
 #include "lt_gemm_st.h"
 
