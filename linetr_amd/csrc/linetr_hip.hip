@@ -834,8 +834,8 @@ static int pack_one(LinetrLineRec& r, double td, int T, int image, int line_loca
 static void angle_of(LinetrLineRec& r) {  // line_process.py:28-41
   double th = std::atan2(r.ep[0] - r.sp[0], r.ep[1] - r.sp[1]);
   if (th < 0) th += M_PI;
-  r.angle[0] = std::cos(2 * th);
-  r.angle[1] = std::sin(2 * th);
+  // one libm call for both (glibc's sincos returns exactly what its sin and cos return)
+  ::sincos(2 * th, &r.angle[1], &r.angle[0]);
 }
 
 extern "C" int linetr_pack_lines(const double* h_klines, const double* h_length, const double* h_angles, int32_t K,
@@ -855,19 +855,27 @@ extern "C" int linetr_pack_lines(const double* h_klines, const double* h_length,
   return LINETR_OK;
 }
 
-// filter + sort of one image into `out` (records carry geometry/length/angle only)
+// filter + sort of one image (records carry geometry/length/angle only).  `emit(n)` is called once with the number of surviving
+// lines and returns where to write them: straight into the caller's record array on the single-thread path (a record is 80 bytes;
+// the earlier form copied every survivor three times).
+struct KeptLine { double sp[2], ep[2], length; };
+template <class Emit>
 static void prefilter_core(const double* L, int32_t K, int32_t height, int32_t width, int32_t border,
-                           double min_length, int32_t max_keylines, const double* vm, std::vector<LinetrLineRec>& out) {
-  std::vector<LinetrLineRec> keep;
+                           double min_length, int32_t max_keylines, const double* vm, Emit emit) {
+  static thread_local std::vector<KeptLine> keep;
+  static thread_local std::vector<std::pair<double, int>> order;
+  keep.clear();
   keep.reserve(K);
   const double xmax = ((double)width - 0.001) - (double)border;   // width-eps-border, line_process.py:72-74
   const double ymax = ((double)height - 0.001) - (double)border;
   for (int k = 0; k < K; ++k) {
     const double* l = L + (size_t)k * 6;
-    LinetrLineRec r{};
+    KeptLine r;
     if (l[0] < l[2]) { r.sp[0] = l[0]; r.sp[1] = l[1]; r.ep[0] = l[2]; r.ep[1] = l[3]; }   // :212-217
     else { r.sp[0] = l[2]; r.sp[1] = l[3]; r.ep[0] = l[0]; r.ep[1] = l[1]; }
-    r.length = l[4] * std::pow(2.0, l[5]);                                                   // :220
+    // lineLength * 2 ** octave (:220); an integral octave is an exact power of two either way: skip the pow call
+    const double oct = l[5];
+    r.length = (oct == std::floor(oct) && std::fabs(oct) < 64.0) ? l[4] * std::ldexp(1.0, (int)oct) : l[4] * std::pow(2.0, oct);
     const bool inside = r.sp[0] >= border && r.sp[0] < width - border && r.sp[1] >= border && r.sp[1] < height - border &&
                         r.ep[0] >= border && r.ep[0] < width - border && r.ep[1] >= border && r.ep[1] < height - border;
     if (!inside) continue;                                                                   // :62-70
@@ -886,17 +894,21 @@ static void prefilter_core(const double* L, int32_t K, int32_t height, int32_t w
     if (!(r.length > min_length)) continue;                                                  // :8
     keep.push_back(r);
   }
-  std::vector<int> idx(keep.size());
-  std::iota(idx.begin(), idx.end(), 0);
-  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return keep[a].length < keep[b].length; });
-  std::reverse(idx.begin(), idx.end());                                                      // :15-16
-  int64_t n_keep = (int64_t)idx.size();
+  // ascending stable order by length, read backwards (:15-16): ties come out in descending input order, as before
+  order.resize(keep.size());
+  for (size_t i = 0; i < keep.size(); ++i) order[i] = {keep[i].length, (int)i};
+  std::stable_sort(order.begin(), order.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
+  int64_t n_keep = (int64_t)order.size();
   if (max_keylines < 0) n_keep = std::max<int64_t>(0, n_keep + max_keylines);                // python slice [:m]
   else n_keep = std::min<int64_t>(n_keep, max_keylines);
-  out.resize(n_keep);
+  LinetrLineRec* out = emit(n_keep);
+  if (!out) return;
   for (int64_t i = 0; i < n_keep; ++i) {
-    out[i] = keep[idx[i]];
-    angle_of(out[i]);                                                                        // :20
+    const KeptLine& kl = keep[order[order.size() - 1 - i].second];
+    LinetrLineRec r{};
+    r.sp[0] = kl.sp[0]; r.sp[1] = kl.sp[1]; r.ep[0] = kl.ep[0]; r.ep[1] = kl.ep[1]; r.length = kl.length;
+    angle_of(r);                                                                             // :20
+    out[i] = r;
   }
 }
 
@@ -905,16 +917,16 @@ extern "C" int linetr_prefilter(const double* L, int32_t K, int32_t height, int3
                                 int32_t image_index, int32_t sub_base, int32_t tok_base, LinetrLineRec* h_recs,
                                 int32_t capacity, int32_t* k_out, int32_t* n_out) {
   if (K < 0 || (K > 0 && !L) || !k_out || !n_out) return fail(LINETR_E_ARG, "null argument");
-  std::vector<LinetrLineRec> sel;
-  prefilter_core(L, K, height, width, border, min_length, max_keylines, vm, sel);
-  if ((int64_t)sel.size() > capacity)
-    return fail(LINETR_E_CAPACITY, "prefilter: %lld lines exceed capacity %d", (long long)sel.size(), capacity);
+  int64_t n_sel = -1;
+  prefilter_core(L, K, height, width, border, min_length, max_keylines, vm, [&](int64_t n) -> LinetrLineRec* {
+    n_sel = n;
+    return n <= capacity ? h_recs : nullptr;
+  });
+  if (n_sel > capacity) return fail(LINETR_E_CAPACITY, "prefilter: %lld lines exceed capacity %d", (long long)n_sel, capacity);
   int cur = sub_base, tcur = tok_base;
-  for (size_t i = 0; i < sel.size(); ++i) {
-    if (int e = pack_one(sel[i], td, T, image_index, (int)i, cur, tcur)) return e;
-    h_recs[i] = sel[i];
-  }
-  *k_out = (int)sel.size();
+  for (int64_t i = 0; i < n_sel; ++i)
+    if (int e = pack_one(h_recs[i], td, T, image_index, (int)i, cur, tcur)) return e;
+  *k_out = (int)n_sel;
   *n_out = cur - sub_base;
   return LINETR_OK;
 }
@@ -924,23 +936,43 @@ extern "C" int linetr_prefilter_batch(const double* L, const int32_t* off, int32
                                       const double* const* vms, double td, int32_t T, int32_t n_threads,
                                       LinetrLineRec* h_recs, int32_t capacity, int32_t* cu_k, int32_t* cu_n) {
   if (B < 0 || !off || !cu_k || !cu_n || (B > 0 && off[B] > 0 && !L)) return fail(LINETR_E_ARG, "null argument");
-  std::vector<std::vector<LinetrLineRec>> sel(B);
   WorkPool& pool = WorkPool::get();
   int nt = n_threads > 0 ? n_threads : pool.size();
   nt = std::max(1, std::min(nt, B / 4));  // not worth a hand-off for fewer than 4 images per chunk
   // contiguous chunks of images, a few per thread so that uneven images balance out
   const int chunks = nt == 1 ? 1 : std::min(B, nt * 2);
+  cu_k[0] = cu_n[0] = 0;
+  int cur = 0, tcur = 0;
+  int64_t k = 0;
+  if (chunks == 1) {
+    // a single pair / a few images: no hand-off, and the survivors are written where they stay
+    for (int i = 0; i < B; ++i) {
+      int64_t n_sel = -1;
+      prefilter_core(L + (size_t)off[i] * 6, off[i + 1] - off[i], height, width, border, min_length, max_keylines,
+                     vms ? vms[i] : nullptr, [&](int64_t n) -> LinetrLineRec* {
+                       n_sel = n;
+                       return k + n <= capacity ? h_recs + k : nullptr;
+                     });
+      if (k + n_sel > capacity) return fail(LINETR_E_CAPACITY, "prefilter_batch: more than %d surviving lines", capacity);
+      for (int64_t j = 0; j < n_sel; ++j)
+        if (int e = pack_one(h_recs[k + j], td, T, i, (int)j, cur, tcur)) return e;
+      k += n_sel;
+      cu_k[i + 1] = (int)k;
+      cu_n[i + 1] = cur;
+    }
+    return LINETR_OK;
+  }
+  std::vector<std::vector<LinetrLineRec>> sel(B);
   auto work = [&](int c) {
     const int i0 = (int)((int64_t)B * c / chunks), i1 = (int)((int64_t)B * (c + 1) / chunks);
     for (int i = i0; i < i1; ++i)
       prefilter_core(L + (size_t)off[i] * 6, off[i + 1] - off[i], height, width, border, min_length, max_keylines,
-                     vms ? vms[i] : nullptr, sel[i]);
+                     vms ? vms[i] : nullptr, [&](int64_t n) -> LinetrLineRec* {
+                       sel[i].resize(n);
+                       return sel[i].data();
+                     });
   };
-  if (chunks == 1) work(0);
-  else pool.run(chunks, work);
-  cu_k[0] = cu_n[0] = 0;
-  int cur = 0, tcur = 0;
-  int64_t k = 0;
+  pool.run(chunks, work);
   for (int i = 0; i < B; ++i) {
     if (k + (int64_t)sel[i].size() > capacity)
       return fail(LINETR_E_CAPACITY, "prefilter_batch: more than %d surviving lines", capacity);
