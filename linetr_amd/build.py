@@ -1,7 +1,9 @@
-"""Build the gfx950 shared library in-tree:  python -m linetr_amd.build [--force]
+"""Build the gfx950 shared library in-tree:  python -m linetr_amd.build [--force] [--experiments | --all]
 
-hipcc cross-compiles for gfx950 without a GPU present; the resulting
-linetr_amd/csrc/liblinetr_hip.so travels to the GPU box with the repo snapshot."""
+hipcc cross-compiles for gfx950 without a GPU present; the resulting linetr_amd/csrc/liblinetr_hip.so travels to the
+GPU box with the repo snapshot.  The library is a handful of translation units (csrc/linetr_*.hip, see lt_handle.h);
+each is compiled to an object under csrc/build/ (in parallel, re-compiled only when one of the files it includes
+changed: hipcc's -MD dependency files) and the objects are linked into the .so."""
 from __future__ import annotations
 
 import glob
@@ -9,12 +11,15 @@ import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 OUT = os.path.join(CSRC, "liblinetr_hip.so")
 OUT_X = os.path.join(CSRC, "liblinetr_hip_experiments.so")     # same sources, -DLINETR_EXPERIMENTS (tools/, experiment tests)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+LFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]
 
 
 def _hipcc():
@@ -24,9 +29,36 @@ def _hipcc():
     raise RuntimeError("hipcc not found (ROCm toolchain required)")
 
 
+def units():
+    return sorted(glob.glob(os.path.join(CSRC, "linetr_*.hip")))
+
+
 def sources():
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) +
-                  [os.path.join(HERE, "..", "include", "linetr_hip.h")])
+    return sorted(units() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "linetr_hip.h")])
+
+
+def _deps(dfile):
+    """prerequisites listed in a make-style dependency file"""
+    try:
+        txt = open(dfile).read()
+    except OSError:
+        return None
+    txt = txt.replace("\\\n", " ")
+    return [t for t in txt.split(":", 1)[1].split() if t] if ":" in txt else None
+
+
+def _object_stale(obj, dfile):
+    if not os.path.exists(obj):
+        return True
+    deps = _deps(dfile)
+    if deps is None:
+        return True
+    t = os.path.getmtime(obj)
+    for d in deps:
+        p = d if os.path.isabs(d) else os.path.join(CSRC, d)
+        if not os.path.exists(p) or os.path.getmtime(p) > t:
+            return True
+    return False
 
 
 def up_to_date(out=OUT) -> bool:
@@ -42,10 +74,27 @@ def build(force: bool = False, verbose: bool = True, experiments: bool = False) 
     out = OUT_X if experiments else OUT
     if not force and up_to_date(out):
         return out
-    cmd = [_hipcc(), *FLAGS, *(["-DLINETR_EXPERIMENTS"] if experiments else []), "-o", out, os.path.join(CSRC, "linetr_hip.hip")]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    tag = "x" if experiments else "p"
+    defs = ["-DLINETR_EXPERIMENTS"] if experiments else []
+    jobs, objs = [], []
+    for src in units():
+        stem = os.path.splitext(os.path.basename(src))[0]
+        obj = os.path.join(OBJ, f"{stem}.{tag}.o")
+        dfile = obj[:-2] + ".d"
+        objs.append(obj)
+        if force or _object_stale(obj, dfile):
+            jobs.append([hipcc, *CFLAGS, *defs, "-MD", "-MF", dfile, "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, *LFLAGS, "-o", out, *objs])
     return out
 
 

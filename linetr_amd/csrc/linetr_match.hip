@@ -1,0 +1,265 @@
+// liblinetr_hip.so, translation unit 3 of 4: the descriptor-distance matcher, the dense-map producer and the slab packing of the
+// multi-GPU path (C ABI in include/linetr_hip.h; kernels in lt_match.h, lt_producer.h).
+#include <algorithm>
+#include <numeric>
+
+#include "lt_handle.h"
+#include "lt_match.h"
+#include "lt_producer.h"
+
+using namespace lt;
+
+// =============================================================================================
+// matcher
+// =============================================================================================
+
+namespace {
+// Pinned staging ring for the small host tables the matcher uploads (PairDesc array, identity maps).  A slot is
+// reused only after the copy that read it has completed (event), so no entry point has to synchronise the stream.
+struct PinnedRing {
+  struct Slot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; };
+  Slot slots[8];
+  int next = 0;
+  std::mutex m;
+  // returns a host pointer of >= bytes, or nullptr; *slot_out identifies the slot for commit()
+  void* acquire(size_t bytes, int* slot_out) {
+    std::lock_guard<std::mutex> lk(m);
+    Slot& s = slots[next];
+    *slot_out = next;
+    next = (next + 1) % 8;
+    if (s.busy) { (void)hipEventSynchronize(s.ev); s.busy = false; }
+    if (s.cap < bytes) {
+      if (s.p) (void)hipHostFree(s.p);
+      s.p = nullptr; s.cap = 0;
+      const size_t cap = std::max<size_t>(align_up((int64_t)bytes * 2, 4096), 16384);
+      if (hipHostMalloc(&s.p, cap, hipHostMallocDefault) != hipSuccess) { s.p = nullptr; return nullptr; }
+      s.cap = cap;
+    }
+    if (!s.ev && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { s.ev = nullptr; return nullptr; }
+    return s.p;
+  }
+  int commit(int slot, hipStream_t st) {   // call after the last async copy out of the slot has been enqueued
+    std::lock_guard<std::mutex> lk(m);
+    LT_HIP(hipEventRecord(slots[slot].ev, st));
+    slots[slot].busy = true;
+    return 0;
+  }
+};
+PinnedRing& staging_ring() {   // one ring per device (its events belong to the device current at creation); leaked: see WorkPool
+  static PinnedRing* rings[64] = {};
+  static std::mutex m;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(m);
+  PinnedRing*& r = rings[dev & 63];
+  if (!r) r = new PinnedRing();
+  return *r;
+}
+
+// ints of argmin scratch one pair needs (layout in lt_match.h)
+int64_t pair_scratch_ints(int k0, int k1) { return 2 * (int64_t)k0 + 2 * (int64_t)k1 + 1 + 2 * (int64_t)cdiv(std::max(k0, 1), PM_ROWS) * k1 + 8; }
+}  // namespace
+
+extern "C" int64_t linetr_match_workspace_bytes(int32_t n_pairs, int64_t sum_n0n1, int64_t sum_k0k1, int64_t sum_k) {
+  (void)sum_k0k1;
+  // scratch bound: sum over pairs of pair_scratch_ints(k0,k1) <= 4 sum_k + 2 (sum_k0k1 / PM_ROWS + sum_k) + 9 P, and
+  // k0 k1 <= n0 n1
+  const int64_t scratch = 6 * sum_k + 2 * (sum_n0n1 / PM_ROWS + 1) + 9 * (int64_t)n_pairs;
+  return align_up((int64_t)n_pairs * sizeof(PairDesc), 256) + align_up(sum_n0n1 * 4, 256) + align_up(scratch * 4, 256) + 256;
+}
+
+extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* dims, const float* d_desc0,
+                                     const int64_t* off_n0, const int32_t* d_s2l0, const int64_t* off_s0,
+                                     const float* d_desc1, const int64_t* off_n1, const int32_t* d_s2l1,
+                                     const int64_t* off_s1, float thr, int32_t mutual, float* d_dk, const int64_t* off_dk,
+                                     int32_t* d_match01, const int64_t* off_k0, void* d_ws, int64_t ws_bytes, void* stream);
+
+extern "C" int linetr_match(LinetrHandle* h, int32_t P, const int32_t* dims, const float* d_desc0, const int64_t* off_n0,
+                            const int32_t* d_s2l0, const float* d_desc1, const int64_t* off_n1, const int32_t* d_s2l1,
+                            float thr, int32_t mutual, float* d_dk, const int64_t* off_dk, int32_t* d_match01,
+                            const int64_t* off_k0, void* d_ws, int64_t ws_bytes, void* stream) {
+  return linetr_match_gathered(h, P, dims, d_desc0, off_n0, d_s2l0, nullptr, d_desc1, off_n1, d_s2l1, nullptr, thr, mutual,
+                               d_dk, off_dk, d_match01, off_k0, d_ws, ws_bytes, stream);
+}
+
+extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* dims, const float* d_desc0,
+                                     const int64_t* off_n0, const int32_t* d_s2l0, const int64_t* off_s0,
+                                     const float* d_desc1, const int64_t* off_n1, const int32_t* d_s2l1,
+                                     const int64_t* off_s1, float thr, int32_t mutual, float* d_dk, const int64_t* off_dk,
+                                     int32_t* d_match01, const int64_t* off_k0, void* d_ws, int64_t ws_bytes, void* stream) {
+  if (P < 0) return fail(LINETR_E_ARG, "match: bad argument");
+  if (P == 0) return LINETR_OK;
+  if (!dims || !off_n0 || !off_n1 || !off_dk || !off_k0 || !d_ws) return fail(LINETR_E_ARG, "match: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (h) LT_HIP(hipSetDevice(h->device));
+  PairTable tab{};
+  int slot = -1;
+  PairDesc* pd = tab.inl;
+  if (P > PT_INLINE) {
+    pd = (PairDesc*)staging_ring().acquire((size_t)P * sizeof(PairDesc), &slot);
+    if (!pd) return fail(LINETR_E_HIP, "match: pinned staging allocation failed");
+  } else {
+    tab.n_inline = P;
+  }
+  int64_t od = 0, os = 0, sum_k = 0;
+  int max_n0 = 0, max_n1 = 0, max_k1 = 0, max_chunks = 0;
+  double flops = 0;
+  for (int p = 0; p < P; ++p) {
+    PairDesc& d = pd[p];
+    d.n0 = dims[p * 4 + 0]; d.k0 = dims[p * 4 + 1]; d.n1 = dims[p * 4 + 2]; d.k1 = dims[p * 4 + 3];
+    if (d.n0 < 0 || d.n1 < 0 || d.k0 < 0 || d.k1 < 0 || d.k0 > d.n0 || d.k1 > d.n1)
+      return fail(LINETR_E_ARG, "match: bad dims for pair %d", p);
+    d.off_n0 = off_n0[p]; d.off_n1 = off_n1[p]; d.off_dk = off_dk[p]; d.off_k0 = off_k0[p];
+    d.off_s0 = off_s0 ? off_s0[p] : off_n0[p];
+    d.off_s1 = off_s1 ? off_s1[p] : off_n1[p];
+    d.off_d = od; od += (int64_t)d.n0 * d.n1;
+    d.chunks = cdiv(std::max(d.k0, 1), PM_ROWS);
+    d.pad_ = 0;
+    d.off_seg = os; os += pair_scratch_ints(d.k0, d.k1);
+    sum_k += d.k0 + d.k1;
+    max_n0 = std::max(max_n0, d.n0); max_n1 = std::max(max_n1, d.n1);
+    max_k1 = std::max(max_k1, d.k1); max_chunks = std::max(max_chunks, d.chunks);
+    flops += 2.0 * d.n0 * d.n1 * D;
+  }
+  if (ws_bytes < linetr_match_workspace_bytes(P, od, 0, sum_k)) return fail(LINETR_E_WORKSPACE, "match: workspace too small");
+  char* base = (char*)d_ws;
+  PairDesc* d_pd = (PairDesc*)base;
+  float* d_dist = (float*)(base + align_up((int64_t)P * sizeof(PairDesc), 256));
+  int* d_scr = (int*)((char*)d_dist + align_up(od * 4, 256));
+  if (slot >= 0) {
+    LT_HIP(hipMemcpyAsync(d_pd, pd, P * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+    if (int e = staging_ring().commit(slot, st)) return e;
+    tab.ptr = d_pd;
+  }
+  if (max_n0 > 0 && max_n1 > 0) {
+    if (!d_desc0 || !d_desc1 || !d_s2l0 || !d_s2l1 || !d_dk) return fail(LINETR_E_ARG, "match: null tensor");
+    // (r03: one fused launch for a single pair -- every block computing its own strip of D, pooling it, the last
+    // arriver finishing -- was built and measured at 0.10 ms submit-to-done against 0.08 ms for these three launches: 13
+    // blocks walking 4 column tiles x 8 K steps of exposed load latency each lose to 16 + 13 + 1 blocks in parallel.)
+    ProfScope ps(h, st, "pair_dist", flops, 0);
+    hipLaunchKernelGGL(pair_dist_kernel, dim3(cdiv(max_n1, 64), cdiv(max_n0, 64), P), dim3(256), 0, st, tab, d_desc0,
+                       d_desc1, d_dist);
+    LT_LAUNCH_CHECK();
+  }
+  {
+    ProfScope ps(h, st, "pair_match", 0, 0);
+    if (max_k1 > 0) {
+      const int seg1_global = max_k1 > PM_MAX_K1;    // the reference has no limit (max_keylines / max_keypoints = -1)
+      hipLaunchKernelGGL(pair_pool_kernel, dim3(max_chunks, P), dim3(256),
+                         (size_t)((seg1_global ? 0 : max_k1) + PM_ROWS + 2) * sizeof(int), st, tab, d_s2l0, d_s2l1, d_dist, d_dk,
+                         d_scr, seg1_global);
+      LT_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(pair_final_kernel, dim3(P), dim3(256), 0, st, tab, thr, mutual, d_match01, d_scr);
+    LT_LAUNCH_CHECK();
+  }
+  return LINETR_OK;   // fully asynchronous: the pair table travels in the kernel arguments or in ring-owned pinned memory
+}
+
+extern "C" int linetr_match_points(LinetrHandle* h, const float* d0_cn, int32_t n0, const float* d1_cn, int32_t n1,
+                                   float thr, int32_t mutual, float* d_dist, int32_t* d_match01, void* d_ws,
+                                   int64_t ws_bytes, void* stream) {
+  if (n0 < 0 || n1 < 0) return fail(LINETR_E_ARG, "match_points: bad argument");
+  if (n0 == 0) return LINETR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (h) LT_HIP(hipSetDevice(h->device));
+  // scratch: row-major copies + identity sub2line maps + the generic matcher's workspace
+  const int64_t need_t = align_up((int64_t)n0 * D * 4, 256) + align_up((int64_t)std::max(n1, 1) * D * 4, 256) +
+                         align_up((int64_t)n0 * 4, 256) + align_up((int64_t)std::max(n1, 1) * 4, 256);
+  const int64_t need_m = linetr_match_workspace_bytes(1, (int64_t)n0 * n1, 0, n0 + n1);
+  if (ws_bytes < need_t + need_m) return fail(LINETR_E_WORKSPACE, "match_points: workspace too small (need %lld)", (long long)(need_t + need_m));
+  char* base = (char*)d_ws;
+  float* r0 = (float*)base; base += align_up((int64_t)n0 * D * 4, 256);
+  float* r1 = (float*)base; base += align_up((int64_t)std::max(n1, 1) * D * 4, 256);
+  int* id0 = (int*)base; base += align_up((int64_t)n0 * 4, 256);
+  int* id1 = (int*)base; base += align_up((int64_t)std::max(n1, 1) * 4, 256);
+  {
+    int slot = 0;
+    const int m = std::max(n0, n1);
+    int* iota = (int*)staging_ring().acquire((size_t)m * sizeof(int), &slot);
+    if (!iota) return fail(LINETR_E_HIP, "match_points: pinned staging allocation failed");
+    std::iota(iota, iota + m, 0);
+    LT_HIP(hipMemcpyAsync(id0, iota, n0 * 4, hipMemcpyHostToDevice, st));
+    if (n1 > 0) LT_HIP(hipMemcpyAsync(id1, iota, n1 * 4, hipMemcpyHostToDevice, st));
+    if (int e = staging_ring().commit(slot, st)) return e;
+  }
+  hipLaunchKernelGGL(transpose_cn_kernel, dim3(cdiv(n0, 32), D / 32), dim3(32, 8), 0, st, d0_cn, r0, D, n0);
+  if (n1 > 0) hipLaunchKernelGGL(transpose_cn_kernel, dim3(cdiv(n1, 32), D / 32), dim3(32, 8), 0, st, d1_cn, r1, D, n1);
+  LT_LAUNCH_CHECK();
+  const int32_t dims[4] = {n0, n0, n1, n1};
+  const int64_t zero = 0;
+  return linetr_match(h, 1, dims, r0, &zero, id0, r1, &zero, id1, thr, mutual, d_dist, &zero, d_match01, &zero, base,
+                      ws_bytes - need_t, stream);
+}
+
+extern "C" int64_t linetr_match_distmat_workspace_bytes(int32_t n0, int32_t n1) {
+  n0 = std::max(n0, 0); n1 = std::max(n1, 0);
+  return 256 + align_up((int64_t)n0 * 4, 256) + align_up((int64_t)std::max(n1, 1) * 4, 256) +
+         align_up((int64_t)n0 * std::max(n1, 1) * 4, 256) + align_up(pair_scratch_ints(n0, n1) * 4, 256);
+}
+
+extern "C" int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_t n0, int32_t n1, float thr,
+                                    int32_t mutual, int32_t* d_match01, void* d_ws, int64_t ws_bytes, void* stream) {
+  if (n0 < 0 || n1 < 0) return fail(LINETR_E_ARG, "match_distmat: bad argument");
+  if (n0 == 0) return LINETR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (h) LT_HIP(hipSetDevice(h->device));
+  // scratch: PairDesc | identity maps | Dk copy | argmin ints
+  const int64_t o_id0 = 256, o_id1 = o_id0 + align_up((int64_t)n0 * 4, 256);
+  const int64_t o_dk = o_id1 + align_up((int64_t)std::max(n1, 1) * 4, 256);
+  const int64_t o_scr = o_dk + align_up((int64_t)n0 * std::max(n1, 1) * 4, 256);
+  const int64_t need = linetr_match_distmat_workspace_bytes(n0, n1);
+  if (!d_ws || ws_bytes < need) return fail(LINETR_E_WORKSPACE, "match_distmat: workspace too small (need %lld)", (long long)need);
+  char* base = (char*)d_ws;
+  const int m = std::max(n0, n1);
+  int slot = 0;
+  int* iota = (int*)staging_ring().acquire((size_t)m * sizeof(int), &slot);
+  if (!iota) return fail(LINETR_E_HIP, "match_distmat: pinned staging allocation failed");
+  PairTable tab{};
+  tab.n_inline = 1;
+  PairDesc* pd = tab.inl;
+  pd->n0 = pd->k0 = n0; pd->n1 = pd->k1 = n1;
+  pd->chunks = cdiv(n0, PM_ROWS);
+  std::iota(iota, iota + m, 0);
+  LT_HIP(hipMemcpyAsync(base + o_id0, iota, n0 * 4, hipMemcpyHostToDevice, st));
+  if (n1 > 0) LT_HIP(hipMemcpyAsync(base + o_id1, iota, n1 * 4, hipMemcpyHostToDevice, st));
+  if (int e = staging_ring().commit(slot, st)) return e;
+  if (n1 > 0) {
+    const int seg1_global = n1 > PM_MAX_K1;
+    hipLaunchKernelGGL(pair_pool_kernel, dim3(pd->chunks, 1), dim3(256), (size_t)((seg1_global ? 0 : n1) + PM_ROWS + 2) * sizeof(int),
+                       st, tab, (const int*)(base + o_id0), (const int*)(base + o_id1), d_dist, (float*)(base + o_dk),
+                       (int*)(base + o_scr), seg1_global);
+    LT_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(pair_final_kernel, dim3(1), dim3(256), 0, st, tab, thr, mutual, d_match01, (int*)(base + o_scr));
+  LT_LAUNCH_CHECK();
+  return LINETR_OK;
+}
+
+extern "C" int linetr_superpoint_heads(LinetrHandle* h, const float* d_score_logits, const float* d_desc_raw, int32_t B,
+                                       int32_t Hc, int32_t Wc, float* d_dense_score, float* d_dense_desc_nhwc,
+                                       float* d_dense_desc_nchw, void* stream) {
+  if (B < 0 || Hc <= 0 || Wc <= 0) return fail(LINETR_E_ARG, "superpoint_heads: bad shape B=%d Hc=%d Wc=%d", B, Hc, Wc);
+  if (d_dense_score && !d_score_logits) return fail(LINETR_E_ARG, "superpoint_heads: score output without score logits");
+  if ((d_dense_desc_nhwc || d_dense_desc_nchw) && !d_desc_raw)
+    return fail(LINETR_E_ARG, "superpoint_heads: descriptor output without the raw descriptor head");
+  if (B == 0) return LINETR_OK;
+  if (h) LT_HIP(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int HW = Hc * Wc;
+  const dim3 grid((unsigned)cdiv(HW, 64), (unsigned)B);
+  if (d_dense_desc_nhwc || d_dense_desc_nchw) {
+    const double by = (double)B * HW * D * 4.0 * (1 + (d_dense_desc_nhwc ? 1 : 0) + (d_dense_desc_nchw ? 1 : 0));
+    ProfScope ps(h, st, "sp_desc_head", 3.0 * B * HW * D, by);
+    static const int cells = LT_XENV("LINETR_SP_CELLS") ? atoi(LT_XENV("LINETR_SP_CELLS")) : 32;   // tuning aid
+    if (cells == 64) hipLaunchKernelGGL(sp_desc_head_kernel<64>, grid, dim3(256), 0, st, d_desc_raw, d_dense_desc_nhwc, d_dense_desc_nchw, HW);
+    else hipLaunchKernelGGL(sp_desc_head_kernel<32>, dim3((unsigned)cdiv(HW, 32), (unsigned)B), dim3(256), 0, st, d_desc_raw, d_dense_desc_nhwc, d_dense_desc_nchw, HW);
+    LT_LAUNCH_CHECK();
+  }
+  if (d_dense_score) {
+    ProfScope ps(h, st, "sp_score_head", 0, (double)B * HW * (65 + 64) * 4.0);
+    hipLaunchKernelGGL(sp_score_head_kernel, grid, dim3(256), 0, st, d_score_logits, d_dense_score, Hc, Wc);
+    LT_LAUNCH_CHECK();
+  }
+  return LINETR_OK;
+}

@@ -1,17 +1,9 @@
-// liblinetr_hip.so -- host side of the C ABI declared in include/linetr_hip.h.
-// Weight preparation (float64 on the host), host pre-filter, launch sequencing, profiling.
-#include <dlfcn.h>
-
+// liblinetr_hip.so, translation unit 2 of 4: tokenise / forward / describe and the diagnostics entry points of the C ABI, the
+// GEMM dispatcher, and every kernel of the descriptor network (csrc/lt_*.h).
 #include <algorithm>
-#include <condition_variable>
-#include <functional>
-#include <map>
-#include <memory>
-#include <mutex>
 #include <numeric>
-#include <thread>
 
-#include "lt_common.h"
+#include "lt_handle.h"
 #include "lt_gemm.h"
 #include "lt_gemm_split.h"
 #include "lt_gemm_split16.h"
@@ -24,7 +16,6 @@
 #ifdef LINETR_EXPERIMENTS
 #include "lt_mlp_fused.h"
 #endif
-#include "lt_match.h"
 #include "lt_model.h"
 #include "lt_attn_fused.h"
 #include "lt_gemm_ws.h"
@@ -32,63 +23,9 @@
 #ifdef LINETR_EXPERIMENTS
 #include "lt_attn_st.h"
 #endif
-#include "lt_producer.h"
 #include "lt_token.h"
 
 using namespace lt;
-
-// =============================================================================================
-// handle
-// =============================================================================================
-
-struct SigLayer {
-  const float *Wqkv, *bqkv, *W1, *b1, *W2, *b2;  // merge conv folded into W1
-  const float* W2p = nullptr;                    // W2 with K permuted inside 16-groups (lt_mlp_fused.h)
-};
-
-struct ProfClass {
-  const char* name;
-  int calls = 0;
-  double flops = 0, bytes = 0;
-  float ms = 0;
-};
-
-struct LinetrHandle {
-  LinetrModelConfig cfg;
-  int device = 0;
-  float* arena = nullptr;  // all prepared weights, one allocation
-  // word / line positional encoders (BN folded)
-  const float *wW1, *wb1, *wW2, *wb2, *wW3, *wb3, *wW4, *wb4;
-  const float *lW1, *lb1, *lW2, *lb2, *lW3, *lb3, *lW4, *lb4, *lW5, *lb5;
-  // line-descriptive layer (CLS-row algebra)
-  ClsPoolConst pool;
-  const float *Watt, *batt, *Wfc, *bfc, *ln1g, *ln1b, *Wf1, *bf1, *Wf2, *bf2, *ln2g, *ln2b;
-  std::vector<SigLayer> sig;
-  const float *Wfin, *bfin;
-  const float *Wfin2 = nullptr, *bfin2 = nullptr;   // final projection with the last signature layer's second MLP GEMM folded in
-  // split-bf16 copies of every GEMM weight (2 and 3 planes), keyed by the fp32 pointer
-  int precision = LINETR_PREC_BF16X6;
-  unsigned char* split_arena = nullptr;
-  struct SplitW { size_t off2, off3; int64_t rows; int K; size_t offh = 0; size_t offst = 0; };  // bf16x2 planes, bf16x3 planes, fp16x2 planes, ST image (lt_gemm_st.h; 0 = none)
-  std::map<const float*, SplitW> split;
-  std::map<const float*, unsigned char*> debug_split;  // linetr_debug_gemm(cache_weights=1)
-  // side stream: work that is independent of the token-MLP GEMMs (NHWC transpose, line-position MLP) runs here and
-  // is joined back with events; created lazily, disabled with LINETR_NO_SIDE_STREAM=1
-  hipStream_t side = nullptr;
-  bool side_failed = false;
-  hipEvent_t ev_fork = nullptr, ev_tok = nullptr, ev_nhwc = nullptr, ev_lpos = nullptr;
-  // stream-K workspace of the 128x256 GEMM (partial accumulator tiles + flags, one slot per CU; lt_gemm_split.h)
-  float* zeros = nullptr;   // 4096 zero floats: the "no bias" vector of the split-tile GEMM (lt_gemm_st.h)
-  float* sk_ws = nullptr;
-  unsigned* sk_flags = nullptr;
-  unsigned sk_epoch = 0;
-  // profiling
-  bool profiling = false;
-  std::vector<ProfClass> classes;
-  struct Pending { int cls; hipEvent_t a, b; };
-  std::vector<Pending> pending;
-  std::vector<hipEvent_t> event_pool;
-};
 
 namespace {
 
@@ -119,118 +56,6 @@ bool side_stream_ready(LinetrHandle* h, int n_sublines) {
   h->ev_fork = ev[0]; h->ev_tok = ev[1]; h->ev_nhwc = ev[2]; h->ev_lpos = ev[3];
   return true;
 }
-
-// Persistent host worker pool (the batched pre-filter used to create and join 7 std::threads per call).
-// Leaked on purpose: the workers are detached and live until process exit, so there is no static-destruction order
-// problem when the library is unloaded from an interpreter that is shutting down.
-class WorkPool {
- public:
-  static WorkPool& get() {
-    static WorkPool* p = new WorkPool();
-    return *p;
-  }
-  int size() const { return n_workers_ + 1; }
-  // runs fn(0..n-1), the calling thread takes part; one parallel region at a time
-  void run(int n, const std::function<void(int)>& fn) {
-    if (n <= 0) return;
-    if (n == 1 || n_workers_ == 0) { for (int i = 0; i < n; ++i) fn(i); return; }
-    std::lock_guard<std::mutex> region(region_);
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      job_ = &fn; n_jobs_ = n; next_ = 0; pending_ = n; ++gen_;
-    }
-    cv_work_.notify_all();
-    drain();
-    std::unique_lock<std::mutex> lk(m_);
-    cv_done_.wait(lk, [&] { return pending_ == 0; });
-    job_ = nullptr;
-  }
-
- private:
-  WorkPool() {
-    // one process per GPU: the ranks of a node share its cores (LOCAL_WORLD_SIZE is set by torch.distributed.run);
-    // LINETR_HOST_THREADS overrides (0 = run the pre-filter on the calling thread)
-    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    if (const char* lw = getenv("LOCAL_WORLD_SIZE")) hw /= (unsigned)std::max(1, atoi(lw));
-    n_workers_ = (int)std::min(15u, hw > 1 ? hw / 2 : 0u);
-    if (const char* ht = getenv("LINETR_HOST_THREADS")) n_workers_ = std::max(0, std::min(63, atoi(ht) - 1));
-    for (int i = 0; i < n_workers_; ++i) std::thread([this] { loop(); }).detach();
-  }
-  void drain() {
-    for (;;) {
-      int i;
-      const std::function<void(int)>* f;
-      {
-        std::lock_guard<std::mutex> lk(m_);
-        if (!job_ || next_ >= n_jobs_) return;
-        i = next_++;
-        f = job_;
-      }
-      (*f)(i);
-      std::lock_guard<std::mutex> lk(m_);
-      if (--pending_ == 0) cv_done_.notify_all();
-    }
-  }
-  void loop() {
-    uint64_t seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_work_.wait(lk, [&] { return gen_ != seen; });
-        seen = gen_;
-      }
-      drain();
-    }
-  }
-  std::mutex m_, region_;
-  std::condition_variable cv_work_, cv_done_;
-  const std::function<void(int)>* job_ = nullptr;
-  int n_jobs_ = 0, next_ = 0, pending_ = 0, n_workers_ = 0;
-  uint64_t gen_ = 0;
-};
-
-int prof_class(LinetrHandle* h, const char* name) {
-  for (size_t i = 0; i < h->classes.size(); ++i)
-    if (h->classes[i].name == name || strcmp(h->classes[i].name, name) == 0) return (int)i;
-  ProfClass c;
-  c.name = name;
-  h->classes.push_back(c);
-  return (int)h->classes.size() - 1;
-}
-
-hipEvent_t prof_event(LinetrHandle* h) {
-  if (!h->event_pool.empty()) {
-    hipEvent_t e = h->event_pool.back();
-    h->event_pool.pop_back();
-    return e;
-  }
-  hipEvent_t e = nullptr;
-  (void)hipEventCreate(&e);   // a null event only loses this kernel's timing sample
-  return e;
-}
-
-// RAII bracket around one kernel launch
-struct ProfScope {
-  LinetrHandle* h;
-  hipStream_t st;
-  int cls = -1;
-  hipEvent_t a{}, b{};
-  ProfScope(LinetrHandle* h_, hipStream_t st_, const char* name, double flops, double bytes) : h(h_), st(st_) {
-    if (!h || !h->profiling) return;
-    cls = prof_class(h, name);
-    h->classes[cls].calls++;
-    h->classes[cls].flops += flops;
-    h->classes[cls].bytes += bytes;
-    a = prof_event(h);
-    b = prof_event(h);
-    (void)hipEventRecord(a, st);
-  }
-  ~ProfScope() {
-    if (cls < 0) return;
-    (void)hipEventRecord(b, st);
-    h->pending.push_back({cls, a, b});
-  }
-};
 
 const char* gemm_class_name(const GemmArgs& g, int groups, const char* kind) {
   const char* tile;
@@ -433,556 +258,44 @@ int run_sig_mlp(LinetrHandle* h, hipStream_t st, const float* z, const float* ms
 }
 
 #endif  // LINETR_EXPERIMENTS
-// ---- float64 weight preparation ---------------------------------------------------------------
-
-struct TensorMap {
-  std::map<std::string, std::pair<const float*, int64_t>> t;
-  const float* get(const std::string& k, int64_t numel, int& err) const {
-    auto it = t.find(k);
-    if (it == t.end() || it->second.first == nullptr) {
-      err = fail(LINETR_E_WEIGHTS, "state_dict tensor '%s' missing", k.c_str());
-      return nullptr;
-    }
-    if (it->second.second != numel) {
-      err = fail(LINETR_E_WEIGHTS, "state_dict tensor '%s' has %lld elements, expected %lld", k.c_str(),
-                 (long long)it->second.second, (long long)numel);
-      return nullptr;
-    }
-    return it->second.first;
-  }
-};
-
-struct Arena {
-  std::vector<float> host;
-  size_t put(const std::vector<double>& v) {
-    size_t off = (host.size() + 63) / 64 * 64;
-    host.resize(off + v.size());
-    for (size_t i = 0; i < v.size(); ++i) host[off + i] = (float)v[i];
-    return off;
-  }
-};
-
-// Conv1d(k=1)+BatchNorm1d(eval) -> one affine map (models/line_transformer.py:9-20)
-void fold_bn(const float* W, const float* b, const float* g, const float* beta, const float* mean,
-             const float* var, int out, int in, std::vector<double>& Wf, std::vector<double>& bf) {
-  Wf.resize((size_t)out * in);
-  bf.resize(out);
-  for (int o = 0; o < out; ++o) {
-    const double s = (double)g[o] / std::sqrt((double)var[o] + 1e-5);
-    for (int i = 0; i < in; ++i) Wf[(size_t)o * in + i] = (double)W[(size_t)o * in + i] * s;
-    bf[o] = ((double)b[o] - (double)mean[o]) * s + (double)beta[o];
-  }
-}
-
-std::vector<double> to_d(const float* p, size_t n) { return std::vector<double>(p, p + n); }
-
 }  // namespace
 
-// =============================================================================================
-// lifetime
-// =============================================================================================
-
-extern "C" int linetr_abi_version(void) { return LINETR_ABI_VERSION; }
-extern "C" const char* linetr_last_error(void) { return g_err.c_str(); }
-
-extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, const char* const* names,
-                             const float* const* h_data, const int64_t* numel, int32_t device,
-                             LinetrHandle** out) {
-  if (!cfg || !out || !names || !h_data || !numel) return fail(LINETR_E_ARG, "null argument");
-  if (cfg->d_model != D || cfg->n_heads != HEADS)
-    return fail(LINETR_E_ARG, "only descriptor_dim=256 / n_heads=4 are supported");
-  if (cfg->d_inner % 128 != 0 || cfg->n_sig_layers < 0 || cfg->n_desc_layers < 1)
-    return fail(LINETR_E_ARG, "bad d_inner / layer counts");
-  const int e0 = cfg->enc_channels[0], e1 = cfg->enc_channels[1], e2 = cfg->enc_channels[2], e3 = cfg->enc_channels[3];
-  if (e0 != 32 || e1 % 64 || e2 % 64 || e3 % 64 || e3 != D)
-    return fail(LINETR_E_ARG, "keyline_encoder must be [32, 64k, 64k, 256] (got %d,%d,%d,%d)", e0, e1, e2, e3);
-  int ndev = 0;
-  LT_HIP(hipGetDeviceCount(&ndev));
-  if (ndev <= 0 || device >= ndev) return fail(LINETR_E_HIP, "no usable HIP device (count=%d)", ndev);
-  LT_HIP(hipSetDevice(device));
-
-  TensorMap tm;
-  for (int i = 0; i < n_tensors; ++i) tm.t[names[i]] = {h_data[i], numel[i]};
-  int err = 0;
-  Arena ar;
-  auto H = std::make_unique<LinetrHandle>();
-  H->cfg = *cfg;
-  H->device = device;
-  struct Fix { const float** dst; size_t off; };
-  std::vector<Fix> fix;
-  auto place = [&](const float** dst, const std::vector<double>& v) { fix.push_back({dst, ar.put(v)}); };
-  struct GemmW { const float** dst; int64_t rows; int K; bool st; };
-  std::vector<GemmW> gemm_w;
-  // st: the weight also gets a split-tile image (lt_gemm_st.h) -- the q/k/v projections, which the fused projection +
-  // attention kernel streams by LDS-DMA (lt_attn_fused.h); in the experiments build every eligible weight gets one
-  auto place_w = [&](const float** dst, const std::vector<double>& v, int64_t rows, int K, bool st = false) {
-    place(dst, v);
-    gemm_w.push_back({dst, rows, K, st});
-  };
-
-  // ---- positional encoders: 4 x (conv + BN + ReLU) + linear ------------------------------------
-  const int ch_w[6] = {3, e0, e1, e2, e3, D}, ch_l[6] = {5, e0, e1, e2, e3, D};
-  std::vector<double> W5w, b5w;  // last (linear) layer of the word encoder, consumed algebraically
-  for (int enc = 0; enc < 2; ++enc) {
-    const std::string pre = enc == 0 ? "klenc.word_position_enc.encoder." : "klenc.line_position_enc.encoder.";
-    const int* ch = enc == 0 ? ch_w : ch_l;
-    const float** Wdst[4] = {enc == 0 ? &H->wW1 : &H->lW1, enc == 0 ? &H->wW2 : &H->lW2,
-                             enc == 0 ? &H->wW3 : &H->lW3, enc == 0 ? &H->wW4 : &H->lW4};
-    const float** bdst[4] = {enc == 0 ? &H->wb1 : &H->lb1, enc == 0 ? &H->wb2 : &H->lb2,
-                             enc == 0 ? &H->wb3 : &H->lb3, enc == 0 ? &H->wb4 : &H->lb4};
-    for (int i = 0; i < 4; ++i) {
-      const std::string c = pre + std::to_string(3 * i), bn = pre + std::to_string(3 * i + 1);
-      const float* W = tm.get(c + ".weight", (int64_t)ch[i + 1] * ch[i], err);
-      const float* b = tm.get(c + ".bias", ch[i + 1], err);
-      const float* g = tm.get(bn + ".weight", ch[i + 1], err);
-      const float* be = tm.get(bn + ".bias", ch[i + 1], err);
-      const float* mu = tm.get(bn + ".running_mean", ch[i + 1], err);
-      const float* va = tm.get(bn + ".running_var", ch[i + 1], err);
-      if (err) return err;
-      std::vector<double> Wf, bf;
-      fold_bn(W, b, g, be, mu, va, ch[i + 1], ch[i], Wf, bf);
-      // layers 2-4 also get split-tile images: the one-kernel MLP of lt_tokmlp.h keeps layers 2 / 3 in LDS and layer 4 in registers as
-      // such, and the weight-stationary GEMM of lt_gemm_ws.h reads layer 4's planes from one
-      if (i == 0) place(Wdst[i], Wf); else place_w(Wdst[i], Wf, ch[i + 1], ch[i], true);
-      place(bdst[i], bf);
-    }
-    const float* W = tm.get(pre + "12.weight", (int64_t)D * e3, err);
-    const float* b = tm.get(pre + "12.bias", D, err);
-    if (err) return err;
-    if (enc == 0) { W5w = to_d(W, (size_t)D * D); b5w = to_d(b, D); }
-    else { place_w(&H->lW5, to_d(W, (size_t)D * D), D, e3); place(&H->lb5, to_d(b, D)); }
-  }
-
-  // ---- line-descriptive layer: only the last one matters (line_transformer.py:123-125) ----------
-  {
-    const std::string p = "klenc.desc_layers." + std::to_string(cfg->n_desc_layers - 1) + ".";
-    const float* cls = tm.get("klenc.cls_token", D, err);
-    const float* Wq = tm.get(p + "slf_attn.w_qs.weight", D * D, err);
-    const float* bq = tm.get(p + "slf_attn.w_qs.bias", D, err);
-    const float* Wk = tm.get(p + "slf_attn.w_ks.weight", D * D, err);
-    const float* bk = tm.get(p + "slf_attn.w_ks.bias", D, err);
-    const float* Wv = tm.get(p + "slf_attn.w_vs.weight", D * D, err);
-    const float* bv = tm.get(p + "slf_attn.w_vs.bias", D, err);
-    const float* Wfc = tm.get(p + "slf_attn.fc.weight", D * D, err);
-    const float* bfc = tm.get(p + "slf_attn.fc.bias", D, err);
-    const float* g1 = tm.get(p + "slf_attn.layer_norm.weight", D, err);
-    const float* b1 = tm.get(p + "slf_attn.layer_norm.bias", D, err);
-    const int DI = cfg->d_inner;
-    const float* W1 = tm.get(p + "pos_ffn.w_1.weight", (int64_t)DI * D, err);
-    const float* bb1 = tm.get(p + "pos_ffn.w_1.bias", DI, err);
-    const float* W2 = tm.get(p + "pos_ffn.w_2.weight", (int64_t)D * DI, err);
-    const float* bb2 = tm.get(p + "pos_ffn.w_2.bias", D, err);
-    const float* g2 = tm.get(p + "pos_ffn.layer_norm.weight", D, err);
-    const float* b2 = tm.get(p + "pos_ffn.layer_norm.bias", D, err);
-    if (err) return err;
-    // CLS query, pre-scaled by 1/sqrt(64) (line_attention.py:14)
-    std::vector<double> q(D);
-    for (int o = 0; o < D; ++o) {
-      double s = bq[o];
-      for (int i = 0; i < D; ++i) s += (double)Wq[o * D + i] * cls[i];
-      q[o] = s / 8.0;
-    }
-    std::vector<double> U(HEADS * D, 0.0), U2(HEADS * D, 0.0);
-    for (int h = 0; h < HEADS; ++h) {
-      double c = 0.0;
-      for (int d = 0; d < DH; ++d) {
-        const int o = h * DH + d;  // descriptive heads are head-major (line_attention.py:55-57)
-        c += q[o] * bk[o];
-        for (int i = 0; i < D; ++i) U[h * D + i] += q[o] * Wk[o * D + i];
-      }
-      for (int i = 0; i < D; ++i) {  // U2 = W5^T u_h
-        double s = 0.0;
-        for (int o = 0; o < D; ++o) s += W5w[(size_t)o * D + i] * U[h * D + o];
-        U2[h * D + i] = s;
-      }
-      double ub5 = 0.0, ucls = 0.0;
-      for (int i = 0; i < D; ++i) { ub5 += U[h * D + i] * b5w[i]; ucls += U[h * D + i] * cls[i]; }
-      H->pool.c_tok[h] = (float)(ub5 + c);
-      H->pool.s_cls[h] = (float)(ucls + c);
-    }
-    place(&H->pool.U, U);
-    place(&H->pool.U2, U2);
-    // value path after pooling: att_h = Wv_h dbar + (Wv_h W5) abar + p0 * Wv_h (cls - b5) + (Wv_h b5 + bv_h)
-    std::vector<double> Watt((size_t)HEADS * DH * POOLW, 0.0), batt(HEADS * DH);
-    for (int h = 0; h < HEADS; ++h)
-      for (int d = 0; d < DH; ++d) {
-        const int o = h * DH + d;
-        double* row = &Watt[((size_t)h * DH + d) * POOLW];
-        double r = 0.0, bb = bv[o];
-        for (int i = 0; i < D; ++i) {
-          row[i] = Wv[o * D + i];
-          r += (double)Wv[o * D + i] * ((double)cls[i] - b5w[i]);
-          bb += (double)Wv[o * D + i] * b5w[i];
-        }
-        for (int i = 0; i < D; ++i) {
-          double s = 0.0;
-          for (int m = 0; m < D; ++m) s += (double)Wv[o * D + m] * W5w[(size_t)m * D + i];
-          row[D + i] = s;
-        }
-        row[2 * D] = r;
-        batt[o] = bb;
-      }
-    place_w(&H->Watt, Watt, HEADS * DH, POOLW);
-    place(&H->batt, batt);
-    place_w(&H->Wfc, to_d(Wfc, D * D), D, D);
-    std::vector<double> bfc2(D);
-    for (int i = 0; i < D; ++i) bfc2[i] = (double)bfc[i] + cls[i];  // residual of the CLS row is the constant token
-    place(&H->bfc, bfc2);
-    place(&H->ln1g, to_d(g1, D)); place(&H->ln1b, to_d(b1, D));
-    place_w(&H->Wf1, to_d(W1, (size_t)DI * D), DI, D); place(&H->bf1, to_d(bb1, DI));
-    place_w(&H->Wf2, to_d(W2, (size_t)D * DI), D, DI); place(&H->bf2, to_d(bb2, D));
-    place(&H->ln2g, to_d(g2, D)); place(&H->ln2b, to_d(b2, D));
-  }
-
-  // ---- signature layers --------------------------------------------------------------------------
-  H->sig.resize(cfg->n_sig_layers);
-  for (int l = 0; l < cfg->n_sig_layers; ++l) {
-    const std::string p = "selfattn.layers." + std::to_string(l) + ".";
-    const float* Wp[3];
-    const float* bp[3];
-    for (int j = 0; j < 3; ++j) {
-      Wp[j] = tm.get(p + "attn.proj." + std::to_string(j) + ".weight", D * D, err);
-      bp[j] = tm.get(p + "attn.proj." + std::to_string(j) + ".bias", D, err);
-    }
-    const float* Wm = tm.get(p + "attn.merge.weight", D * D, err);
-    const float* bm = tm.get(p + "attn.merge.bias", D, err);
-    const float* W1 = tm.get(p + "mlp.0.weight", 4 * D * D, err);
-    const float* b1 = tm.get(p + "mlp.0.bias", 2 * D, err);
-    const float* g = tm.get(p + "mlp.1.weight", 2 * D, err);
-    const float* be = tm.get(p + "mlp.1.bias", 2 * D, err);
-    const float* mu = tm.get(p + "mlp.1.running_mean", 2 * D, err);
-    const float* va = tm.get(p + "mlp.1.running_var", 2 * D, err);
-    const float* W2 = tm.get(p + "mlp.3.weight", 2 * D * D, err);
-    const float* b2 = tm.get(p + "mlp.3.bias", D, err);
-    if (err) return err;
-    // reference channel c = d*4 + h (line_transformer.py:151)  ->  head-major c' = h*64 + d;
-    // q additionally scaled by 1/sqrt(64) (:134), an exact power of two.
-    std::vector<double> Wqkv((size_t)3 * D * D), bqkv(3 * D);
-    for (int j = 0; j < 3; ++j)
-      for (int h = 0; h < HEADS; ++h)
-        for (int d = 0; d < DH; ++d) {
-          const int src = d * HEADS + h, dst = j * D + h * DH + d;
-          const double sc = j == 0 ? 0.125 : 1.0;
-          for (int i = 0; i < D; ++i) Wqkv[(size_t)dst * D + i] = (double)Wp[j][src * D + i] * sc;
-          bqkv[dst] = (double)bp[j][src] * sc;
-        }
-    std::vector<double> Wm2((size_t)D * D);
-    for (int o = 0; o < D; ++o)
-      for (int h = 0; h < HEADS; ++h)
-        for (int d = 0; d < DH; ++d) Wm2[(size_t)o * D + h * DH + d] = Wm[o * D + d * HEADS + h];
-    std::vector<double> W1f, b1f;
-    fold_bn(W1, b1, g, be, mu, va, 2 * D, 2 * D, W1f, b1f);
-    // fold the attention's merge conv into the MLP's first layer (both linear, nothing in between):
-    //   W1 [x ; Wm a + bm] + b1 = W1a x + (W1b Wm) a + (W1b bm + b1)            (line_transformer.py:154,:166)
-    std::vector<double> W1m((size_t)2 * D * 2 * D);
-    for (int o = 0; o < 2 * D; ++o) {
-      const double* w1b = &W1f[(size_t)o * 2 * D + D];
-      for (int i = 0; i < D; ++i) W1m[(size_t)o * 2 * D + i] = W1f[(size_t)o * 2 * D + i];
-      for (int i = 0; i < D; ++i) {
-        double sacc = 0.0;
-        for (int m = 0; m < D; ++m) sacc += w1b[m] * Wm2[(size_t)m * D + i];
-        W1m[(size_t)o * 2 * D + D + i] = sacc;
-      }
-      double bacc = b1f[o];
-      for (int m = 0; m < D; ++m) bacc += w1b[m] * (double)bm[m];
-      b1f[o] = bacc;
-    }
-    SigLayer& S = H->sig[l];
-    place_w(&S.Wqkv, Wqkv, 3 * D, D, true); place(&S.bqkv, bqkv);
-    place_w(&S.W1, W1m, 2 * D, 2 * D); place(&S.b1, b1f);
-    place_w(&S.W2, to_d(W2, (size_t)2 * D * D), D, 2 * D); place(&S.b2, to_d(b2, D));
+// split-bf16 / fp16 / split-tile copies of the prepared GEMM weights (called once by linetr_create)
+int lt::make_split_copies(LinetrHandle* H, const std::vector<GemmWSpec>& weights) {
+  size_t total = 0;
+  for (auto& w : weights) {
+    LinetrHandle::SplitW sw;
+    sw.rows = w.rows; sw.K = w.K;
+    sw.off2 = total; total += align_up(w.rows * w.K * 4, 256);
+    sw.off3 = total; total += align_up(w.rows * w.K * 6, 256);
+    sw.offh = total; total += align_up(w.rows * w.K * 4, 256);
 #ifdef LINETR_EXPERIMENTS
-    {
-      std::vector<double> W2perm((size_t)2 * D * D);
-      for (int o = 0; o < D; ++o)
-        for (int k = 0; k < 2 * D; ++k) W2perm[(size_t)o * 2 * D + k] = W2[(size_t)o * 2 * D + sig_mlp_kperm(k)];
-      place_w(&S.W2p, W2perm, D, 2 * D);
-    }
-#endif
-  }
-  {
-    const float* W = tm.get("final_proj.weight", D * D, err);
-    const float* b = tm.get("final_proj.bias", D, err);
-    if (err) return err;
-    place_w(&H->Wfin, to_d(W, D * D), D, D);
-    place(&H->bfin, to_d(b, D));
-    if (cfg->n_sig_layers > 0) {
-      // x_out = z + W2 hid + b2 (line_transformer.py:180-183) and final_proj is linear (:245), so
-      //   final_proj(x_out) = [Wfin | Wfin W2] [z ; hid] + (Wfin b2 + bfin)          (float64, once)
-      const std::string p = "selfattn.layers." + std::to_string(cfg->n_sig_layers - 1) + ".";
-      const float* W2 = tm.get(p + "mlp.3.weight", 2 * D * D, err);
-      const float* b2 = tm.get(p + "mlp.3.bias", D, err);
-      if (err) return err;
-      std::vector<double> Wf((size_t)D * 3 * D), bf(D);
-      for (int o = 0; o < D; ++o) {
-        for (int i = 0; i < D; ++i) Wf[(size_t)o * 3 * D + i] = W[o * D + i];
-        for (int j = 0; j < 2 * D; ++j) {
-          double sacc = 0.0;
-          for (int m = 0; m < D; ++m) sacc += (double)W[o * D + m] * (double)W2[(size_t)m * 2 * D + j];
-          Wf[(size_t)o * 3 * D + D + j] = sacc;
-        }
-        double bacc = b[o];
-        for (int m = 0; m < D; ++m) bacc += (double)W[o * D + m] * (double)b2[m];
-        bf[o] = bacc;
-      }
-      place_w(&H->Wfin2, Wf, D, 3 * D);
-      place(&H->bfin2, bf);
-    }
-  }
-
-  LT_HIP(hipMalloc((void**)&H->arena, ar.host.size() * sizeof(float)));
-  LT_HIP(hipMemcpy(H->arena, ar.host.data(), ar.host.size() * sizeof(float), hipMemcpyHostToDevice));
-  for (auto& f : fix) *f.dst = H->arena + f.off;
-  // split-bf16 copies of the GEMM weights, produced on the device
-  {
-    size_t total = 0;
-    for (auto& w : gemm_w) {
-      LinetrHandle::SplitW sw;
-      sw.rows = w.rows; sw.K = w.K;
-      sw.off2 = total; total += align_up(w.rows * w.K * 4, 256);
-      sw.off3 = total; total += align_up(w.rows * w.K * 6, 256);
-      sw.offh = total; total += align_up(w.rows * w.K * 4, 256);
-#ifdef LINETR_EXPERIMENTS
-      const bool want_st = true;
+    const bool want_st = true;
 #else
-      const bool want_st = w.st;                          // the fused projection + attention kernel's q/k/v weights
+    const bool want_st = w.st;                          // the weights that travel by LDS-DMA or stay in registers / LDS
 #endif
-      if (want_st && w.rows % 16 == 0 && w.K % 32 == 0) { total = align_up(total, 1024); sw.offst = total; total += st_bytes(w.rows, w.K); }   // ST image (rows padded to 128)
-      H->split[*w.dst] = sw;
+    if (want_st && w.rows % 16 == 0 && w.K % 32 == 0) { total = align_up(total, 1024); sw.offst = total; total += st_bytes(w.rows, w.K); }   // ST image (rows padded to 128)
+    H->split[w.W] = sw;
+  }
+  LT_HIP(hipMalloc((void**)&H->split_arena, total));
+  LT_HIP(hipMalloc((void**)&H->zeros, 4096 * sizeof(float)));
+  LT_HIP(hipMemset(H->zeros, 0, 4096 * sizeof(float)));
+  for (auto& kv : H->split) {
+    const int64_t n4 = kv.second.rows * kv.second.K / 4;
+    hipLaunchKernelGGL(split_rows_kernel<2>, dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, 0, kv.first,
+                       H->split_arena + kv.second.off2, kv.second.rows, kv.second.K);
+    hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, 0, kv.first,
+                       H->split_arena + kv.second.off3, kv.second.rows, kv.second.K);
+    hipLaunchKernelGGL((split_rows_kernel<2, 1>), dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, 0, kv.first,
+                       H->split_arena + kv.second.offh, kv.second.rows, kv.second.K);
+    if (kv.second.offst) {
+      const int64_t thr = st_row_blocks(kv.second.rows) * (kv.second.K / 16) * 32;
+      hipLaunchKernelGGL(to_st_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, 0, kv.first, kv.second.K,
+                         (int)kv.second.rows, kv.second.K / 16, H->split_arena + kv.second.offst);
     }
-    LT_HIP(hipMalloc((void**)&H->split_arena, total));
-    LT_HIP(hipMalloc((void**)&H->zeros, 4096 * sizeof(float)));
-    LT_HIP(hipMemset(H->zeros, 0, 4096 * sizeof(float)));
-    for (auto& kv : H->split) {
-      const int64_t n4 = kv.second.rows * kv.second.K / 4;
-      hipLaunchKernelGGL(split_rows_kernel<2>, dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, 0, kv.first,
-                         H->split_arena + kv.second.off2, kv.second.rows, kv.second.K);
-      hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, 0, kv.first,
-                         H->split_arena + kv.second.off3, kv.second.rows, kv.second.K);
-      hipLaunchKernelGGL((split_rows_kernel<2, 1>), dim3((unsigned)cdiv((int)n4, 256)), dim3(256), 0, 0, kv.first,
-                         H->split_arena + kv.second.offh, kv.second.rows, kv.second.K);
-      if (kv.second.offst) {
-        const int64_t thr = st_row_blocks(kv.second.rows) * (kv.second.K / 16) * 32;
-        hipLaunchKernelGGL(to_st_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, 0, kv.first, kv.second.K,
-                           (int)kv.second.rows, kv.second.K / 16, H->split_arena + kv.second.offst);
-      }
-    }
-    LT_LAUNCH_CHECK();
-    LT_HIP(hipDeviceSynchronize());
   }
-  if (const char* e = getenv("LINETR_PRECISION")) {
-    if (!strcmp(e, "f32")) H->precision = LINETR_PREC_F32;
-    else if (!strcmp(e, "bf16x3")) H->precision = LINETR_PREC_BF16X3;
-    else if (!strcmp(e, "bf16x6")) H->precision = LINETR_PREC_BF16X6;
-    else if (!strcmp(e, "f16x3")) H->precision = LINETR_PREC_F16X3;
-    else return fail(LINETR_E_ARG, "LINETR_PRECISION must be f32, bf16x3, bf16x6 or f16x3 (got '%s')", e);
-  }
-  *out = H.release();
-  return LINETR_OK;
-}
-
-extern "C" int linetr_set_precision(LinetrHandle* h, int32_t mode) {
-  if (!h || mode < LINETR_PREC_F32 || mode > LINETR_PREC_F16X3) return fail(LINETR_E_ARG, "bad precision mode");
-  h->precision = mode;
-  return LINETR_OK;
-}
-extern "C" int linetr_get_precision(const LinetrHandle* h) { return h ? h->precision : LINETR_E_ARG; }
-
-extern "C" void linetr_destroy(LinetrHandle* h) {
-  if (!h) return;
-  (void)hipSetDevice(h->device);
-  for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-  for (auto e : h->event_pool) (void)hipEventDestroy(e);
-  if (h->side) (void)hipStreamDestroy(h->side);
-  for (hipEvent_t e : {h->ev_fork, h->ev_tok, h->ev_nhwc, h->ev_lpos})
-    if (e) (void)hipEventDestroy(e);
-  if (h->arena) (void)hipFree(h->arena);
-  if (h->split_arena) (void)hipFree(h->split_arena);
-  if (h->zeros) (void)hipFree(h->zeros);
-  if (h->sk_ws) (void)hipFree(h->sk_ws);
-  if (h->sk_flags) (void)hipFree(h->sk_flags);
-  for (auto& kv : h->debug_split) (void)hipFree(kv.second);
-  delete h;
-}
-
-// =============================================================================================
-// host pre-filter
-// =============================================================================================
-
-static int pack_one(LinetrLineRec& r, double td, int T, int image, int line_local, int& sub_cursor, int& tok_cursor) {
-  if (!(td > 0) || T < 1) return fail(LINETR_E_ARG, "token_distance must be > 0 and max_tokens >= 1");
-  const double nt = std::ceil(r.length / td);          // line_process.py:109
-  if (!(nt >= 1) || nt > 1e7) return fail(LINETR_E_ARG, "key-line %d has a non-positive / absurd token count", line_local);
-  r.n_tok = (int)nt;
-  r.n_sub = (r.n_tok + T - 1) / T;                      // :121
-  r.first_sub = sub_cursor;
-  r.image = image;
-  r.line_local = line_local;
-  r.first_tok = tok_cursor;
-  sub_cursor += r.n_sub;
-  tok_cursor += r.n_tok;
-  // the reference asserts every walked distance <= geometric length (:44-45)
-  if (r.n_tok >= 2) {
-    const double dx = r.ep[0] - r.sp[0], dy = r.ep[1] - r.sp[1];
-    const double geo = std::sqrt(dx * dx + dy * dy);
-    if (!(geo >= (double)(r.n_tok - 2) * td))
-      return fail(LINETR_E_ASSERT, "distance should be smaller than line length! (key-line %d)", line_local);
-  }
-  return 0;
-}
-
-static void angle_of(LinetrLineRec& r) {  // line_process.py:28-41
-  double th = std::atan2(r.ep[0] - r.sp[0], r.ep[1] - r.sp[1]);
-  if (th < 0) th += M_PI;
-  // one libm call for both (glibc's sincos returns exactly what its sin and cos return)
-  ::sincos(2 * th, &r.angle[1], &r.angle[0]);
-}
-
-extern "C" int linetr_pack_lines(const double* h_klines, const double* h_length, const double* h_angles, int32_t K,
-                                 double td, int32_t T, int32_t image_index, int32_t sub_base, int32_t tok_base,
-                                 LinetrLineRec* h_recs, int32_t* n_out) {
-  if (K < 0 || (K > 0 && (!h_klines || !h_length || !h_angles || !h_recs))) return fail(LINETR_E_ARG, "null argument");
-  int cur = sub_base, tcur = tok_base;
-  for (int k = 0; k < K; ++k) {
-    LinetrLineRec& r = h_recs[k];
-    r.sp[0] = h_klines[k * 4 + 0]; r.sp[1] = h_klines[k * 4 + 1];
-    r.ep[0] = h_klines[k * 4 + 2]; r.ep[1] = h_klines[k * 4 + 3];
-    r.length = h_length[k];
-    r.angle[0] = h_angles[k * 2]; r.angle[1] = h_angles[k * 2 + 1];
-    if (int e = pack_one(r, td, T, image_index, k, cur, tcur)) return e;
-  }
-  if (n_out) *n_out = cur - sub_base;
-  return LINETR_OK;
-}
-
-// filter + sort of one image (records carry geometry/length/angle only).  `emit(n)` is called once with the number of surviving
-// lines and returns where to write them: straight into the caller's record array on the single-thread path (a record is 80 bytes;
-// the earlier form copied every survivor three times).
-struct KeptLine { double sp[2], ep[2], length; };
-template <class Emit>
-static void prefilter_core(const double* L, int32_t K, int32_t height, int32_t width, int32_t border,
-                           double min_length, int32_t max_keylines, const double* vm, Emit emit) {
-  static thread_local std::vector<KeptLine> keep;
-  static thread_local std::vector<std::pair<double, int>> order;
-  keep.clear();
-  keep.reserve(K);
-  const double xmax = ((double)width - 0.001) - (double)border;   // width-eps-border, line_process.py:72-74
-  const double ymax = ((double)height - 0.001) - (double)border;
-  for (int k = 0; k < K; ++k) {
-    const double* l = L + (size_t)k * 6;
-    KeptLine r;
-    if (l[0] < l[2]) { r.sp[0] = l[0]; r.sp[1] = l[1]; r.ep[0] = l[2]; r.ep[1] = l[3]; }   // :212-217
-    else { r.sp[0] = l[2]; r.sp[1] = l[3]; r.ep[0] = l[0]; r.ep[1] = l[1]; }
-    // lineLength * 2 ** octave (:220); an integral octave is an exact power of two either way: skip the pow call
-    const double oct = l[5];
-    r.length = (oct == std::floor(oct) && std::fabs(oct) < 64.0) ? l[4] * std::ldexp(1.0, (int)oct) : l[4] * std::pow(2.0, oct);
-    const bool inside = r.sp[0] >= border && r.sp[0] < width - border && r.sp[1] >= border && r.sp[1] < height - border &&
-                        r.ep[0] >= border && r.ep[0] < width - border && r.ep[1] >= border && r.ep[1] < height - border;
-    if (!inside) continue;                                                                   // :62-70
-    r.sp[0] = std::min(r.sp[0], xmax); r.ep[0] = std::min(r.ep[0], xmax);
-    r.sp[1] = std::min(r.sp[1], ymax); r.ep[1] = std::min(r.ep[1], ymax);
-    if (vm) {                                                                                // :76-80
-      const int64_t sx = (int64_t)std::floor(r.sp[0]), sy = (int64_t)std::floor(r.sp[1]);
-      const int64_t ex = (int64_t)std::floor(r.ep[0]), ey = (int64_t)std::floor(r.ep[1]);
-      auto at = [&](int64_t y, int64_t x) {  // numpy-style wrap of negative indices
-        if (y < 0) y += height;
-        if (x < 0) x += width;
-        return vm[y * width + x];
-      };
-      if (at(sy, sx) + at(ey, ex) == 0.0) continue;
-    }
-    if (!(r.length > min_length)) continue;                                                  // :8
-    keep.push_back(r);
-  }
-  // ascending stable order by length, read backwards (:15-16): ties come out in descending input order, as before
-  order.resize(keep.size());
-  for (size_t i = 0; i < keep.size(); ++i) order[i] = {keep[i].length, (int)i};
-  std::stable_sort(order.begin(), order.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
-  int64_t n_keep = (int64_t)order.size();
-  if (max_keylines < 0) n_keep = std::max<int64_t>(0, n_keep + max_keylines);                // python slice [:m]
-  else n_keep = std::min<int64_t>(n_keep, max_keylines);
-  LinetrLineRec* out = emit(n_keep);
-  if (!out) return;
-  for (int64_t i = 0; i < n_keep; ++i) {
-    const KeptLine& kl = keep[order[order.size() - 1 - i].second];
-    LinetrLineRec r{};
-    r.sp[0] = kl.sp[0]; r.sp[1] = kl.sp[1]; r.ep[0] = kl.ep[0]; r.ep[1] = kl.ep[1]; r.length = kl.length;
-    angle_of(r);                                                                             // :20
-    out[i] = r;
-  }
-}
-
-extern "C" int linetr_prefilter(const double* L, int32_t K, int32_t height, int32_t width, int32_t border,
-                                double min_length, int32_t max_keylines, const double* vm, double td, int32_t T,
-                                int32_t image_index, int32_t sub_base, int32_t tok_base, LinetrLineRec* h_recs,
-                                int32_t capacity, int32_t* k_out, int32_t* n_out) {
-  if (K < 0 || (K > 0 && !L) || !k_out || !n_out) return fail(LINETR_E_ARG, "null argument");
-  int64_t n_sel = -1;
-  prefilter_core(L, K, height, width, border, min_length, max_keylines, vm, [&](int64_t n) -> LinetrLineRec* {
-    n_sel = n;
-    return n <= capacity ? h_recs : nullptr;
-  });
-  if (n_sel > capacity) return fail(LINETR_E_CAPACITY, "prefilter: %lld lines exceed capacity %d", (long long)n_sel, capacity);
-  int cur = sub_base, tcur = tok_base;
-  for (int64_t i = 0; i < n_sel; ++i)
-    if (int e = pack_one(h_recs[i], td, T, image_index, (int)i, cur, tcur)) return e;
-  *k_out = (int)n_sel;
-  *n_out = cur - sub_base;
-  return LINETR_OK;
-}
-
-extern "C" int linetr_prefilter_batch(const double* L, const int32_t* off, int32_t B, int32_t height, int32_t width,
-                                      int32_t border, double min_length, int32_t max_keylines,
-                                      const double* const* vms, double td, int32_t T, int32_t n_threads,
-                                      LinetrLineRec* h_recs, int32_t capacity, int32_t* cu_k, int32_t* cu_n) {
-  if (B < 0 || !off || !cu_k || !cu_n || (B > 0 && off[B] > 0 && !L)) return fail(LINETR_E_ARG, "null argument");
-  WorkPool& pool = WorkPool::get();
-  int nt = n_threads > 0 ? n_threads : pool.size();
-  nt = std::max(1, std::min(nt, B / 4));  // not worth a hand-off for fewer than 4 images per chunk
-  // contiguous chunks of images, a few per thread so that uneven images balance out
-  const int chunks = nt == 1 ? 1 : std::min(B, nt * 2);
-  cu_k[0] = cu_n[0] = 0;
-  int cur = 0, tcur = 0;
-  int64_t k = 0;
-  if (chunks == 1) {
-    // a single pair / a few images: no hand-off, and the survivors are written where they stay
-    for (int i = 0; i < B; ++i) {
-      int64_t n_sel = -1;
-      prefilter_core(L + (size_t)off[i] * 6, off[i + 1] - off[i], height, width, border, min_length, max_keylines,
-                     vms ? vms[i] : nullptr, [&](int64_t n) -> LinetrLineRec* {
-                       n_sel = n;
-                       return k + n <= capacity ? h_recs + k : nullptr;
-                     });
-      if (k + n_sel > capacity) return fail(LINETR_E_CAPACITY, "prefilter_batch: more than %d surviving lines", capacity);
-      for (int64_t j = 0; j < n_sel; ++j)
-        if (int e = pack_one(h_recs[k + j], td, T, i, (int)j, cur, tcur)) return e;
-      k += n_sel;
-      cu_k[i + 1] = (int)k;
-      cu_n[i + 1] = cur;
-    }
-    return LINETR_OK;
-  }
-  std::vector<std::vector<LinetrLineRec>> sel(B);
-  auto work = [&](int c) {
-    const int i0 = (int)((int64_t)B * c / chunks), i1 = (int)((int64_t)B * (c + 1) / chunks);
-    for (int i = i0; i < i1; ++i)
-      prefilter_core(L + (size_t)off[i] * 6, off[i + 1] - off[i], height, width, border, min_length, max_keylines,
-                     vms ? vms[i] : nullptr, [&](int64_t n) -> LinetrLineRec* {
-                       sel[i].resize(n);
-                       return sel[i].data();
-                     });
-  };
-  pool.run(chunks, work);
-  for (int i = 0; i < B; ++i) {
-    if (k + (int64_t)sel[i].size() > capacity)
-      return fail(LINETR_E_CAPACITY, "prefilter_batch: more than %d surviving lines", capacity);
-    for (size_t j = 0; j < sel[i].size(); ++j) {
-      if (int e = pack_one(sel[i][j], td, T, i, (int)j, cur, tcur)) return e;
-      h_recs[k++] = sel[i][j];
-    }
-    cu_k[i + 1] = (int)k;
-    cu_n[i + 1] = cur;
-  }
+  LT_LAUNCH_CHECK();
+  LT_HIP(hipDeviceSynchronize());
   return LINETR_OK;
 }
 
@@ -1617,261 +930,6 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
   return e;
 }
 
-// =============================================================================================
-// matcher
-// =============================================================================================
-
-namespace {
-// Pinned staging ring for the small host tables the matcher uploads (PairDesc array, identity maps).  A slot is
-// reused only after the copy that read it has completed (event), so no entry point has to synchronise the stream.
-struct PinnedRing {
-  struct Slot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; };
-  Slot slots[8];
-  int next = 0;
-  std::mutex m;
-  // returns a host pointer of >= bytes, or nullptr; *slot_out identifies the slot for commit()
-  void* acquire(size_t bytes, int* slot_out) {
-    std::lock_guard<std::mutex> lk(m);
-    Slot& s = slots[next];
-    *slot_out = next;
-    next = (next + 1) % 8;
-    if (s.busy) { (void)hipEventSynchronize(s.ev); s.busy = false; }
-    if (s.cap < bytes) {
-      if (s.p) (void)hipHostFree(s.p);
-      s.p = nullptr; s.cap = 0;
-      const size_t cap = std::max<size_t>(align_up((int64_t)bytes * 2, 4096), 16384);
-      if (hipHostMalloc(&s.p, cap, hipHostMallocDefault) != hipSuccess) { s.p = nullptr; return nullptr; }
-      s.cap = cap;
-    }
-    if (!s.ev && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { s.ev = nullptr; return nullptr; }
-    return s.p;
-  }
-  int commit(int slot, hipStream_t st) {   // call after the last async copy out of the slot has been enqueued
-    std::lock_guard<std::mutex> lk(m);
-    LT_HIP(hipEventRecord(slots[slot].ev, st));
-    slots[slot].busy = true;
-    return 0;
-  }
-};
-PinnedRing& staging_ring() {   // one ring per device (its events belong to the device current at creation); leaked: see WorkPool
-  static PinnedRing* rings[64] = {};
-  static std::mutex m;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  std::lock_guard<std::mutex> lk(m);
-  PinnedRing*& r = rings[dev & 63];
-  if (!r) r = new PinnedRing();
-  return *r;
-}
-
-// ints of argmin scratch one pair needs (layout in lt_match.h)
-int64_t pair_scratch_ints(int k0, int k1) { return 2 * (int64_t)k0 + 2 * (int64_t)k1 + 1 + 2 * (int64_t)cdiv(std::max(k0, 1), PM_ROWS) * k1 + 8; }
-}  // namespace
-
-extern "C" int64_t linetr_match_workspace_bytes(int32_t n_pairs, int64_t sum_n0n1, int64_t sum_k0k1, int64_t sum_k) {
-  (void)sum_k0k1;
-  // scratch bound: sum over pairs of pair_scratch_ints(k0,k1) <= 4 sum_k + 2 (sum_k0k1 / PM_ROWS + sum_k) + 9 P, and
-  // k0 k1 <= n0 n1
-  const int64_t scratch = 6 * sum_k + 2 * (sum_n0n1 / PM_ROWS + 1) + 9 * (int64_t)n_pairs;
-  return align_up((int64_t)n_pairs * sizeof(PairDesc), 256) + align_up(sum_n0n1 * 4, 256) + align_up(scratch * 4, 256) + 256;
-}
-
-extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* dims, const float* d_desc0,
-                                     const int64_t* off_n0, const int32_t* d_s2l0, const int64_t* off_s0,
-                                     const float* d_desc1, const int64_t* off_n1, const int32_t* d_s2l1,
-                                     const int64_t* off_s1, float thr, int32_t mutual, float* d_dk, const int64_t* off_dk,
-                                     int32_t* d_match01, const int64_t* off_k0, void* d_ws, int64_t ws_bytes, void* stream);
-
-extern "C" int linetr_match(LinetrHandle* h, int32_t P, const int32_t* dims, const float* d_desc0, const int64_t* off_n0,
-                            const int32_t* d_s2l0, const float* d_desc1, const int64_t* off_n1, const int32_t* d_s2l1,
-                            float thr, int32_t mutual, float* d_dk, const int64_t* off_dk, int32_t* d_match01,
-                            const int64_t* off_k0, void* d_ws, int64_t ws_bytes, void* stream) {
-  return linetr_match_gathered(h, P, dims, d_desc0, off_n0, d_s2l0, nullptr, d_desc1, off_n1, d_s2l1, nullptr, thr, mutual,
-                               d_dk, off_dk, d_match01, off_k0, d_ws, ws_bytes, stream);
-}
-
-extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* dims, const float* d_desc0,
-                                     const int64_t* off_n0, const int32_t* d_s2l0, const int64_t* off_s0,
-                                     const float* d_desc1, const int64_t* off_n1, const int32_t* d_s2l1,
-                                     const int64_t* off_s1, float thr, int32_t mutual, float* d_dk, const int64_t* off_dk,
-                                     int32_t* d_match01, const int64_t* off_k0, void* d_ws, int64_t ws_bytes, void* stream) {
-  if (P < 0) return fail(LINETR_E_ARG, "match: bad argument");
-  if (P == 0) return LINETR_OK;
-  if (!dims || !off_n0 || !off_n1 || !off_dk || !off_k0 || !d_ws) return fail(LINETR_E_ARG, "match: null argument");
-  hipStream_t st = (hipStream_t)stream;
-  if (h) LT_HIP(hipSetDevice(h->device));
-  PairTable tab{};
-  int slot = -1;
-  PairDesc* pd = tab.inl;
-  if (P > PT_INLINE) {
-    pd = (PairDesc*)staging_ring().acquire((size_t)P * sizeof(PairDesc), &slot);
-    if (!pd) return fail(LINETR_E_HIP, "match: pinned staging allocation failed");
-  } else {
-    tab.n_inline = P;
-  }
-  int64_t od = 0, os = 0, sum_k = 0;
-  int max_n0 = 0, max_n1 = 0, max_k1 = 0, max_chunks = 0;
-  double flops = 0;
-  for (int p = 0; p < P; ++p) {
-    PairDesc& d = pd[p];
-    d.n0 = dims[p * 4 + 0]; d.k0 = dims[p * 4 + 1]; d.n1 = dims[p * 4 + 2]; d.k1 = dims[p * 4 + 3];
-    if (d.n0 < 0 || d.n1 < 0 || d.k0 < 0 || d.k1 < 0 || d.k0 > d.n0 || d.k1 > d.n1)
-      return fail(LINETR_E_ARG, "match: bad dims for pair %d", p);
-    d.off_n0 = off_n0[p]; d.off_n1 = off_n1[p]; d.off_dk = off_dk[p]; d.off_k0 = off_k0[p];
-    d.off_s0 = off_s0 ? off_s0[p] : off_n0[p];
-    d.off_s1 = off_s1 ? off_s1[p] : off_n1[p];
-    d.off_d = od; od += (int64_t)d.n0 * d.n1;
-    d.chunks = cdiv(std::max(d.k0, 1), PM_ROWS);
-    d.pad_ = 0;
-    d.off_seg = os; os += pair_scratch_ints(d.k0, d.k1);
-    sum_k += d.k0 + d.k1;
-    max_n0 = std::max(max_n0, d.n0); max_n1 = std::max(max_n1, d.n1);
-    max_k1 = std::max(max_k1, d.k1); max_chunks = std::max(max_chunks, d.chunks);
-    flops += 2.0 * d.n0 * d.n1 * D;
-  }
-  if (ws_bytes < linetr_match_workspace_bytes(P, od, 0, sum_k)) return fail(LINETR_E_WORKSPACE, "match: workspace too small");
-  char* base = (char*)d_ws;
-  PairDesc* d_pd = (PairDesc*)base;
-  float* d_dist = (float*)(base + align_up((int64_t)P * sizeof(PairDesc), 256));
-  int* d_scr = (int*)((char*)d_dist + align_up(od * 4, 256));
-  if (slot >= 0) {
-    LT_HIP(hipMemcpyAsync(d_pd, pd, P * sizeof(PairDesc), hipMemcpyHostToDevice, st));
-    if (int e = staging_ring().commit(slot, st)) return e;
-    tab.ptr = d_pd;
-  }
-  if (max_n0 > 0 && max_n1 > 0) {
-    if (!d_desc0 || !d_desc1 || !d_s2l0 || !d_s2l1 || !d_dk) return fail(LINETR_E_ARG, "match: null tensor");
-    // (r03: one fused launch for a single pair -- every block computing its own strip of D, pooling it, the last
-    // arriver finishing -- was built and measured at 0.10 ms submit-to-done against 0.08 ms for these three launches: 13
-    // blocks walking 4 column tiles x 8 K steps of exposed load latency each lose to 16 + 13 + 1 blocks in parallel.)
-    ProfScope ps(h, st, "pair_dist", flops, 0);
-    hipLaunchKernelGGL(pair_dist_kernel, dim3(cdiv(max_n1, 64), cdiv(max_n0, 64), P), dim3(256), 0, st, tab, d_desc0,
-                       d_desc1, d_dist);
-    LT_LAUNCH_CHECK();
-  }
-  {
-    ProfScope ps(h, st, "pair_match", 0, 0);
-    if (max_k1 > 0) {
-      const int seg1_global = max_k1 > PM_MAX_K1;    // the reference has no limit (max_keylines / max_keypoints = -1)
-      hipLaunchKernelGGL(pair_pool_kernel, dim3(max_chunks, P), dim3(256),
-                         (size_t)((seg1_global ? 0 : max_k1) + PM_ROWS + 2) * sizeof(int), st, tab, d_s2l0, d_s2l1, d_dist, d_dk,
-                         d_scr, seg1_global);
-      LT_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(pair_final_kernel, dim3(P), dim3(256), 0, st, tab, thr, mutual, d_match01, d_scr);
-    LT_LAUNCH_CHECK();
-  }
-  return LINETR_OK;   // fully asynchronous: the pair table travels in the kernel arguments or in ring-owned pinned memory
-}
-
-extern "C" int linetr_match_points(LinetrHandle* h, const float* d0_cn, int32_t n0, const float* d1_cn, int32_t n1,
-                                   float thr, int32_t mutual, float* d_dist, int32_t* d_match01, void* d_ws,
-                                   int64_t ws_bytes, void* stream) {
-  if (n0 < 0 || n1 < 0) return fail(LINETR_E_ARG, "match_points: bad argument");
-  if (n0 == 0) return LINETR_OK;
-  hipStream_t st = (hipStream_t)stream;
-  if (h) LT_HIP(hipSetDevice(h->device));
-  // scratch: row-major copies + identity sub2line maps + the generic matcher's workspace
-  const int64_t need_t = align_up((int64_t)n0 * D * 4, 256) + align_up((int64_t)std::max(n1, 1) * D * 4, 256) +
-                         align_up((int64_t)n0 * 4, 256) + align_up((int64_t)std::max(n1, 1) * 4, 256);
-  const int64_t need_m = linetr_match_workspace_bytes(1, (int64_t)n0 * n1, 0, n0 + n1);
-  if (ws_bytes < need_t + need_m) return fail(LINETR_E_WORKSPACE, "match_points: workspace too small (need %lld)", (long long)(need_t + need_m));
-  char* base = (char*)d_ws;
-  float* r0 = (float*)base; base += align_up((int64_t)n0 * D * 4, 256);
-  float* r1 = (float*)base; base += align_up((int64_t)std::max(n1, 1) * D * 4, 256);
-  int* id0 = (int*)base; base += align_up((int64_t)n0 * 4, 256);
-  int* id1 = (int*)base; base += align_up((int64_t)std::max(n1, 1) * 4, 256);
-  {
-    int slot = 0;
-    const int m = std::max(n0, n1);
-    int* iota = (int*)staging_ring().acquire((size_t)m * sizeof(int), &slot);
-    if (!iota) return fail(LINETR_E_HIP, "match_points: pinned staging allocation failed");
-    std::iota(iota, iota + m, 0);
-    LT_HIP(hipMemcpyAsync(id0, iota, n0 * 4, hipMemcpyHostToDevice, st));
-    if (n1 > 0) LT_HIP(hipMemcpyAsync(id1, iota, n1 * 4, hipMemcpyHostToDevice, st));
-    if (int e = staging_ring().commit(slot, st)) return e;
-  }
-  hipLaunchKernelGGL(transpose_cn_kernel, dim3(cdiv(n0, 32), D / 32), dim3(32, 8), 0, st, d0_cn, r0, D, n0);
-  if (n1 > 0) hipLaunchKernelGGL(transpose_cn_kernel, dim3(cdiv(n1, 32), D / 32), dim3(32, 8), 0, st, d1_cn, r1, D, n1);
-  LT_LAUNCH_CHECK();
-  const int32_t dims[4] = {n0, n0, n1, n1};
-  const int64_t zero = 0;
-  return linetr_match(h, 1, dims, r0, &zero, id0, r1, &zero, id1, thr, mutual, d_dist, &zero, d_match01, &zero, base,
-                      ws_bytes - need_t, stream);
-}
-
-extern "C" int64_t linetr_match_distmat_workspace_bytes(int32_t n0, int32_t n1) {
-  n0 = std::max(n0, 0); n1 = std::max(n1, 0);
-  return 256 + align_up((int64_t)n0 * 4, 256) + align_up((int64_t)std::max(n1, 1) * 4, 256) +
-         align_up((int64_t)n0 * std::max(n1, 1) * 4, 256) + align_up(pair_scratch_ints(n0, n1) * 4, 256);
-}
-
-extern "C" int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_t n0, int32_t n1, float thr,
-                                    int32_t mutual, int32_t* d_match01, void* d_ws, int64_t ws_bytes, void* stream) {
-  if (n0 < 0 || n1 < 0) return fail(LINETR_E_ARG, "match_distmat: bad argument");
-  if (n0 == 0) return LINETR_OK;
-  hipStream_t st = (hipStream_t)stream;
-  if (h) LT_HIP(hipSetDevice(h->device));
-  // scratch: PairDesc | identity maps | Dk copy | argmin ints
-  const int64_t o_id0 = 256, o_id1 = o_id0 + align_up((int64_t)n0 * 4, 256);
-  const int64_t o_dk = o_id1 + align_up((int64_t)std::max(n1, 1) * 4, 256);
-  const int64_t o_scr = o_dk + align_up((int64_t)n0 * std::max(n1, 1) * 4, 256);
-  const int64_t need = linetr_match_distmat_workspace_bytes(n0, n1);
-  if (!d_ws || ws_bytes < need) return fail(LINETR_E_WORKSPACE, "match_distmat: workspace too small (need %lld)", (long long)need);
-  char* base = (char*)d_ws;
-  const int m = std::max(n0, n1);
-  int slot = 0;
-  int* iota = (int*)staging_ring().acquire((size_t)m * sizeof(int), &slot);
-  if (!iota) return fail(LINETR_E_HIP, "match_distmat: pinned staging allocation failed");
-  PairTable tab{};
-  tab.n_inline = 1;
-  PairDesc* pd = tab.inl;
-  pd->n0 = pd->k0 = n0; pd->n1 = pd->k1 = n1;
-  pd->chunks = cdiv(n0, PM_ROWS);
-  std::iota(iota, iota + m, 0);
-  LT_HIP(hipMemcpyAsync(base + o_id0, iota, n0 * 4, hipMemcpyHostToDevice, st));
-  if (n1 > 0) LT_HIP(hipMemcpyAsync(base + o_id1, iota, n1 * 4, hipMemcpyHostToDevice, st));
-  if (int e = staging_ring().commit(slot, st)) return e;
-  if (n1 > 0) {
-    const int seg1_global = n1 > PM_MAX_K1;
-    hipLaunchKernelGGL(pair_pool_kernel, dim3(pd->chunks, 1), dim3(256), (size_t)((seg1_global ? 0 : n1) + PM_ROWS + 2) * sizeof(int),
-                       st, tab, (const int*)(base + o_id0), (const int*)(base + o_id1), d_dist, (float*)(base + o_dk),
-                       (int*)(base + o_scr), seg1_global);
-    LT_LAUNCH_CHECK();
-  }
-  hipLaunchKernelGGL(pair_final_kernel, dim3(1), dim3(256), 0, st, tab, thr, mutual, d_match01, (int*)(base + o_scr));
-  LT_LAUNCH_CHECK();
-  return LINETR_OK;
-}
-
-extern "C" int linetr_superpoint_heads(LinetrHandle* h, const float* d_score_logits, const float* d_desc_raw, int32_t B,
-                                       int32_t Hc, int32_t Wc, float* d_dense_score, float* d_dense_desc_nhwc,
-                                       float* d_dense_desc_nchw, void* stream) {
-  if (B < 0 || Hc <= 0 || Wc <= 0) return fail(LINETR_E_ARG, "superpoint_heads: bad shape B=%d Hc=%d Wc=%d", B, Hc, Wc);
-  if (d_dense_score && !d_score_logits) return fail(LINETR_E_ARG, "superpoint_heads: score output without score logits");
-  if ((d_dense_desc_nhwc || d_dense_desc_nchw) && !d_desc_raw)
-    return fail(LINETR_E_ARG, "superpoint_heads: descriptor output without the raw descriptor head");
-  if (B == 0) return LINETR_OK;
-  if (h) LT_HIP(hipSetDevice(h->device));
-  hipStream_t st = (hipStream_t)stream;
-  const int HW = Hc * Wc;
-  const dim3 grid((unsigned)cdiv(HW, 64), (unsigned)B);
-  if (d_dense_desc_nhwc || d_dense_desc_nchw) {
-    const double by = (double)B * HW * D * 4.0 * (1 + (d_dense_desc_nhwc ? 1 : 0) + (d_dense_desc_nchw ? 1 : 0));
-    ProfScope ps(h, st, "sp_desc_head", 3.0 * B * HW * D, by);
-    static const int cells = LT_XENV("LINETR_SP_CELLS") ? atoi(LT_XENV("LINETR_SP_CELLS")) : 32;   // tuning aid
-    if (cells == 64) hipLaunchKernelGGL(sp_desc_head_kernel<64>, grid, dim3(256), 0, st, d_desc_raw, d_dense_desc_nhwc, d_dense_desc_nchw, HW);
-    else hipLaunchKernelGGL(sp_desc_head_kernel<32>, dim3((unsigned)cdiv(HW, 32), (unsigned)B), dim3(256), 0, st, d_desc_raw, d_dense_desc_nhwc, d_dense_desc_nchw, HW);
-    LT_LAUNCH_CHECK();
-  }
-  if (d_dense_score) {
-    ProfScope ps(h, st, "sp_score_head", 0, (double)B * HW * (65 + 64) * 4.0);
-    hipLaunchKernelGGL(sp_score_head_kernel, grid, dim3(256), 0, st, d_score_logits, d_dense_score, Hc, Wc);
-    LT_LAUNCH_CHECK();
-  }
-  return LINETR_OK;
-}
-
 extern "C" int linetr_debug_posenc(LinetrHandle* h, int32_t which, const float* d_in0, const float* d_in1,
                                       const float* d_in2, int64_t rows, float* d_out, void* stream) {
   if (!h || !d_in0 || !d_in1 || !d_out || (which == 1 && !d_in2) || which < 0 || which > 1)
@@ -1984,67 +1042,3 @@ extern "C" int linetr_debug_mlp_stamps(unsigned long long* out) {   // debug bui
   return LINETR_OK;
 }
 #endif
-
-// =============================================================================================
-// multi-GPU collective (C-ABI form of parallel.allgather_descriptors)
-// =============================================================================================
-
-extern "C" int linetr_allgather_desc(void* nccl_comm, const void* d_slab, void* d_out, int64_t slab_bytes, void* stream) {
-  if (!nccl_comm || !d_slab || !d_out || slab_bytes <= 0) return fail(LINETR_E_ARG, "allgather_desc: bad argument");
-  // ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t, ncclComm_t, hipStream_t)
-  typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
-  static allgather_fn fn = nullptr;
-  static std::mutex mu;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    if (!fn) {
-      void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
-      for (const char* name : {"librccl.so", "librccl.so.1"}) {
-        if (sym) break;
-        if (void* lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD)) sym = dlsym(lib, "ncclAllGather");   // only an ALREADY loaded RCCL
-      }
-      fn = reinterpret_cast<allgather_fn>(sym);
-    }
-  }
-  if (!fn) return fail(LINETR_E_HIP, "allgather_desc: no RCCL (ncclAllGather) is loaded in this process");
-  const int rc = fn(d_slab, d_out, (size_t)slab_bytes, /*ncclChar*/ 0, nccl_comm, (hipStream_t)stream);
-  if (rc != 0) return fail(LINETR_E_HIP, "allgather_desc: ncclAllGather failed with ncclResult_t %d", rc);
-  return LINETR_OK;
-}
-
-// =============================================================================================
-// profiling
-// =============================================================================================
-
-extern "C" int linetr_set_profiling(LinetrHandle* h, int32_t on) {
-  if (!h) return fail(LINETR_E_ARG, "null handle");
-  for (auto& p : h->pending) { h->event_pool.push_back(p.a); h->event_pool.push_back(p.b); }
-  h->pending.clear();
-  h->classes.clear();
-  h->profiling = on != 0;
-  return LINETR_OK;
-}
-
-extern "C" int linetr_get_profile(LinetrHandle* h, LinetrProfileEntry* out, int32_t max_entries, int32_t* n_out) {
-  if (!h || !n_out) return fail(LINETR_E_ARG, "null argument");
-  LT_HIP(hipSetDevice(h->device));
-  for (auto& p : h->pending) {
-    LT_HIP(hipEventSynchronize(p.b));
-    float ms = 0.f;
-    LT_HIP(hipEventElapsedTime(&ms, p.a, p.b));
-    h->classes[p.cls].ms += ms;
-    h->event_pool.push_back(p.a);
-    h->event_pool.push_back(p.b);
-  }
-  h->pending.clear();
-  const int n = std::min<int>((int)h->classes.size(), max_entries);
-  for (int i = 0; i < n; ++i) {
-    out[i].name = h->classes[i].name;
-    out[i].calls = h->classes[i].calls;
-    out[i].ms = h->classes[i].ms;
-    out[i].flops = h->classes[i].flops;
-    out[i].bytes = h->classes[i].bytes;
-  }
-  *n_out = (int)h->classes.size();
-  return LINETR_OK;
-}

@@ -73,6 +73,14 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- device helpers -------------------------------------------------------------------------
 
+// constants of the CLS-row attention pooling (lt_model.h: the cls_pool kernels; prepared in float64 by linetr_create)
+struct ClsPoolConst {
+  const float* U;     // [4][256]  u_h
+  const float* U2;    // [4][256]  W5^T u_h
+  float c_tok[4];     // u_h.b5 + c_h   (additive constant of token rows)
+  float s_cls[4];     // u_h.cls + c_h  (score of the CLS key, row 0)
+};
+
 constexpr float LOG2E = 1.44269504088896340736f;
 
 // Wave-wide reductions on the VALU's DPP paths (no LDS crossbar): xor-1 / xor-2 inside quads, half-row and row

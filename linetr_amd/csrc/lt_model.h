@@ -269,12 +269,6 @@ __global__ __launch_bounds__(256) void mlp123_kernel(const float* __restrict__ p
 // One 256-thread block per sub-line.
 //   pooled[n][h] = [ sum_j p_hj desc_j (256) | sum_j p_hj a4_j (256) | p_h0 | 0 x31 ]
 // ---------------------------------------------------------------------------------------------
-struct ClsPoolConst {
-  const float* U;     // [4][256]  u_h
-  const float* U2;    // [4][256]  W5^T u_h
-  float c_tok[4];     // u_h.b5 + c_h   (additive constant of token rows)
-  float s_cls[4];     // u_h.cls + c_h  (score of the CLS key, row 0)
-};
 
 __global__ __launch_bounds__(256) void cls_pool_kernel(const float* __restrict__ desc /*[N][T][256]*/,
                                                        const float* __restrict__ a4 /*[N*T][256]*/, int T,

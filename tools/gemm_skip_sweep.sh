@@ -10,7 +10,7 @@ if [ "$1" = build ]; then
   rm -f tools/liblinetr_skip*.so
   for n in "${masks[@]}"; do
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DLT_GEMM_DEBUG_SKIP=$n -Iinclude \
-      -o tools/liblinetr_skip$n.so linetr_amd/csrc/linetr_hip.hip 2>&1 | grep -E " error|undefined" &
+      -o tools/liblinetr_skip$n.so linetr_amd/csrc/linetr_core.hip linetr_amd/csrc/linetr_net.hip linetr_amd/csrc/linetr_match.hip 2>&1 | grep -E " error|undefined" &
   done; wait
 else
   for shape in ${SHAPES:-8192x4096x4096}; do for m in ${MODES:-bf16x6 bf16x3}; do for n in "${masks[@]}"; do

@@ -1,8 +1,9 @@
 """Registers / LDS / residency of every kernel in the shipped library, from the code-object metadata (no GPU needed).
     python tools/resource_table.py [filter ...]
-Compiles linetr_amd/csrc/linetr_hip.hip with -save-temps into a scratch directory and prints one line per kernel:
+Compiles every translation unit linetr_amd/csrc/linetr_*.hip with -save-temps into a scratch directory and prints one line per kernel:
 threads, VGPRs (incl. AGPRs), spilled VGPRs, static LDS bytes (dynamic LDS is set by the launchers) and the waves per SIMD
 the register count allows (512 registers per lane and SIMD, allocated in blocks of 8).  Behind DESIGN.md section 4.2."""
+import glob
 import os
 import re
 import subprocess
@@ -15,11 +16,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     filters = sys.argv[1:]
     with tempfile.TemporaryDirectory() as tmp:
-        src = os.path.join(ROOT, "linetr_amd", "csrc", "linetr_hip.hip")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                        "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-save-temps", "-o", "lib.so", src],
-                       cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        asm = open(os.path.join(tmp, "linetr_hip-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+        asm = ""
+        for src in sorted(glob.glob(os.path.join(ROOT, "linetr_amd", "csrc", "linetr_*.hip"))):
+            stem = os.path.splitext(os.path.basename(src))[0]
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
+                            "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-save-temps", "-o", stem + ".o", src],
+                           cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            asm += open(os.path.join(tmp, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     items = re.findall(r"- \.agpr_count:.*?\.wavefront_size:\s+\d+", asm, flags=re.S)
     names, rows = [], []
     for it in items:
