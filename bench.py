@@ -37,7 +37,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from linetr_amd import parallel, synth  # noqa: E402
+from linetr_amd import parallel
+from workloads import synth  # noqa: E402
 from linetr_amd.engine import Engine  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
@@ -440,17 +441,18 @@ def sub_workload(eng, name, device, settle_s, repeat=1, brief=False):
     own short settle), with its dominant kernel.  repeat > 1: the workload's default batch repeated that many times
     (BASELINE.json names no batch size for cfg5; the default of 8 pairs leaves two thirds of the CUs without a GEMM tile)."""
     H, W, n_lines, lo, hi, T, pairs = WORKLOADS[name]
-    lines, _dd, nhwc, ds, hw, T = make_inputs(name, pairs, 0, device, eng)
-    del _dd
+    lines, dd_nchw, nhwc, ds, hw, T = make_inputs(name, pairs, 0, device, eng)
+    if pairs != 1:
+        del dd_nchw
     if repeat > 1:
         lines, nhwc, ds, pairs = lines * repeat, nhwc.repeat(repeat, 1, 1, 1), ds.repeat(repeat, 1, 1), pairs * repeat
-    pipe = Pipeline(eng, lines, nhwc, ds, hw, T, 1, pairs)
+    pipe = Pipeline(eng, lines, nhwc, ds, hw, T, 1, pairs)      # sub-workloads are fed the producer's channel-last map (stated in "workload")
     sync = torch.cuda.synchronize
     settle(pipe.step, sync, min_s=settle_s, max_s=max(settle_s * 3, 1.0))
     steps = 20
     elapsed, per_step, host_ms, (tb, ld, _g) = timed_steps(pipe.step, sync, steps, device)
     prof, tot = profile_steps(eng, pipe.describe)
-    out = {"workload": f"{name}: {pairs} pair(s) of {W}x{H}, {n_lines} lines/image -> {int(tb.N / (2 * pairs))} sub-lines x {T} tokens",
+    out = {"workload": f"{name}: {pairs} pair(s) of {W}x{H}, {n_lines} lines/image -> {int(tb.N / (2 * pairs))} sub-lines x {T} tokens, fed the channel-last map",
            "descriptors_per_step": int(tb.N), "value": round(tb.N * steps / elapsed, 1), "unit": "line-descriptors/s",
            "ms_per_step": round(elapsed / steps * 1e3, 4), "ms_per_step_median": round(float(np.median(per_step)), 4),
            "host_ms_per_step": round(float(np.median(host_ms)), 4), "gpu_ms_per_step_profiled": round(tot / 3, 4),
@@ -461,8 +463,14 @@ def sub_workload(eng, name, device, settle_s, repeat=1, brief=False):
         for k in ("kernels", "host_ms_per_step", "gpu_ms_per_step_profiled"):
             out.pop(k, None)
         out["inputs"] = f"the {pairs // repeat}-pair set repeated {repeat}x"
+    if not brief:        # argmin margins of this workload's own matches
+        margs = pipe.match_args(tb, ld)
+        dk, off_dk, m01, _ok0 = eng.match_offsets(*margs, LINE_CFG["nn_threshold"], True)
+        out["argmin"] = argmin_margins(dk, off_dk, margs[2])
+        out["matches_per_step"] = int((m01 >= 0).sum().item())
     if pairs == 1:      # single pair: strict latency (submit, wait, repeat) of describe and of describe + match
         margs = pipe.match_args(tb, ld)
+        out["oracle_check"] = oracle_check_pair(lines, dd_nchw, ds, hw, T, ld, tb, m01, dk)
         lat, lat_m = [], []
         for _ in range(5):
             pipe.describe(); eng.match_offsets(*margs, LINE_CFG["nn_threshold"], True)
@@ -499,8 +507,151 @@ def sub_workload(eng, name, device, settle_s, repeat=1, brief=False):
             lat_m.append(t3 - t2)
         out["pair_latency_polled_ms"] = round(float(np.median(lat)) * 1e3, 4)
         out["pair_match_latency_polled_ms"] = round(float(np.median(lat_m)) * 1e3, 4)
+        out["dropin"] = dropin_pair_section(device, lines, dd_nchw, nhwc, ds, hw, T)
     del pipe, lines, nhwc, ds
     return out
+
+
+def argmin_margins(dk, off_dk, dims):
+    """Best-vs-second-best gap of every row and every column of each pair's key-line distance matrix Dk (SURVEY.md section 7,
+    "hard parts": an argmin is only as stable as its margin).  Returns the smallest gap over the batch and how many gaps are
+    below 1e-5 (the descriptors agree with the reference to ~4e-7, i.e. distances to ~1e-6)."""
+    mins, small, n = [], 0, 0
+    for p in range(len(dims)):
+        k0, k1 = int(dims[p][1]), int(dims[p][3])
+        if k0 < 1 or k1 < 1:
+            continue
+        d = dk[int(off_dk[p]):int(off_dk[p + 1])].view(k0, k1).clamp(min=0)
+        for m in (d, d.t()):
+            if m.shape[1] < 2:
+                continue
+            two = torch.topk(m, 2, dim=1, largest=False).values
+            gap = two[:, 1] - two[:, 0]
+            mins.append(gap.min())
+            small += int((gap < 1e-5).sum().item())
+            n += gap.numel()
+    return {"min_argmin_margin": float(torch.stack(mins).min().item()) if mins else None, "margins_below_1e-5": small,
+            "argmins_checked": n}
+
+
+def oracle_check_pair(lines, dd_nchw, ds, hw, T, ld, tb, m01, dk):
+    """cfg2 only, outside every timed region: the pair's descriptors and line matches against the CPU oracle on the same
+    inputs (the oracle is the checker here, never the thing measured)."""
+    from oracle import linetr_oracle as O
+    sd = synth.to_torch_state_dict(synth.calibrated_state_dict())
+    cfg = dict(LINE_CFG, max_tokens=T)
+    outs = []
+    with torch.no_grad():
+        for i in range(2):
+            o = O.preprocess(synth.array_to_keylines(lines[i]), (1, 1, *hw), dd_nchw[i:i + 1].cpu(), ds[i:i + 1].cpu(), cfg)
+            outs.append(O.forward(sd, o, hw))
+        M, Dk = O.match_lines(outs[0]["line_desc"], outs[1]["line_desc"], outs[0]["mat_klines2sublines"][0],
+                              outs[1]["mat_klines2sublines"][0], LINE_CFG["nn_threshold"])
+    ld_c, cu = ld.cpu().numpy(), tb.cu_n
+    err = max(float(np.abs(ld_c[cu[i]:cu[i + 1]].T - outs[i]["line_desc"][0].numpy()).max()) for i in range(2))
+    got = np.zeros_like(M[0])
+    m = m01.cpu().numpy()
+    got[np.nonzero(m >= 0)[0], m[m >= 0]] = 1
+    return {"matches_identical_to_oracle": bool(np.array_equal(got, M[0])), "matches": int(got.sum()),
+            "max_abs_desc_err_vs_oracle": err, "max_abs_dk_err_vs_oracle": float(np.abs(dk.cpu().numpy().reshape(Dk[0].shape) - Dk[0]).max())}
+
+
+class _StubSuperPoint(torch.nn.Module):
+    """Stands where SuperPoint stands in Matching (models/matching.py:20-22, out of the metric): hands back dense maps and
+    key points that already sit in HBM, so that what is timed is the line branch of the reference call surface."""
+
+    def __init__(self, outs):
+        super().__init__()
+        self.outs, self.i, self.config = outs, 0, {"nn_threshold": 0.7}
+
+    def forward(self, data):
+        o = self.outs[self.i % len(self.outs)]
+        self.i += 1
+        return dict(o)
+
+
+class _StubLSD:
+    def __init__(self, klines):
+        self.klines, self.i = klines, 0
+
+    def detect_torch(self, image):
+        k = self.klines[self.i % len(self.klines)]
+        self.i += 1
+        return k
+
+
+def dropin_pair_section(device, lines, dd_nchw, dd_nhwc, ds, hw, T, n_kp=512):
+    """What the reference's own scripts pay per pair (match_line_pairs.py:90, demo_LineTR.py:207): the calls of the
+    `models.*` import path -- LineTransformer.preprocess + forward for both images and Matching.match_lines -- with the
+    detector's KeyLines and SuperPoint's maps injected (both out of the metric).  Wall time, one synchronisation at the end
+    (match_lines returns NumPy arrays, like the reference)."""
+    from models.matching import Matching         # the shim package: the import path of the reference's scripts
+    H, W = hw
+    g = torch.Generator(device=device).manual_seed(5)
+    klines = [synth.array_to_keylines(l) for l in lines[:2]]
+
+    def sp_out(i, nhwc):
+        kp = torch.rand(n_kp, 2, device=device, generator=g) * torch.tensor([W - 1.0, H - 1.0], device=device)
+        de = torch.nn.functional.normalize(torch.randn(256, n_kp, device=device, generator=g), dim=0)
+        o = {"keypoints": [kp], "scores": (torch.rand(n_kp, device=device, generator=g),), "descriptors": [de],
+             "dense_descriptor": dd_nchw[i:i + 1], "dense_score": ds[i:i + 1]}
+        if nhwc:
+            o["dense_descriptor_nhwc"] = dd_nhwc[i:i + 1]
+        return o
+
+    res = {}
+    img = torch.zeros(1, 1, H, W, device=device)
+    for tag, nhwc in (("", False), ("_fed_nhwc", True)):
+        m = Matching({"auto_min_length": False, "linetransformer": {"mode": "train", "max_tokens": T, "image_shape": [H, W],
+                                                                    **{k: LINE_CFG[k] for k in ("min_length", "token_distance", "remove_borders", "max_keylines", "nn_threshold")}}},
+                     superpoint=_StubSuperPoint([sp_out(0, nhwc), sp_out(1, nhwc)]), lsd=_StubLSD(klines))
+        m.linetransformer.load_state_dict(synth.to_torch_state_dict(synth.calibrated_state_dict()), strict=True)
+        m = m.to(device).eval()
+        lt = m.linetransformer
+        sp = [sp_out(0, nhwc), sp_out(1, nhwc)]
+        shape = (1, 1, H, W)
+
+        def line_branch():
+            o = [lt(lt.preprocess(klines[i], shape, sp[i], img)) for i in range(2)]
+            return m.match_lines(o[0]["line_desc"], o[0]["mat_klines2sublines"], o[1]["line_desc"], o[1]["mat_klines2sublines"],
+                                 lt.config["nn_threshold"])
+
+        def full_forward():
+            return m({"image0": img, "image1": img})
+
+        with torch.no_grad():
+            for fn, key in ((line_branch, "dropin_pair" + tag + "_ms"), (full_forward, "dropin_matching_forward" + tag + "_ms")):
+                for _ in range(5):
+                    fn()
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(20):
+                    t0 = time.perf_counter()
+                    r = fn()
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                res[key] = round(float(np.median(ts)) * 1e3, 4)
+            if not nhwc:
+                ml = line_branch()[0]
+                res["dropin_matches"] = int(ml.sum())
+                # where the wall time goes: host-only part of preprocess (NumPy glue + record packing), and the GPU's share
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    from models.line_process import change_cv2_T_np, filter_by_length, remove_borders
+                    kl = filter_by_length(remove_borders(change_cv2_T_np(klines[0]), LINE_CFG["remove_borders"], H, W, None),
+                                          LINE_CFG["min_length"], LINE_CFG["max_keylines"])
+                res["dropin_host_numpy_glue_ms_per_image"] = round((time.perf_counter() - t0) / 10 * 1e3, 4)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    line_branch()
+                e1.record()
+                torch.cuda.synchronize()
+                res["dropin_pair_hip_event_ms"] = round(e0.elapsed_time(e1) / 10, 4)
+    res["dropin_note"] = ("LineTransformer.preprocess + forward x2 + Matching.match_lines through `from models.matching import Matching` "
+                          "(KeyLines and SuperPoint maps injected, both outside the metric); *_fed_nhwc: the producer also hands out the "
+                          f"channel-last map (FusedHeadSuperPoint); dropin_matching_forward adds the point matcher on {n_kp} key points per image")
+    return res
 
 
 # =====================================================================================================================
@@ -701,11 +852,14 @@ def main():
     ap.add_argument("--precision", default="bf16x6", choices=["f32", "bf16x6", "bf16x3", "f16x3"],
                     help="MFMA path of the dense contractions (bf16x6 = fp32-faithful split, the default)")
     ap.add_argument("--streams", type=int, default=1, help="independent sub-batches run on this many HIP streams")
-    ap.add_argument("--dense-layout", default="nhwc", choices=["nhwc", "nchw"],
-                    help="layout of the resident dense descriptor map (nhwc = what the repo's producer emits)")
+    ap.add_argument("--dense-layout", default="nchw", choices=["nhwc", "nchw"],
+                    help="layout of the resident dense descriptor map: nchw = the reference's 'dense_descriptor' (models/superpoint.py:193; "
+                         "the metric's input, SURVEY 8d), nhwc = what the repo's own producer emits (reported beside it as value_fed_nhwc)")
     ap.add_argument("--settle-s", type=float, default=2.0, help="minimum seconds of load before anything is timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt-precisions", action="store_true")
+    ap.add_argument("--alt-precisions", action="store_true",
+                    help="also time the step in the other MFMA modes (their fast kernels differ from bf16x6's: not a like-for-like "
+                         "cost of the six products, so no longer part of the default line)")
     ap.add_argument("--no-sub-workloads", action="store_true", help="skip the cfg2 / cfg5 sub-objects")
     ap.add_argument("--cpu-budget", type=float, default=14.0)
     ap.add_argument("--pairs-total", type=int, default=1024, help="cfg4: pairs of the whole job")
@@ -839,6 +993,7 @@ def main():
     torch.cuda.synchronize()
     pair_match_ms = (time.perf_counter() - t0) / reps / pairs * 1e3
     n_matches = int((m01 >= 0).sum().item())
+    argmin = argmin_margins(dk, off_dk, margs[2])
     # ... and for ONE pair at a time (latency of get_dist_matrix + subline2keyline + nn_matcher_distmat)
     one_args = (margs[0], margs[1], margs[2][:1], margs[3][:1], margs[4][:1], margs[5][:1], margs[6][:1])
     for _ in range(3):
@@ -879,9 +1034,10 @@ def main():
         "config": {"workload": f"{args.workload}: {pairs} pairs/GPU of {W}x{H}, {n_lines} lines/image -> "
                                f"{int(tb.N / n_img)} sub-lines x {T} tokens, d_model=256, seeded weights",
                    "pairs_per_gpu": pairs, "descriptors_per_step": int(n_desc_step),
-                   "dense_layout": args.dense_layout + (" (channel-last map as the repo's producer linetr_superpoint_heads emits it; the step "
-                                                        "fed with the reference's NCHW map is ms_per_step_fed_nchw / value_fed_nchw)"
-                                                        if args.dense_layout == "nhwc" else ""),
+                   "dense_layout": args.dense_layout + (" (the reference's 'dense_descriptor' [B,256,H/8,W/8]: the step includes the layout pass; "
+                                                        "fed with the channel-last map the repo's producer linetr_superpoint_heads emits it is "
+                                                        "ms_per_step_fed_nhwc / value_fed_nhwc)" if args.dense_layout == "nchw" else
+                                                        " (channel-last map of the repo's own producer; the reference's layout: value_fed_nchw)"),
                    "collective": "all_gather(line_desc + counts + key-line maps)" if world > 1 else "none"},
         "ms_per_step_median": round(float(np.median(per_step)), 4), "ms_per_step_p10": round(float(np.percentile(per_step, 10)), 4),
         "ms_per_step_p90": round(float(np.percentile(per_step, 90)), 4),
@@ -895,7 +1051,7 @@ def main():
         "collective_backend": (None if world == 1 else os.environ.get("LINETR_BENCH_BACKEND", "nccl")),
         "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and hasattr(torch.cuda, "nccl") else None),
         "pair_match_ms": round(pair_match_ms, 4), "pair_match_latency_ms": round(pair_match_latency_ms, 4),
-        "matches_per_step": n_matches,
+        "matches_per_step": n_matches, "argmin": argmin,
         "whole_step": {**whole_step_executed(prof, prof_steps, ms_per_step),
                        "survey_algorithmic_gflop_per_step": round(alg_flops_step / 1e9, 1),
                        "survey_note": "SURVEY 8(d)'s formula counts the reference's graph; exact algebra (K-projection fold, "
@@ -917,7 +1073,7 @@ def main():
         out[f"ms_per_step_fed_{other}"] = round((time.perf_counter() - t0) / 10 * 1e3, 4)
         out[f"value_fed_{other}"] = round(n_desc_step / out[f"ms_per_step_fed_{other}"] * 1e3, 1)
         out["producer"] = producer_section(eng, H, W, n_img)
-    if world == 1 and not args.no_alt_precisions:   # the same step in the other MFMA modes (few steps each), for reference
+    if world == 1 and args.alt_precisions:   # the same step in the other MFMA modes (few steps each); opt-in
         alt = {}
         for mode in ("bf16x3", "f16x3", "bf16x6", "f32"):
             if mode == args.precision:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LINETR_ABI_VERSION 2
+#define LINETR_ABI_VERSION 3
 
 enum {
   LINETR_OK = 0,
@@ -79,6 +79,9 @@ typedef struct {
   float* angle_sub;   /* [N,2]     angle_sublines                                   */
   float* desc;        /* [N,T,256] desc_sublines                                    */
   float* score;       /* [N,T]     score_sublines                                   */
+  float* mat;         /* [K,N]     mat_klines2sublines (models/line_process.py:160-165): 1/num_sublines over a key-line's own */
+                      /*           sub-lines, 0 elsewhere.  Optional (NULL = not written); single-image calls only -- it is    */
+                      /*           written by extra blocks of the tokeniser's own launch                                    */
 } LinetrTokens;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -106,7 +109,9 @@ void linetr_destroy(LinetrHandle* h);
  * Writes up to `capacity` records (first_sub/n_tok/n_sub/image filled as by linetr_pack_lines;
  * `sub_base` / `tok_base` = number of sub-lines / real tokens of the images that precede this one in the batch) and
  * returns K' in *k_out, the number of sub-lines of this image in *n_out.  LINETR_E_ASSERT if a token distance
- * exceeds the geometric line length (the reference's AssertionError, line_process.py:44-45). */
+ * exceeds the geometric line length (the reference's AssertionError, line_process.py:44-45).
+ * Survivors are written straight into h_recs: on ANY error return the contents of h_recs are unspecified (the same holds
+ * for linetr_prefilter_batch). */
 int linetr_prefilter(const double* h_lines6, int32_t K, int32_t height, int32_t width, int32_t border,
                      double min_length, int32_t max_keylines, const double* h_valid_mask,
                      double token_distance, int32_t max_tokens, int32_t image_index, int32_t sub_base,
@@ -142,12 +147,21 @@ int64_t linetr_tokenize_workspace_bytes(int32_t n_images, int32_t height, int32_
  * linetr_superpoint_heads emits: no layout pass), d_dense_score [B,height,width].  The end-point clip of line_process.py:114-116 is applied, and
  * the clipped end points are what `out.klines` holds (reference quirk: it mutates through a view).
  * d_sub2line [N] int32 (key-line index of every sub-line INSIDE ITS IMAGE, non-decreasing per image)
- * is written for linetr_match.  `out.desc` may be NULL to skip descriptor sampling. */
+ * is written for linetr_match.  `out.desc` may be NULL to skip descriptor sampling.  `h` may be NULL (no weights are
+ * involved; the current HIP device is used). */
 int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N,
                     double token_distance, int32_t max_tokens, const float* d_dense_desc,
                     const float* d_dense_score, int32_t n_images, int32_t height, int32_t width,
                     int32_t align_corners, int32_t dense_is_nhwc, LinetrTokens out, int32_t* d_sub2line,
                     void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* sample_descriptors (models/line_process.py:86-98) on its own, for the module-level function of the shim: n points
+ * d_points [n,2] (x,y in pixels) of ONE image sampled bilinearly (zero padding) from its dense descriptor map
+ * ([256,Hc,Wc], or [Hc,Wc,256] with dense_is_nhwc) and L2-normalised; d_out [n,256] row-major.  `h` may be NULL. */
+int64_t linetr_sample_descriptors_workspace_bytes(int32_t Hc, int32_t Wc, int32_t dense_is_nhwc);
+int linetr_sample_descriptors(LinetrHandle* h, const float* d_points, int64_t n, const float* d_dense_desc, int32_t Hc,
+                              int32_t Wc, int32_t align_corners, int32_t dense_is_nhwc, float* d_out, void* d_workspace,
+                              int64_t workspace_bytes, void* stream);
 
 /* ---- device: descriptor network ------------------------------------------------------------- */
 
@@ -224,6 +238,14 @@ int64_t linetr_match_distmat_workspace_bytes(int32_t n0, int32_t n1);
 int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_t n0, int32_t n1, float nn_thresh,
                          int32_t mutual, int32_t* d_match01, void* d_workspace, int64_t workspace_bytes,
                          void* stream);
+
+/* LineTransformer.subline2keyline (models/line_transformer.py:277-282) alone: Dk [k0,k1] = A0 D A1^T for a sub-line distance
+ * matrix d_dist [n0,n1] that already lives on the device, the two mat_klines2sublines given as the sub-line -> key-line maps
+ * linetr_tokenize writes (non-decreasing; rows of A are 1/num_sublines).  `h` may be NULL.  Asynchronous on `stream`. */
+int64_t linetr_pool_distmat_workspace_bytes(int32_t k0, int32_t k1);
+int linetr_pool_distmat(LinetrHandle* h, const float* d_dist, int32_t n0, int32_t n1, const int32_t* d_sub2line0, int32_t k0,
+                        const int32_t* d_sub2line1, int32_t k1, float* d_dk, void* d_workspace, int64_t workspace_bytes,
+                        void* stream);
 
 /* nn_matcher (models/nn_matcher.py:33-42): point-descriptor variant, desc given [256,n] column-major
  * like SuperPoint's `descriptors` -- section 8(f) "next" row, same kernels. */
@@ -309,6 +331,22 @@ int linetr_debug_gemm_st(LinetrHandle* h, const void* d_A1, int32_t K1, const vo
  * /opt/rocm's librccl.so); LINETR_E_HIP if none is loaded.  No reference counterpart (BASELINE.json cfg4); asynchronous
  * on `stream`.  linetr_match_gathered then matches straight out of d_out. */
 int linetr_allgather_desc(void* nccl_comm, const void* d_slab, void* d_out, int64_t slab_bytes, void* stream);
+
+/* The ncclAllGather to call.  A process can hold two RCCL copies (PyTorch's bundled one and /opt/rocm's); the function must
+ * come from the copy that created `nccl_comm`, so a caller that knows which one that is hands its ncclAllGather in here
+ * (dlsym on its own library handle).  Without this call linetr_allgather_desc takes the first ncclAllGather the process-wide
+ * symbol resolution finds -- correct when only one RCCL is loaded.  NULL resets to that default. */
+int linetr_set_allgather_fn(void* nccl_allgather_fn);
+
+/* One rank's slab for that all-gather in ONE launch (the layout linetr_amd/parallel.py documents and GatheredSet /
+ * linetr_match_gathered read): float32 [hr + mr + rows_cap][256] = int32 header {n_images, sub-lines per image[cap],
+ * key-lines per image[cap]} | int32 sub2line[rows_cap] | line_desc rows, with hr = ceil((1 + 2 cap) / 256) and
+ * mr = ceil(rows_cap / 256).  The counts are taken from the DEVICE prefix sums d_cu_n / d_cu_k [n_images + 1] (what
+ * linetr_describe leaves there), so nothing is copied from the host; d_cu_k / d_sub2line may be NULL.  zero_tail != 0 also
+ * clears the descriptor rows N .. rows_cap.  LINETR_E_CAPACITY if the batch does not fit.  No reference counterpart. */
+int linetr_pack_slab(const float* d_line_desc, int32_t N, const int32_t* d_cu_n, const int32_t* d_cu_k, int32_t n_images,
+                     const int32_t* d_sub2line, int32_t n_images_cap, int32_t rows_cap, int32_t zero_tail, float* d_slab,
+                     void* stream);
 
 /* ---- instrumentation ------------------------------------------------------------------------ */
 

@@ -37,7 +37,7 @@ assert REC_DTYPE.itemsize == C.sizeof(LineRec) == 80
 
 class Tokens(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("klines", "length", "angles", "sublines", "pnt", "mask", "resp",
-                                          "angle_sub", "desc", "score")]
+                                          "angle_sub", "desc", "score", "mat")]
 
 
 class ProfileEntry(C.Structure):
@@ -104,9 +104,17 @@ def lib(path=None):
         L.linetr_debug_from_st.argtypes = [vp, vp, i32, i32, vp, i32, vp]
         L.linetr_debug_gemm_st.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.linetr_allgather_desc.argtypes = [vp, vp, vp, i64, vp]
+    L.linetr_set_allgather_fn.argtypes = [vp]
+    L.linetr_pack_slab.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, i32, vp, vp]
+    L.linetr_sample_descriptors_workspace_bytes.argtypes = [i32, i32, i32]
+    L.linetr_sample_descriptors_workspace_bytes.restype = i64
+    L.linetr_sample_descriptors.argtypes = [vp, vp, i64, vp, i32, i32, i32, i32, vp, vp, i64, vp]
+    L.linetr_pool_distmat_workspace_bytes.argtypes = [i32, i32]
+    L.linetr_pool_distmat_workspace_bytes.restype = i64
+    L.linetr_pool_distmat.argtypes = [vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, i64, vp]
     L.linetr_set_profiling.argtypes = [vp, i32]
     L.linetr_get_profile.argtypes = [vp, C.POINTER(ProfileEntry), i32, C.POINTER(i32)]
-    if L.linetr_abi_version() != 2:
+    if L.linetr_abi_version() != 3:
         raise RuntimeError("liblinetr_hip.so ABI version mismatch")
     _libs[path] = L
     return L
@@ -115,7 +123,8 @@ def lib(path=None):
 EXPORTS = ["linetr_abi_version", "linetr_last_error", "linetr_create", "linetr_destroy", "linetr_prefilter",
            "linetr_prefilter_batch", "linetr_pack_lines", "linetr_tokenize_workspace_bytes", "linetr_tokenize", "linetr_forward_workspace_bytes",
            "linetr_forward", "linetr_describe_workspace_bytes", "linetr_describe", "linetr_match_workspace_bytes", "linetr_match", "linetr_match_gathered", "linetr_match_points",
-           "linetr_match_distmat", "linetr_match_distmat_workspace_bytes", "linetr_superpoint_heads", "linetr_set_precision", "linetr_get_precision", "linetr_debug_posenc", "linetr_debug_gemm", "linetr_allgather_desc", "linetr_set_profiling", "linetr_get_profile"]
+           "linetr_match_distmat", "linetr_match_distmat_workspace_bytes", "linetr_superpoint_heads", "linetr_set_precision", "linetr_get_precision", "linetr_debug_posenc", "linetr_debug_gemm", "linetr_allgather_desc", "linetr_set_allgather_fn", "linetr_pack_slab", "linetr_sample_descriptors_workspace_bytes",
+           "linetr_sample_descriptors", "linetr_pool_distmat_workspace_bytes", "linetr_pool_distmat", "linetr_set_profiling", "linetr_get_profile"]
 
 
 EXPERIMENT_EXPORTS = ["linetr_st_bytes", "linetr_debug_to_st", "linetr_debug_from_st", "linetr_debug_gemm_st"]
@@ -125,10 +134,12 @@ class NativeError(RuntimeError):
     pass
 
 
-def check(code: int):
+def check(code: int, L=None):
+    """`L`: the library the failing call went through (every .so keeps its own thread-local error text); default = the
+    product library."""
     if code == 0:
         return
-    msg = lib().linetr_last_error().decode("utf-8", "replace")
+    msg = (L if L is not None else lib()).linetr_last_error().decode("utf-8", "replace")
     if code == E_ASSERT:
         raise AssertionError(msg)     # same exception type the reference raises (line_process.py:44-45)
     raise NativeError(f"liblinetr_hip error {code}: {msg}")

@@ -455,8 +455,13 @@ static int pack_one(LinetrLineRec& r, double td, int T, int image, int line_loca
 static void angle_of(LinetrLineRec& r) {  // line_process.py:28-41
   double th = std::atan2(r.ep[0] - r.sp[0], r.ep[1] - r.sp[1]);
   if (th < 0) th += M_PI;
+#ifdef __GLIBC__
   // one libm call for both (glibc's sincos returns exactly what its sin and cos return)
   ::sincos(2 * th, &r.angle[1], &r.angle[0]);
+#else
+  r.angle[0] = std::cos(2 * th);
+  r.angle[1] = std::sin(2 * th);
+#endif
 }
 
 extern "C" int linetr_pack_lines(const double* h_klines, const double* h_length, const double* h_angles, int32_t K,
@@ -611,21 +616,30 @@ extern "C" int linetr_prefilter_batch(const double* L, const int32_t* off, int32
 // multi-GPU collective (C-ABI form of parallel.allgather_descriptors)
 // =============================================================================================
 
+// ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t, ncclComm_t, hipStream_t)
+typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+static allgather_fn g_allgather = nullptr;
+static std::mutex g_allgather_mu;
+
+extern "C" int linetr_set_allgather_fn(void* fn) {
+  std::lock_guard<std::mutex> lk(g_allgather_mu);
+  g_allgather = reinterpret_cast<allgather_fn>(fn);
+  return LINETR_OK;
+}
+
 extern "C" int linetr_allgather_desc(void* nccl_comm, const void* d_slab, void* d_out, int64_t slab_bytes, void* stream) {
   if (!nccl_comm || !d_slab || !d_out || slab_bytes <= 0) return fail(LINETR_E_ARG, "allgather_desc: bad argument");
-  // ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t, ncclComm_t, hipStream_t)
-  typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
-  static allgather_fn fn = nullptr;
-  static std::mutex mu;
+  allgather_fn fn = nullptr;
   {
-    std::lock_guard<std::mutex> lk(mu);
-    if (!fn) {
+    std::lock_guard<std::mutex> lk(g_allgather_mu);
+    fn = g_allgather;
+    if (!fn) {   // not given by the caller: the first ncclAllGather the process-wide symbol resolution finds
       void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
       for (const char* name : {"librccl.so", "librccl.so.1"}) {
         if (sym) break;
         if (void* lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD)) sym = dlsym(lib, "ncclAllGather");   // only an ALREADY loaded RCCL
       }
-      fn = reinterpret_cast<allgather_fn>(sym);
+      fn = g_allgather = reinterpret_cast<allgather_fn>(sym);
     }
   }
   if (!fn) return fail(LINETR_E_HIP, "allgather_desc: no RCCL (ncclAllGather) is loaded in this process");

@@ -145,6 +145,10 @@ extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* 
     ProfScope ps(h, st, "pair_match", 0, 0);
     if (max_k1 > 0) {
       const int seg1_global = max_k1 > PM_MAX_K1;    // the reference has no limit (max_keylines / max_keypoints = -1)
+      if (seg1_global) {
+        hipLaunchKernelGGL(pair_seg1_kernel, dim3(cdiv(max_n1, 2048), P), dim3(256), 0, st, tab, d_s2l1, d_scr);
+        LT_LAUNCH_CHECK();
+      }
       hipLaunchKernelGGL(pair_pool_kernel, dim3(max_chunks, P), dim3(256),
                          (size_t)((seg1_global ? 0 : max_k1) + PM_ROWS + 2) * sizeof(int), st, tab, d_s2l0, d_s2l1, d_dist, d_dk,
                          d_scr, seg1_global);
@@ -226,12 +230,61 @@ extern "C" int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_
   if (int e = staging_ring().commit(slot, st)) return e;
   if (n1 > 0) {
     const int seg1_global = n1 > PM_MAX_K1;
+    if (seg1_global) {
+      hipLaunchKernelGGL(pair_seg1_kernel, dim3(cdiv(n1, 2048), 1), dim3(256), 0, st, tab, (const int*)(base + o_id1), (int*)(base + o_scr));
+      LT_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(pair_pool_kernel, dim3(pd->chunks, 1), dim3(256), (size_t)((seg1_global ? 0 : n1) + PM_ROWS + 2) * sizeof(int),
                        st, tab, (const int*)(base + o_id0), (const int*)(base + o_id1), d_dist, (float*)(base + o_dk),
                        (int*)(base + o_scr), seg1_global);
     LT_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(pair_final_kernel, dim3(1), dim3(256), 0, st, tab, thr, mutual, d_match01, (int*)(base + o_scr));
+  LT_LAUNCH_CHECK();
+  return LINETR_OK;
+}
+
+// subline2keyline (models/line_transformer.py:277-282) alone: Dk = A0 D A1^T for the segmented-mean matrices the tokeniser
+// produces, given as sub-line -> key-line maps (non-decreasing).  Same kernel as linetr_match's pooling stage.
+extern "C" int64_t linetr_pool_distmat_workspace_bytes(int32_t k0, int32_t k1) {
+  return align_up(pair_scratch_ints(std::max(k0, 0), std::max(k1, 0)) * 4, 256) + 256;
+}
+
+extern "C" int linetr_pool_distmat(LinetrHandle* h, const float* d_dist, int32_t n0, int32_t n1, const int32_t* d_s2l0, int32_t k0,
+                                   const int32_t* d_s2l1, int32_t k1, float* d_dk, void* d_ws, int64_t ws_bytes, void* stream) {
+  if (n0 < 0 || n1 < 0 || k0 < 0 || k1 < 0 || k0 > n0 || k1 > n1) return fail(LINETR_E_ARG, "pool_distmat: bad dims");
+  if (k0 == 0 || k1 == 0) return LINETR_OK;
+  if (!d_dist || !d_s2l0 || !d_s2l1 || !d_dk || !d_ws) return fail(LINETR_E_ARG, "pool_distmat: null pointer");
+  if (ws_bytes < linetr_pool_distmat_workspace_bytes(k0, k1)) return fail(LINETR_E_WORKSPACE, "pool_distmat: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (h) LT_HIP(hipSetDevice(h->device));
+  PairTable tab{};
+  tab.n_inline = 1;
+  PairDesc* pd = tab.inl;
+  pd->n0 = n0; pd->k0 = k0; pd->n1 = n1; pd->k1 = k1;
+  pd->chunks = cdiv(k0, PM_ROWS);
+  const int seg1_global = k1 > PM_MAX_K1;
+  ProfScope ps(h, st, "pair_pool", 0, 4.0 * ((double)n0 * n1 + (double)k0 * k1));
+  if (seg1_global) {
+    hipLaunchKernelGGL(pair_seg1_kernel, dim3(cdiv(n1, 2048), 1), dim3(256), 0, st, tab, d_s2l1, (int*)d_ws);
+    LT_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(pair_pool_kernel, dim3(pd->chunks, 1), dim3(256), (size_t)((seg1_global ? 0 : k1) + PM_ROWS + 2) * sizeof(int), st,
+                     tab, d_s2l0, d_s2l1, d_dist, d_dk, (int*)d_ws, seg1_global);
+  LT_LAUNCH_CHECK();
+  return LINETR_OK;
+}
+
+// One rank's all-gather slab in one launch (layout: lt_match.h pack_slab_kernel, linetr_amd/parallel.py)
+extern "C" int linetr_pack_slab(const float* d_line_desc, int32_t N, const int32_t* d_cu_n, const int32_t* d_cu_k, int32_t n_images,
+                                const int32_t* d_sub2line, int32_t n_images_cap, int32_t rows_cap, int32_t zero_tail, float* d_slab,
+                                void* stream) {
+  if (N < 0 || n_images < 0 || n_images > n_images_cap || N > rows_cap) return fail(LINETR_E_CAPACITY, "pack_slab: %d images / %d rows exceed the slab capacity (%d / %d)", n_images, N, n_images_cap, rows_cap);
+  if (!d_slab || (N > 0 && !d_line_desc) || (n_images > 0 && !d_cu_n)) return fail(LINETR_E_ARG, "pack_slab: null pointer");
+  const int hr = (1 + 2 * n_images_cap + D - 1) / D, mr = (rows_cap + D - 1) / D;
+  const int64_t items = (int64_t)(zero_tail ? rows_cap : N) * (D / 4) + (d_sub2line ? N : 0) + 1 + 2 * (int64_t)n_images_cap;
+  hipLaunchKernelGGL(pack_slab_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_line_desc, N, d_cu_n,
+                     d_cu_k, n_images, d_sub2line, n_images_cap, rows_cap, hr, mr, zero_tail, d_slab);
   LT_LAUNCH_CHECK();
   return LINETR_OK;
 }

@@ -312,16 +312,16 @@ extern "C" int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int
                                int32_t T, const float* d_dense_desc, const float* d_dense_score, int32_t n_images,
                                int32_t height, int32_t width, int32_t align_corners, int32_t dense_is_nhwc,
                                LinetrTokens out, int32_t* d_sub2line, void* d_ws, int64_t ws_bytes, void* stream) {
-  if (!h) return fail(LINETR_E_ARG, "null handle");
   if (K <= 0 || N <= 0) return LINETR_OK;
   if (!d_recs || !d_dense_score || !out.sublines || !out.pnt || !out.mask || !out.resp || !out.angle_sub ||
       !out.score || (out.desc && !d_dense_desc))
     return fail(LINETR_E_ARG, "tokenize: null pointer");
   if (T < 1 || T > 4096 || height % 8 || width % 8) return fail(LINETR_E_ARG, "tokenize: bad max_tokens / image size");
+  if (out.mat && n_images != 1) return fail(LINETR_E_ARG, "tokenize: mat_klines2sublines is written for single-image calls only");
   if (ws_bytes < linetr_tokenize_workspace_bytes(n_images, height, width, N))
     return fail(LINETR_E_WORKSPACE, "tokenize: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  LT_HIP(hipSetDevice(h->device));
+  if (h) LT_HIP(hipSetDevice(h->device));   // no weights involved: without a handle the current device is used
   const int Hc = height / 8, Wc = width / 8, P = Hc * Wc;
   float* nhwc = (float*)d_ws;
   int* s2l_g = (int*)((char*)d_ws + align_up((int64_t)n_images * P * D * 4, 256));
@@ -333,9 +333,10 @@ extern "C" int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int
   }
   {
     ProfScope ps(h, st, "tokenize", 0, (double)N * T * 16);
-    hipLaunchKernelGGL(tokenize_kernel, dim3(N), dim3(64), 0, st, d_recs, s2l_g, N, td, T, height, width,
+    // (with out.mat: K more blocks write the rows of mat_klines2sublines in the same launch)
+    hipLaunchKernelGGL(tokenize_kernel, dim3(N + (out.mat ? K : 0)), dim3(64), 0, st, d_recs, s2l_g, N, td, T, height, width,
                        d_dense_score, out.sublines, out.pnt, out.mask, out.resp, out.angle_sub, out.score, (float*)nullptr,
-                       (float*)nullptr, 0, (int64_t)0);
+                       (float*)nullptr, 0, (int64_t)0, out.mat);
     LT_LAUNCH_CHECK();
   }
   if (out.desc) {
@@ -351,6 +352,37 @@ extern "C" int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int
                        ntok, T, dense_is_nhwc ? d_dense_desc : nhwc, Hc, Wc, align_corners, out.desc);
     LT_LAUNCH_CHECK();
   }
+  return LINETR_OK;
+}
+
+// sample_descriptors (models/line_process.py:86-98) on its own: n points of ONE image
+extern "C" int64_t linetr_sample_descriptors_workspace_bytes(int32_t Hc, int32_t Wc, int32_t dense_is_nhwc) {
+  return dense_is_nhwc ? 0 : align_up((int64_t)Hc * Wc * D * 4, 256);
+}
+
+extern "C" int linetr_sample_descriptors(LinetrHandle* h, const float* d_points, int64_t n, const float* d_dense_desc, int32_t Hc,
+                                         int32_t Wc, int32_t align_corners, int32_t dense_is_nhwc, float* d_out, void* d_ws,
+                                         int64_t ws_bytes, void* stream) {
+  if (n < 0 || Hc <= 0 || Wc <= 0) return fail(LINETR_E_ARG, "sample_descriptors: bad shape");
+  if (n == 0) return LINETR_OK;
+  if (!d_points || !d_dense_desc || !d_out) return fail(LINETR_E_ARG, "sample_descriptors: null pointer");
+  if (ws_bytes < linetr_sample_descriptors_workspace_bytes(Hc, Wc, dense_is_nhwc) || (!dense_is_nhwc && !d_ws))
+    return fail(LINETR_E_WORKSPACE, "sample_descriptors: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (h) LT_HIP(hipSetDevice(h->device));
+  const int P = Hc * Wc;
+  const float* nhwc = d_dense_desc;
+  if (!dense_is_nhwc) {
+    ProfScope ps(h, st, "nchw_to_nhwc", 0, 2.0 * P * D * 4);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(P, 64), D / 64, 1), dim3(256), 0, st, d_dense_desc, (float*)d_ws, D, P);
+    LT_LAUNCH_CHECK();
+    nhwc = (const float*)d_ws;
+  }
+  ProfScope ps(h, st, "sample_desc", 0, (double)n * D * 4 * 2);
+  // T = 1 and no records: every point is its own "sub-line" of image 0
+  hipLaunchKernelGGL(sample_desc_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, d_points, (const int*)nullptr,
+                     (const LinetrLineRec*)nullptr, n, 1, nhwc, Hc, Wc, align_corners, d_out);
+  LT_LAUNCH_CHECK();
   return LINETR_OK;
 }
 
@@ -855,6 +887,7 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
   if (T < 1 || T > 4096 || height % 8 || width % 8) return fail(LINETR_E_ARG, "describe: bad max_tokens / image size");
   if (n_real < N || n_real > (int64_t)N * T) return fail(LINETR_E_ARG, "describe: implausible real-token count");
   if (out.desc && !out.pnt) return fail(LINETR_E_ARG, "describe: out.desc requires out.pnt");
+  if (out.mat && n_images != 1) return fail(LINETR_E_ARG, "describe: mat_klines2sublines is written for single-image calls only");
   if (ws_bytes < linetr_describe_workspace_bytes(h, n_images, height, width, N, n_real))
     return fail(LINETR_E_WORKSPACE, "describe: workspace too small");
   const int64_t rows = n_real + n_images;
@@ -894,9 +927,9 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
   {
     ProfScope ps(h, st, "tokenize", 0, (double)n_real * 16);
     // (the last cdiv(n_images, 64) blocks write the per-image padding rows of the compact token list)
-    hipLaunchKernelGGL(tokenize_kernel, dim3(N + cdiv(n_images, 64)), dim3(64), 0, st, d_recs, dw.s2l_g, N, td, T, height, width,
-                       d_dense_score, sublines, out.pnt, out.mask, resp, angle_sub, out.score, dw.cpnt, dw.cscore, n_images,
-                       (int64_t)n_real);
+    hipLaunchKernelGGL(tokenize_kernel, dim3(N + cdiv(n_images, 64) + (out.mat ? K : 0)), dim3(64), 0, st, d_recs, dw.s2l_g, N, td, T,
+                       height, width, d_dense_score, sublines, out.pnt, out.mask, resp, angle_sub, out.score, dw.cpnt, dw.cscore,
+                       n_images, (int64_t)n_real, out.mat);
     LT_LAUNCH_CHECK();
   }
   if (use_side) {

@@ -114,6 +114,17 @@ __device__ __forceinline__ int seg_lower_bound(const int* __restrict__ m, int n,
   return lo;
 }
 
+// seg1 table of a pair in global scratch (images with more than PM_MAX_K1 key-lines / key-points): grid (blocks, pairs)
+__global__ __launch_bounds__(256) void pair_seg1_kernel(const PairTable pairs, const int* __restrict__ s2l1, int* __restrict__ scratch) {
+  const PairDesc pd = pairs.get(blockIdx.y);
+  if (pd.k1 <= 0) return;
+  int* seg1 = scratch + pd.off_seg + 2 * (int64_t)pd.k0 + pd.k1 + 2 * (int64_t)pd.chunks * pd.k1;
+  const int* m1 = s2l1 + pd.off_s1;
+  for (int n = blockIdx.x * 256 + threadIdx.x; n < pd.n1; n += gridDim.x * 256)
+    if (n == 0 || m1[n] != m1[n - 1]) seg1[m1[n]] = n;
+  if (blockIdx.x == 0 && threadIdx.x == 0) seg1[pd.k1] = pd.n1;
+}
+
 __global__ __launch_bounds__(256) void pair_pool_kernel(const PairTable pairs, const int* __restrict__ s2l0,
                                                         const int* __restrict__ s2l1, const float* __restrict__ dist,
                                                         float* __restrict__ dk_out, int* __restrict__ scratch, int seg1_global) {
@@ -123,22 +134,24 @@ __global__ __launch_bounds__(256) void pair_pool_kernel(const PairTable pairs, c
   if (chunk >= pd.chunks || pd.k1 <= 0) return;
   const int tid = threadIdx.x;
   const int i0 = chunk * PM_ROWS, rows = min(PM_ROWS, pd.k0 - i0);
-  // large images: every block of the pair builds the (identical) seg1 table in the pair's scratch region instead
+  // large images: the seg1 table does not fit the LDS; pair_seg1_kernel has built it in the pair's scratch region (one writer,
+  // an earlier launch on the same stream) and the blocks of this launch only read it
   int* seg1 = seg1_global ? scratch + pd.off_seg + 2 * (int64_t)pd.k0 + pd.k1 + 2 * (int64_t)pd.chunks * pd.k1 : pm_lds;
   int* seg0 = seg1_global ? pm_lds : pm_lds + pd.k1 + 1;
   const int* m0 = s2l0 + pd.off_s0;
   const int* m1 = s2l1 + pd.off_s1;
   // segment starts: sub-lines of a key-line are contiguous and key-line ids non-decreasing, so a start is where the id
   // changes -- one coalesced pass (a chain of dependent global loads per binary search cost ~5 us of pure latency)
-  for (int n = tid; n < pd.n1; n += 256)
-    if (n == 0 || m1[n] != m1[n - 1]) seg1[m1[n]] = n;
+  if (!seg1_global)
+    for (int n = tid; n < pd.n1; n += 256)
+      if (n == 0 || m1[n] != m1[n - 1]) seg1[m1[n]] = n;
   for (int n = tid; n < pd.n0; n += 256)
     if (n == 0 || m0[n] != m0[n - 1]) {
       const int k = m0[n] - i0;
       if (k >= 0 && k <= rows) seg0[k] = n;
     }
   if (tid == 0) {
-    seg1[pd.k1] = pd.n1;
+    if (!seg1_global) seg1[pd.k1] = pd.n1;
     if (i0 + rows == pd.k0) seg0[rows] = pd.n0;
   }
   __syncthreads();
@@ -246,6 +259,37 @@ __global__ void transpose_cn_kernel(const float* __restrict__ in, float* __restr
   for (int i = threadIdx.y; i < 32; i += 8) {
     int p = p0 + i;
     if (p < n) out[(int64_t)p * C + c0 + threadIdx.x] = tile[threadIdx.x][i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One rank's slab of the multi-GPU all-gather (linetr_amd/parallel.py): float32 [hr + mr + rows_cap][256] =
+// int32 header {n_images, n_0.., k_0..} | int32 sub2line[rows_cap] | line_desc rows (tail rows zeroed when asked).
+// Counts come from the device prefix sums linetr_describe already holds: nothing is copied from the host.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_slab_kernel(const float* __restrict__ desc, int N, const int* __restrict__ cu_n,
+                                                        const int* __restrict__ cu_k, int n_images, const int* __restrict__ s2l,
+                                                        int n_images_cap, int rows_cap, int hr, int mr, int zero_tail,
+                                                        float* __restrict__ slab) {
+  const int64_t row_items = (int64_t)(zero_tail ? rows_cap : N) * (D / 4);
+  const int64_t map_items = s2l ? N : 0;
+  const int64_t hdr_items = 1 + 2 * (int64_t)n_images_cap;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < row_items) {
+    const int64_t r = i / (D / 4);
+    const f32x4 v = r < N ? reinterpret_cast<const f32x4*>(desc)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    reinterpret_cast<f32x4*>(slab + (int64_t)(hr + mr) * D)[i] = v;
+  } else if (i < row_items + map_items) {
+    const int64_t j = i - row_items;
+    reinterpret_cast<int*>(slab + (int64_t)hr * D)[j] = s2l[j];
+  } else if (i < row_items + map_items + hdr_items) {
+    const int j = (int)(i - row_items - map_items);
+    int* hdr = reinterpret_cast<int*>(slab);
+    int v = 0;
+    if (j == 0) v = n_images;
+    else if (j <= n_images_cap) { const int im = j - 1; v = im < n_images ? cu_n[im + 1] - cu_n[im] : 0; }
+    else { const int im = j - 1 - n_images_cap; v = (cu_k && im < n_images) ? cu_k[im + 1] - cu_k[im] : 0; }
+    hdr[j] = v;
   }
 }
 

@@ -105,18 +105,29 @@ __global__ __launch_bounds__(64) void tokenize_kernel(
     int height, int width, const float* __restrict__ dense_score, float* __restrict__ sublines,
     float* __restrict__ pnt, float* __restrict__ mask, float* __restrict__ resp,
     float* __restrict__ angle_sub, float* __restrict__ score, float* __restrict__ cpnt,
-    float* __restrict__ cscore, int n_pad_images, int64_t first_pad) {
+    float* __restrict__ cscore, int n_pad_images, int64_t first_pad, float* __restrict__ mat_k2s) {
 #pragma clang fp contract(off)
   const int n = blockIdx.x;
   if (n >= N) {
-    // blocks past the sub-lines: one shared padding token per image for the compact token list -- coordinate (0, 0), score
-    // dense_score[img][0][0] (the reference pads with zeros and gathers the score at the rounded coordinate, line_process.py:174-179)
-    const int i = (n - N) * 64 + threadIdx.x;
-    if (i < n_pad_images) {
-      cpnt[(first_pad + i) * 2 + 0] = 0.f;
-      cpnt[(first_pad + i) * 2 + 1] = 0.f;
-      cscore[first_pad + i] = dense_score[(int64_t)i * height * width];
+    const int pad_blocks = (n_pad_images + 63) / 64;
+    if (n - N < pad_blocks) {
+      // blocks past the sub-lines: one shared padding token per image for the compact token list -- coordinate (0, 0), score
+      // dense_score[img][0][0] (the reference pads with zeros and gathers the score at the rounded coordinate, line_process.py:174-179)
+      const int i = (n - N) * 64 + threadIdx.x;
+      if (i < n_pad_images) {
+        cpnt[(first_pad + i) * 2 + 0] = 0.f;
+        cpnt[(first_pad + i) * 2 + 1] = 0.f;
+        cscore[first_pad + i] = dense_score[(int64_t)i * height * width];
+      }
+      return;
     }
+    // one more block per key-line (single-image calls only): its row of mat_klines2sublines [K][N], 1 / num_sublines over the
+    // key-line's own sub-lines and 0 elsewhere (line_process.py:160-165; Python's 1/num is a float64 quotient stored as float32)
+    const int k = n - N - pad_blocks;
+    const LinetrLineRec r = recs[k];
+    float* row = mat_k2s + (int64_t)k * N;
+    const float w = (float)(1.0 / (double)r.n_sub);
+    for (int j = threadIdx.x; j < N; j += 64) row[j] = (j >= r.first_sub && j < r.first_sub + r.n_sub) ? w : 0.f;
     return;
   }
   const LinetrLineRec r = recs[sub2line_g[n]];
@@ -315,7 +326,7 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(
   if (tok >= n_tokens) return;
   const int lane = threadIdx.x & 63;
   const int n = (int)(tok / T);
-  const int img = recs[sub2line_g[n]].image;
+  const int img = recs ? recs[sub2line_g[n]].image : 0;   // no records: all points belong to one image (linetr_sample_descriptors)
   const f32x4 o = sample_one(pnt[tok * 2 + 0], pnt[tok * 2 + 1], nhwc + (int64_t)img * Hc * Wc * D, Hc, Wc,
                              align_corners, lane);
   *reinterpret_cast<f32x4*>(desc + tok * D + lane * 4) = o;

@@ -43,6 +43,7 @@ class TokenBatch:
     desc: torch.Tensor        # [N,T,256]
     score: torch.Tensor       # [N,T]
     sub2line: torch.Tensor    # [N] int32, key-line index inside the image
+    mat: torch.Tensor = None  # [K,N] mat_klines2sublines (single-image tokenise calls with want_mat=True)
     extra: dict = field(default_factory=dict)
 
     @property
@@ -57,6 +58,7 @@ class TokenBatch:
         t = nat.Tokens()
         for k in ("klines", "length", "angles", "sublines", "pnt", "mask", "resp", "angle_sub", "desc", "score"):
             setattr(t, k, getattr(self, k).data_ptr())
+        t.mat = self.mat.data_ptr() if self.mat is not None else None
         return t
 
 
@@ -188,7 +190,7 @@ class Engine:
         nat.check(self._L.linetr_prefilter_batch(nat.np_ptr(cat), nat.np_ptr(offsets), B, int(height), int(width),
                                                  int(remove_borders), float(min_length), int(max_keylines), vm_ptrs,
                                                  float(token_distance), int(max_tokens), int(n_threads),
-                                                 nat.np_ptr(recs), cap, nat.np_ptr(cu_k), nat.np_ptr(cu_n)))
+                                                 nat.np_ptr(recs), cap, nat.np_ptr(cu_k), nat.np_ptr(cu_n)), self._L)
         K = int(cu_k[-1])
         out = recs[:K]
         self._last_host = {"slot": slot, "recs_ptr": recs.ctypes.data, "rec_bytes": rec_bytes, "B": B}
@@ -203,12 +205,12 @@ class Engine:
         ln = np.ascontiguousarray(length, dtype=np.float64)
         an = np.ascontiguousarray(angles, dtype=np.float64)
         nat.check(self._L.linetr_pack_lines(nat.np_ptr(kl), nat.np_ptr(ln), nat.np_ptr(an), K, float(token_distance),
-                                            int(max_tokens), int(image), int(sub_base), 0, nat.np_ptr(recs), C.byref(n_out)))
+                                            int(max_tokens), int(image), int(sub_base), 0, nat.np_ptr(recs), C.byref(n_out)), self._L)
         return recs[:K], n_out.value
 
     # ------------------------------------------------------------------ device stages
     def tokenize(self, recs, cu_k, cu_n, dense_desc, dense_score, *, token_distance, max_tokens, align_corners=False,
-                 sample_desc=True, dense_layout="nchw") -> TokenBatch:
+                 sample_desc=True, dense_layout="nchw", want_mat=False) -> TokenBatch:
         """line_tokenizer on the device.  dense_desc [B,256,H/8,W/8] (dense_layout='nchw') or [B,H/8,W/8,256]
         ('nhwc', the producer's layout: no transposition pass), dense_score [B,H,W]."""
         B = len(cu_k) - 1
@@ -235,6 +237,10 @@ class Engine:
             resp=torch.empty((N,), **f), angle_sub=torch.empty((N, 2), **f),
             desc=torch.empty((N, T, D), **f) if sample_desc else torch.empty((0,), **f),
             score=torch.empty((N, T), **f), sub2line=torch.empty((N,), dtype=torch.int32, device=dev))
+        if want_mat:
+            if B != 1:
+                raise ValueError("want_mat needs a single-image call (the reference's matrix is per image)")
+            tb.mat = torch.empty((K, N), **f)    # written by extra blocks of the tokeniser's own launch
         if K == 0 or N == 0:
             return tb
         last = getattr(self, "_last_host", None)
@@ -255,9 +261,10 @@ class Engine:
         ct = tb.c_tokens()
         if not sample_desc:
             ct.desc = None
-        nat.check(self._L.linetr_tokenize(self._h, d_recs.data_ptr(), K, N, float(token_distance), T,
-                                          dense_desc.data_ptr(), dense_score.data_ptr(), B, H, W, int(bool(align_corners)),
-                                          int(nhwc), ct, tb.sub2line.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+        with torch.cuda.device(self.device):     # a weight-less engine has no handle: the current device is used
+            nat.check(self._L.linetr_tokenize(self._h, d_recs.data_ptr(), K, N, float(token_distance), T,
+                                              dense_desc.data_ptr(), dense_score.data_ptr(), B, H, W, int(bool(align_corners)),
+                                              int(nhwc), ct, tb.sub2line.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), self._L)
         tb.extra["d_recs"] = d_recs  # keep alive until the stream has consumed it
         return tb
 
@@ -307,7 +314,7 @@ class Engine:
                                           d_cu.data_ptr() if d_cu is not None else None, B, float(token_distance), T,
                                           dense_desc.data_ptr(), dense_score.data_ptr(), H, W, int(bool(align_corners)),
                                           int(nhwc), ct, tb.sub2line.data_ptr(), ld.data_ptr(), ws.data_ptr(),
-                                          ws.numel(), self._stream()))
+                                          ws.numel(), self._stream()), self._L)
         return tb, ld
 
     def describe_lines(self, lines6, offsets, dense_desc, dense_score, *, remove_borders, min_length, max_keylines,
@@ -410,7 +417,7 @@ class Engine:
         nbytes = self._L.linetr_forward_workspace_bytes(self._h, N, T)
         ws = self._workspace("fwd", nbytes)
         nat.check(self._L.linetr_forward(self._h, C.byref(t), nat.np_ptr(cu), d_cu_n.data_ptr() if d_cu_n is not None else None,
-                                         len(cu) - 1, T, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+                                         len(cu) - 1, T, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), self._L)
         return out
 
     def forward(self, tb: TokenBatch, out=None) -> torch.Tensor:
@@ -443,7 +450,7 @@ class Engine:
         nat.check(self._L.linetr_match(self._h, P, nat.np_ptr(dims), d0.data_ptr(), nat.np_ptr(off_n0),
                                        sub2line0.data_ptr(), d1.data_ptr(), nat.np_ptr(off_n1), sub2line1.data_ptr(),
                                        float(thr), int(bool(mutual)), dk.data_ptr(), nat.np_ptr(off_dk[:-1].copy()),
-                                       m01.data_ptr(), nat.np_ptr(off_k0), ws.data_ptr(), ws.numel(), self._stream()))
+                                       m01.data_ptr(), nat.np_ptr(off_k0), ws.data_ptr(), ws.numel(), self._stream()), self._L)
         return dk[:int(off_dk[-1])], off_dk, m01[:int(cu_k0[-1])]
 
     def match_offsets(self, desc_flat, s2l_flat, dims, off_n0, off_s0, off_n1, off_s1, thr, mutual=True):
@@ -483,8 +490,56 @@ class Engine:
                                                 s0.ctypes.data, d.data_ptr(), o1.ctypes.data, s2l_flat.data_ptr(),
                                                 s1.ctypes.data, float(thr), int(bool(mutual)), dk.data_ptr(),
                                                 off_dk.ctypes.data, m01.data_ptr(), off_k0.ctypes.data, ws.data_ptr(), ws.numel(),
-                                                self._stream()))
+                                                self._stream()), self._L)
         return dk[:int(off_dk[-1])], off_dk, m01[:int(off_k0[-1])], off_k0
+
+    def pool_distmat(self, dist: torch.Tensor, sub2line0: torch.Tensor, k0: int, sub2line1: torch.Tensor, k1: int):
+        """subline2keyline on the device: dist [n0,n1] + the two sub-line -> key-line maps -> Dk [k0,k1]."""
+        d = self._f32(dist)
+        n0, n1 = int(d.shape[0]), int(d.shape[1])
+        dk = torch.empty((k0, k1), dtype=torch.float32, device=self.device)
+        if k0 == 0 or k1 == 0:
+            return dk
+        ws = self._workspace("pool", self._L.linetr_pool_distmat_workspace_bytes(k0, k1))
+        s0 = sub2line0.to(device=self.device, dtype=torch.int32)
+        s1 = sub2line1.to(device=self.device, dtype=torch.int32)
+        with torch.cuda.device(self.device):
+            nat.check(self._L.linetr_pool_distmat(self._h, d.data_ptr(), n0, n1, s0.data_ptr(), k0, s1.data_ptr(), k1,
+                                                  dk.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), self._L)
+        return dk
+
+    def sample_descriptors(self, points: torch.Tensor, dense_desc: torch.Tensor, *, align_corners=False, dense_layout="nchw"):
+        """sample_descriptors (line_process.py:86-98) for n points [n,2] of one image; dense_desc [256,Hc,Wc] or
+        [Hc,Wc,256]; returns [n,256]."""
+        pts = self._f32(points.reshape(-1, 2))
+        dd = self._f32(dense_desc)
+        nhwc = dense_layout == "nhwc"
+        Hc, Wc = (int(dd.shape[0]), int(dd.shape[1])) if nhwc else (int(dd.shape[1]), int(dd.shape[2]))
+        n = int(pts.shape[0])
+        out = torch.empty((n, D), dtype=torch.float32, device=self.device)
+        if n == 0:
+            return out
+        ws = self._workspace("sample", self._L.linetr_sample_descriptors_workspace_bytes(Hc, Wc, int(nhwc)) + 256)
+        with torch.cuda.device(self.device):
+            nat.check(self._L.linetr_sample_descriptors(self._h, pts.data_ptr(), n, dd.data_ptr(), Hc, Wc, int(bool(align_corners)),
+                                                        int(nhwc), out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), self._L)
+        return out
+
+    def to_host(self, *tensors):
+        """Device tensors -> NumPy arrays with ONE stream synchronisation: every tensor is copied asynchronously into a cached
+        pinned staging buffer, then the stream is waited for once (`.cpu()` per tensor would synchronise per tensor)."""
+        sizes = [t.numel() * t.element_size() for t in tensors]
+        offs = np.concatenate([[0], np.cumsum([(b + 255) // 256 * 256 for b in sizes])]).astype(np.int64)
+        stage = self.__dict__.get("_host_stage")
+        if stage is None or stage.numel() < int(offs[-1]):
+            stage = self._host_stage = torch.empty(int(offs[-1]) * 2 + 4096, dtype=torch.uint8, pin_memory=True)
+        views = []
+        for t, o, b in zip(tensors, offs[:-1], sizes):
+            v = stage[int(o):int(o) + b].view(t.dtype).view(t.shape)
+            v.copy_(t.contiguous(), non_blocking=True)
+            views.append(v)
+        torch.cuda.current_stream(self.device).synchronize()
+        return [v.numpy().copy() for v in views]
 
     def match_points(self, desc0_cn: torch.Tensor, desc1_cn: torch.Tensor, thr, mutual=True):
         """nn_matcher on [256,n] descriptors; returns (dist [n0,n1] device, match01 [n0] device)."""
@@ -498,7 +553,7 @@ class Engine:
         ws = self._workspace("match", need)
         nat.check(self._L.linetr_match_points(self._h, d0.data_ptr(), n0, d1.data_ptr(), n1, float(thr),
                                               int(bool(mutual)), dist.data_ptr(), m01.data_ptr(), ws.data_ptr(),
-                                              ws.numel(), self._stream()))
+                                              ws.numel(), self._stream()), self._L)
         return dist, m01
 
     def superpoint_heads(self, score_logits: torch.Tensor = None, desc_raw: torch.Tensor = None, *, nhwc=True,
@@ -526,14 +581,14 @@ class Engine:
         ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(self.device):     # a heads-only engine has no handle: the current device is used
             nat.check(self._L.linetr_superpoint_heads(self._h, ptr(sl), ptr(dr), B, Hc, Wc, ptr(score), ptr(o_nhwc),
-                                                      ptr(o_nchw), self._stream()))
+                                                      ptr(o_nchw), self._stream()), self._L)
         return score, o_nhwc, o_nchw
 
     PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}
 
     def set_precision(self, mode: str):
         """arithmetic mode of the dense contractions: 'f32' | 'bf16x6' (fp32-faithful, default) | 'bf16x3'."""
-        nat.check(self._L.linetr_set_precision(self._h, self.PRECISIONS[mode]))
+        nat.check(self._L.linetr_set_precision(self._h, self.PRECISIONS[mode]), self._L)
 
     def get_precision(self) -> str:
         code = self._L.linetr_get_precision(self._h)
@@ -548,7 +603,7 @@ class Engine:
         out = torch.empty((rows, 128), dtype=torch.float32, device=self.device)
         nat.check(self._L.linetr_debug_posenc(self._h, {"word": 0, "line": 1}[which], a.data_ptr(), b.data_ptr(),
                                                  c.data_ptr() if c is not None else None, rows, out.data_ptr(),
-                                                 self._stream()))
+                                                 self._stream()), self._L)
         return out
 
     def debug_gemm(self, A, W, bias=None, residual=None, act=0, cache_weights=False, out=None):
@@ -568,7 +623,7 @@ class Engine:
         nat.check(self._L.linetr_debug_gemm(self._h, A.data_ptr(), A.stride(0), W.data_ptr(),
                                             b.data_ptr() if b is not None else None,
                                             r.data_ptr() if r is not None else None, Y.data_ptr(), Y.stride(0), M, N, K,
-                                            int(act), int(cache_weights), self._stream()))
+                                            int(act), int(cache_weights), self._stream()), self._L)
         return Y
 
     # ------------------------------------------------------------------ split-tile operands (lt_gemm_st.h)
@@ -577,12 +632,12 @@ class Engine:
         X = self._f32(X)
         rows, K = X.shape
         out = torch.empty(int(self._L.linetr_st_bytes(rows, K)), dtype=torch.uint8, device=self.device)
-        nat.check(self._L.linetr_debug_to_st(self._h, X.data_ptr(), X.stride(0), rows, K, out.data_ptr(), self._stream()))
+        nat.check(self._L.linetr_debug_to_st(self._h, X.data_ptr(), X.stride(0), rows, K, out.data_ptr(), self._stream()), self._L)
         return out
 
     def from_st(self, st, rows, K):
         X = torch.empty((rows, K), dtype=torch.float32, device=self.device)
-        nat.check(self._L.linetr_debug_from_st(self._h, st.data_ptr(), rows, K, X.data_ptr(), K, self._stream()))
+        nat.check(self._L.linetr_debug_from_st(self._h, st.data_ptr(), rows, K, X.data_ptr(), K, self._stream()), self._L)
         return X
 
     def gemm_st(self, A1, K1, W, M, N, A2=None, K2=0, bias=None, residual=None, act=0, out_st=None, out=None):
@@ -592,16 +647,16 @@ class Engine:
             self._h, A1.data_ptr(), K1, A2.data_ptr() if A2 is not None else None, K2, W.data_ptr(),
             b.data_ptr() if b is not None else None, residual.data_ptr() if residual is not None else None,
             out_st.data_ptr() if out_st is not None else None, out.data_ptr() if out is not None else None,
-            out.stride(0) if out is not None else 0, M, N, int(act), self._stream()))
+            out.stride(0) if out is not None else 0, M, N, int(act), self._stream()), self._L)
         return out_st if out_st is not None else out
 
     # ------------------------------------------------------------------ profiling
     def set_profiling(self, on: bool):
-        nat.check(self._L.linetr_set_profiling(self._h, int(on)))
+        nat.check(self._L.linetr_set_profiling(self._h, int(on)), self._L)
 
     def get_profile(self):
         arr = (nat.ProfileEntry * 64)()
         n = C.c_int32()
-        nat.check(self._L.linetr_get_profile(self._h, arr, 64, C.byref(n)))
+        nat.check(self._L.linetr_get_profile(self._h, arr, 64, C.byref(n)), self._L)
         return [dict(name=arr[i].name.decode(), calls=arr[i].calls, ms=arr[i].ms, flops=arr[i].flops,
                      bytes=arr[i].bytes) for i in range(min(n.value, 64))]

@@ -9,7 +9,8 @@ parameters; tokenisation, the descriptor network and the matcher run in liblinet
 Reference behaviour mirrored here (file:line in the reference checkout):
   * config dict merged over default_config and mutated by callers (models/line_transformer.py:187-206)
   * mode == 'test' loads <pkg>/weights/LineTR_weight.pth strictly and prints a message (:220-223)
-  * preprocess(): cv2 KeyLines -> arrays -> remove_borders -> filter_by_length -> tokeniser (:251-275);
+  * preprocess(): cv2 KeyLines -> arrays -> remove_borders -> filter_by_length -> tokeniser (:251-275; the module-level
+    functions live in linetr_amd.line_process, as in the reference);
     writes config['image_shape'] = image_shape (:258); ndarray valid masks honoured, tensors ignored
   * forward(): same dict object returned with 'line_desc' [1,256,N] added (:225-249)
 """
@@ -23,65 +24,12 @@ from torch import nn
 
 from .engine import Engine
 
+from .line_process import *  # noqa: F401,F403  (the reference's module does the same: models/line_transformer.py:6)
+from .line_process import (change_cv2_T_np, filter_by_length, get_angles, get_dist_matrix, remove_borders,  # noqa: F401
+                           tokenize_into)
+
 __all__ = ["LineTransformer", "get_dist_matrix", "change_cv2_T_np", "remove_borders", "filter_by_length",
-           "get_angles"]
-
-
-# ------------------------------------------------------------------------------------------------
-# O(K) host glue that must reproduce NumPy's own ordering (np.argsort tie order) -- kept in NumPy on
-# purpose; the per-token work happens on the device.
-# ------------------------------------------------------------------------------------------------
-
-def get_angles(lines):
-    """(cos 2theta, sin 2theta) with theta = arctan2(dx, dy) folded into [0, pi)."""
-    if len(lines) == 0:
-        return []
-    theta = np.arctan2(lines[:, 1, 0] - lines[:, 0, 0], lines[:, 1, 1] - lines[:, 0, 1])
-    theta = np.where(theta < 0, theta + np.pi, theta)
-    return np.stack([np.cos(2 * theta), np.sin(2 * theta)], axis=1)
-
-
-def change_cv2_T_np(klines_cv):
-    """KeyLine objects -> {'klines' [K,2,2], 'length_klines' [K], 'angles' [K,2]} (float64)."""
-    if len(klines_cv) == 0:
-        return {"klines": np.zeros((0, 2, 2)), "length_klines": np.zeros((0,)), "angles": []}
-    raw = np.array([(l.startPointX, l.startPointY, l.endPointX, l.endPointY, l.lineLength, l.octave)
-                    for l in klines_cv], dtype=np.float64)
-    keep_order = raw[:, 0] < raw[:, 2]
-    sp = np.where(keep_order[:, None], raw[:, 0:2], raw[:, 2:4])
-    ep = np.where(keep_order[:, None], raw[:, 2:4], raw[:, 0:2])
-    klines = np.stack([sp, ep], axis=1)
-    return {"klines": klines, "length_klines": raw[:, 4] * np.exp2(raw[:, 5]), "angles": get_angles(klines)}
-
-
-def remove_borders(lines, border, height, width, valid_mask_given=None):
-    kl = lines["klines"]
-    if len(kl) == 0:
-        return lines
-    xs, ys = kl[:, :, 0], kl[:, :, 1]
-    ok = ((xs >= border) & (xs < width - border) & (ys >= border) & (ys < height - border)).all(axis=1)
-    np.minimum(xs, width - 0.001 - border, out=xs)     # in place, like the reference
-    np.minimum(ys, height - 0.001 - border, out=ys)
-    if isinstance(valid_mask_given, np.ndarray):
-        idx = np.floor(kl).astype(int)
-        either = valid_mask_given[idx[:, 0, 1], idx[:, 0, 0]] + valid_mask_given[idx[:, 1, 1], idx[:, 1, 0]]
-        ok &= either.astype(bool)
-    return {k: v[ok] for k, v in lines.items()}
-
-
-def filter_by_length(lines, min_length, max_sublines):
-    sel = lines["length_klines"] > min_length
-    kl, ln = lines["klines"][sel], lines["length_klines"][sel]
-    order = np.argsort(ln)[::-1][:max_sublines]
-    kl = kl[order]
-    return {"klines": kl, "length_klines": ln[order], "angles": get_angles(kl)}
-
-
-def get_dist_matrix(desc0, desc1):
-    """[b,256,N0],[b,256,N1] NumPy -> clip(2 - 2 d0^T d1, 0) [b,N0,N1] float32, on the HIP matcher kernel."""
-    from .nn_matcher import nn_matcher
-    desc0, desc1 = np.asarray(desc0), np.asarray(desc1)
-    return np.concatenate([nn_matcher(desc0[b], desc1[b], np.inf, False)[1] for b in range(desc0.shape[0])], 0)
+           "get_angles", "get_line_dist", "point_on_line", "sample_descriptors", "line_tokenizer", "preprocess"]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -232,34 +180,11 @@ class LineTransformer(nn.Module):
         K = len(klines["klines"])
         if K == 0:
             return klines
-        ds = pred_superpoint["dense_score"]
-        # a producer that also hands out the channel-last map (linetr_amd.superpoint.FusedHeadSuperPoint) saves the
-        # NCHW -> NHWC pass; the reference's key is used otherwise
-        layout = "nhwc" if pred_superpoint.get("dense_descriptor_nhwc") is not None else "nchw"
-        dd = pred_superpoint["dense_descriptor_nhwc" if layout == "nhwc" else "dense_descriptor"]
-        eng = self.engine(dd.device)
-        td, T = self.config["token_distance"], self.config["max_tokens"]
-        recs, N = eng.pack(klines["klines"], klines["length_klines"], klines["angles"], td, T)
-        align = int(torch.__version__[2]) > 2   # the reference's own version switch (line_process.py:93)
-        tb = eng.tokenize(recs, np.array([0, K], np.int32), np.array([0, N], np.int32), dd, ds, token_distance=td,
-                          max_tokens=T, align_corners=align, dense_layout=layout)
-        n_sub = torch.from_numpy(recs["n_sub"].astype(np.int64)).to(tb.sub2line.device)
-        s2l = tb.sub2line.long()
-        A = torch.zeros((K, N), device=tb.sub2line.device)
-        A[s2l, torch.arange(N, device=s2l.device)] = (1 / n_sub.to(torch.float64))[s2l].float()
-        # the reference clips the end points through a view, so the exported key-lines carry the clip
-        klines["klines"] = tb.klines[None]
-        klines["length_klines"] = tb.length[None]
-        klines["angles"] = tb.angles[None]
-        klines["sublines"] = tb.sublines[None]
-        klines["pnt_sublines"] = tb.pnt[None]
-        klines["mask_sublines"] = tb.mask[None, :, :, None]
-        klines["resp_sublines"] = tb.resp[None, :, None]
-        klines["angle_sublines"] = tb.angle_sub[None]
-        klines["desc_sublines"] = tb.desc[None]
-        klines["score_sublines"] = tb.score[None, :, :, None]
-        klines["mat_klines2sublines"] = A[None]
-        return klines
+        dd = pred_superpoint.get("dense_descriptor_nhwc")
+        if dd is None:
+            dd = pred_superpoint["dense_descriptor"]
+        return tokenize_into(klines, self.engine(dd.device), self.config["token_distance"], self.config["max_tokens"],
+                             pred_superpoint)
 
     def forward(self, data):
         if len(data["klines"]) == 0:
@@ -276,10 +201,20 @@ class LineTransformer(nn.Module):
         return data
 
     def subline2keyline(self, distance_sublines, mat_klines2sublines0, mat_klines2sublines1):
-        """Mean sub-line distance per key-line pair: (A0 @ D @ A1^T)[None], NumPy in / NumPy out."""
+        """Mean sub-line distance per key-line pair: (A0 @ D @ A1^T)[None], NumPy in / NumPy out
+        (models/line_transformer.py:277-282).  Matrices that come from this package's tokeniser carry their sub-line ->
+        key-line map and are pooled by the matcher's segmented-mean kernel (linetr_pool_distmat); any other matrix is
+        multiplied out as given."""
+        s0 = getattr(mat_klines2sublines0, "_linetr_sub2line", None)
+        s1 = getattr(mat_klines2sublines1, "_linetr_sub2line", None)
+        dev = mat_klines2sublines0.device if mat_klines2sublines0.is_cuda else None
+        d = torch.as_tensor(np.asarray(distance_sublines), dtype=torch.float32)
+        if s0 is not None and s1 is not None and d.dim() == 2:
+            eng = self.engine(dev)
+            K0, K1 = int(mat_klines2sublines0.shape[-2]), int(mat_klines2sublines1.shape[-2])
+            return eng.pool_distmat(d.to(eng.device), s0, K0, s1, K1)[None].cpu().numpy()
         a0, a1 = mat_klines2sublines0.float(), mat_klines2sublines1.float()
-        d = torch.as_tensor(np.asarray(distance_sublines), dtype=torch.float32, device=a0.device)
-        return (a0 @ d @ a1.t())[None].cpu().numpy()
+        return (a0 @ d.to(a0.device) @ a1.t())[None].cpu().numpy()
 
     def default_ret(self):
         return {"klines": torch.empty((1, 0, 2, 2)), "sublines": torch.empty((1, 0, 2, 2)),

@@ -78,9 +78,15 @@ class Matching(torch.nn.Module):
             if isinstance(data[k], (list, tuple)):
                 data[k] = torch.stack(data[k])
 
-        # point matches (nn_matcher on the device)
-        m_p, d_p = nn_matcher(data["descriptors0"][0].detach().cpu().numpy(), data["descriptors1"][0].detach().cpu().numpy(),
-                              self.superpoint.config["nn_threshold"], is_mutual_NN=True)
+        # point matches (models/nn_matcher.py:33-42 on the device; the descriptors never leave it)
+        d0, d1 = data["descriptors0"][0].detach(), data["descriptors1"][0].detach()
+        if d0.is_cuda and d0.shape[0] == 256 and d0.shape[1] > 0 and d1.shape[1] > 0:
+            eng = self._engine_for(d0.device)
+            dist, m01 = eng.match_points(d0, d1, float(np.float32(self.superpoint.config["nn_threshold"])), True)
+            m01_h, dist_h = eng.to_host(m01, dist)
+            m_p, d_p = match01_to_matrix(m01_h, int(d1.shape[1])), dist_h[None]
+        else:   # empty sets / host tensors: the NumPy-in, NumPy-out surface function
+            m_p, d_p = nn_matcher(d0.cpu().numpy(), d1.cpu().numpy(), self.superpoint.config["nn_threshold"], is_mutual_NN=True)
         pred["matches_p"] = torch.from_numpy(m_p)
         pred["matching_scores_p"] = torch.from_numpy(d_p)
 
@@ -91,6 +97,13 @@ class Matching(torch.nn.Module):
         pred["matching_scores_l"] = torch.from_numpy(d_l)
         return pred
 
+    def _engine_for(self, device):
+        try:
+            return self.linetransformer.engine(device)
+        except RuntimeError:      # LineTransformer still on the CPU: the matcher needs no weights
+            from .line_process import _token_engine
+            return _token_engine(device)
+
     def forward_batch(self, pairs):
         """Batched counterpart of forward() (section 8(f)-3: the reference's surface is one pair per call).
 
@@ -100,7 +113,7 @@ class Matching(torch.nn.Module):
         linetr_match call.  Returns a list of P dicts with the keys forward() produces, except that the dense
         per-token tensors (pnt/mask/desc/score_sublines) are not materialised.  Key-line order follows the native
         pre-filter (ties in length: stable), everything else is identical to forward()."""
-        from .synth import keylines_to_array
+        from .line_process import keylines_to_array
         lt = self.linetransformer
         P = len(pairs)
         if P == 0:
@@ -181,10 +194,17 @@ class Matching(torch.nn.Module):
             return np.zeros((1, K0, K1)), np.zeros((1, K0, K1), dtype=np.float32)
         eng = self.linetransformer.engine(line_desc0.device if line_desc0.is_cuda else None)
         dev = eng.device
-        d0 = line_desc0[0].to(dev).t().contiguous()
-        d1 = line_desc1[0].to(dev).t().contiguous()
-        s0 = mat0[0].to(dev).argmax(dim=0).to(torch.int32)
-        s1 = mat1[0].to(dev).argmax(dim=0).to(torch.int32)
+        d0 = line_desc0[0].to(dev).t()      # [N,256] rows: line_desc is a transposed view of exactly that, so no copy
+        d1 = line_desc1[0].to(dev).t()
+        # matrices made by this package's tokeniser carry their sub-line -> key-line map; any other (an anchor reloaded from
+        # an .npz, say) is reduced to it here
+        s0 = getattr(mat0, "_linetr_sub2line", None)
+        s1 = getattr(mat1, "_linetr_sub2line", None)
+        if s0 is None:
+            s0 = mat0[0].to(dev).argmax(dim=0).to(torch.int32)
+        if s1 is None:
+            s1 = mat1[0].to(dev).argmax(dim=0).to(torch.int32)
         dk, _, m01 = eng.match(d0, np.array([0, N0]), s0, np.array([0, K0]), d1, np.array([0, N1]), s1,
                                np.array([0, K1]), float(np.float32(thr)), True)
-        return match01_to_matrix(m01.cpu().numpy(), K1), dk.view(1, K0, K1).cpu().numpy()
+        m01_h, dk_h = eng.to_host(m01, dk)   # one synchronisation for both results
+        return match01_to_matrix(m01_h, K1), dk_h.reshape(1, K0, K1)

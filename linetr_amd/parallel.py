@@ -67,6 +67,17 @@ def pack_descriptors(line_desc: torch.Tensor, cu_n, n_images_cap: int, rows_cap:
     dev = line_desc.device
     if out is None:
         out = torch.zeros((hr + mr + rows_cap, D), dtype=torch.float32, device=dev)
+    if dev.type == "cuda" and d_cu_n is not None and (cu_k is None or d_cu_k is not None) and out.is_contiguous():
+        # ONE launch (linetr_pack_slab): header from the device prefix sums, sub-line map and descriptor rows
+        import ctypes as C
+        from . import _native as nat
+        ld = line_desc if (line_desc.dtype == torch.float32 and line_desc.is_contiguous()) else line_desc.float().contiguous()
+        s2l = sub2line.to(torch.int32).contiguous() if sub2line is not None else None
+        with torch.cuda.device(dev):
+            nat.check(nat.lib().linetr_pack_slab(ld.data_ptr(), N, d_cu_n.data_ptr(), d_cu_k.data_ptr() if d_cu_k is not None else None,
+                                                 n_img, s2l.data_ptr() if s2l is not None else None, n_images_cap, rows_cap, 0,
+                                                 out.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return out
     hdr = out[:hr].view(torch.int32).view(-1)
     if d_cu_n is not None and (cu_k is None or d_cu_k is not None):
         hdr[0:1].fill_(n_img)

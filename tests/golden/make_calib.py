@@ -6,7 +6,7 @@ distances ~1e-4, argmin margins ~1e-6), which would make "matches bit-exact by i
 A trained checkpoint does not behave like that because its BN running stats match its activations.
 This script reproduces that property: it runs the CPU oracle once on a calibration image
 (synthetic lines/maps, seed 13) and records, for every BatchNorm, the per-channel mean/variance of
-its input.  The result (36 KB of data) is committed as linetr_amd/data/bn_calib_seed0.npz and
+its input.  The result (36 KB of data) is committed as workloads/data/bn_calib_seed0.npz and
 overlaid on ``synth.make_state_dict(0)`` by ``synth.calibrated_state_dict()``.
 
     python tests/golden/make_calib.py
@@ -23,7 +23,7 @@ import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 torch.set_grad_enabled(False)
-from linetr_amd import synth  # noqa: E402
+from workloads import synth  # noqa: E402
 from oracle import linetr_oracle as O  # noqa: E402
 
 
@@ -56,7 +56,7 @@ def main(seed=0, image_seed=13):
         O.forward(sd, data, (480, 640))
     finally:
         O._mlp = keep
-    path = os.path.join(ROOT, "linetr_amd", "data", f"bn_calib_seed{seed}.npz")
+    path = os.path.join(ROOT, "workloads", "data", f"bn_calib_seed{seed}.npz")
     np.savez_compressed(path, **stats)
     print(path, len(stats), "tensors", os.path.getsize(path) // 1024, "KB")
 

@@ -14,7 +14,7 @@ import torch
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, ROOT)
-from linetr_amd import synth  # noqa: E402
+from workloads import synth  # noqa: E402
 from oracle import linetr_oracle as O  # noqa: E402
 
 P, S, N_LINES, H, W, STRENGTH = 8, 3, 40, 480, 640, 0.05

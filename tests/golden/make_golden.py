@@ -6,7 +6,7 @@ Run in the build container only (needs /root/reference):
     python tests/golden/make_golden.py
 
 It imports the reference's hot-path modules exactly as SURVEY.md Appendix D prescribes (cv2 stub,
-mode='train' so no weight file is needed), loads the seeded weights of ``linetr_amd.synth`` into
+mode='train' so no weight file is needed), loads the seeded weights of ``workloads.synth`` into
 the reference model, pushes synthetic KeyLines + dense maps through ``preprocess`` -> ``forward`` ->
 the line-matching tail of ``Matching.forward`` and freezes inputs + outputs as small .npz files.
 Only data is written; no reference source or bytecode is copied.  The fixtures are what pins
@@ -34,7 +34,7 @@ from models.line_transformer import LineTransformer  # noqa: E402  (reference)
 from models.nn_matcher import nn_matcher_distmat, nn_matcher  # noqa: E402  (reference)
 from models.line_process import get_dist_matrix  # noqa: E402  (reference)
 
-from linetr_amd import synth  # noqa: E402
+from workloads import synth  # noqa: E402
 
 TENSOR_KEYS = ["klines", "length_klines", "angles", "sublines", "pnt_sublines", "mask_sublines",
                "resp_sublines", "angle_sublines", "score_sublines", "mat_klines2sublines"]

@@ -4,7 +4,7 @@
     python tests/golden/make_golden_superpoint.py        (build container only: needs /root/reference)
 
 The reference's SuperPoint constructor loads `weights/superpoint_v1.pth`, which is not in the checkout; weights are
-data, so `torch.load` is pointed at the seeded state_dict of `linetr_amd.synth.superpoint_state_dict` for the
+data, so `torch.load` is pointed at the seeded state_dict of `workloads.synth.superpoint_state_dict` for the
 duration of the constructor.  Forward hooks capture the raw head outputs (convPb / convDb); the fixture holds those
 inputs plus everything `SuperPoint.forward` returns.  Only data is written.
 """
@@ -25,7 +25,7 @@ torch.set_grad_enabled(False)
 import models.superpoint as ref_sp  # noqa: E402  (reference)
 assert ref_sp.__file__.startswith("/root/reference/"), ref_sp.__file__
 
-from linetr_amd import synth  # noqa: E402
+from workloads import synth  # noqa: E402
 
 
 def build(seed, **cfg):

@@ -17,7 +17,7 @@ import make_golden as G  # noqa: E402  (sets up the cv2 stub and puts /root/refe
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from linetr_amd import synth  # noqa: E402
+from workloads import synth  # noqa: E402
 
 BATCH_KEYS = ["sublines", "pnt_sublines", "mask_sublines", "resp_sublines", "angle_sublines", "desc_sublines", "score_sublines"]
 

@@ -4,7 +4,7 @@ import os
 import numpy as np
 import torch
 
-from linetr_amd import synth
+from workloads import synth
 from oracle import linetr_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")

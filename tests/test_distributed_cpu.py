@@ -80,6 +80,47 @@ def test_allgather_roundtrip_world2(n_pairs):
     assert dict(ret) == {0: True, 1: True}
 
 
+def _sparse_worker(rank, world, port, n_pairs_total, ret):
+    """fewer pairs than ranks: some ranks contribute an EMPTY slab; the slab height is agreed with one MAX all-reduce of the
+    ranks' (very uneven) local row counts, as bench.py's cfg4 job does."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine, ld, cu, cu_k, s2l = _rank_payload(rank, n_pairs_total, world)
+        img_cap = 2 * max(1, (n_pairs_total + world - 1) // world)
+        rows_cap = torch.tensor([int(cu[-1])])
+        dist.all_reduce(rows_cap, op=dist.ReduceOp.MAX)
+        rows_cap = max(int(rows_cap.item()), 1)
+        slab = parallel.pack_descriptors(ld, cu, img_cap, rows_cap, cu_k=cu_k, sub2line=s2l)
+        gs = parallel.GatheredSet(parallel.allgather_descriptors(slab), img_cap, rows_cap)
+        ok = True
+        for r in range(world):
+            r_mine, want_ld, want_cu, want_ck, want_m = _rank_payload(r, n_pairs_total, world)
+            ok &= np.array_equal(gs.cu_n[r], want_cu) and np.array_equal(gs.cu_k[r], want_ck)
+            ok &= (len(r_mine) == 0) == (len(gs.cu_n[r]) == 1)
+            for li in range(len(want_cu) - 1):
+                row, n, m, k = gs.image(r, li)
+                ok &= torch.equal(gs.flat[row:row + n], want_ld[want_cu[li]:want_cu[li + 1]])
+                ok &= torch.equal(gs.flat_i32[m:m + n], want_m[want_cu[li]:want_cu[li + 1]])
+                ok &= k == int(want_ck[li + 1] - want_ck[li])
+        for p in range(n_pairs_total):          # every pair is addressable from every rank, whoever owns it
+            row, n, _, _ = gs.pair_image(p, 1)
+            ok &= n == 3 + (7 * p + 5) % 11
+        ret[rank] = (bool(ok), len(mine))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_without_pairs_and_uneven_slabs_world4():
+    world, n_pairs = 4, 3                        # rank 3 owns nothing
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sparse_worker, args=(world, _free_port(), n_pairs, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: (True, 1), 1: (True, 1), 2: (True, 1), 3: (True, 0)}
+
+
 def _oracle_match(desc0, s2l0, k0, desc1, s2l1, k1, thr=0.8):
     """the oracle's matcher on [n,256] descriptors + key-line maps (what linetr_match_gathered computes on the GPU)."""
     from oracle import linetr_oracle as O
@@ -146,7 +187,7 @@ def test_cfg4_global_matching_on_gathered_set(world):
 
 def test_cfg4_fixture_recall_against_homography():
     """the frozen job itself: own-partner matches (s = 0) recover the correspondences the known homography defines."""
-    from linetr_amd import synth
+    from workloads import synth
     g = np.load(GOLD)
     hit = tot = 0
     for p in range(int(g["P"])):
@@ -180,7 +221,7 @@ def test_pack_capacity_errors():
 def test_homography_sampler_properties():
     """cfg4 generator: deterministic per seed, warped end points of the common lines land on image-1 rows, every line
     inside the margin box, strength -> 0 tends to the identity."""
-    from linetr_amd import synth
+    from workloads import synth
     a = synth.homography_pair(7, 60)
     b = synth.homography_pair(7, 60)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
@@ -204,7 +245,7 @@ def test_warped_dense_maps_follow_the_homography():
     the descriptor sampled from view 1 at M x0 has cosine > 0.9 with view 0's descriptor at x0 (bilinear resampling +
     5 % noise), and the score maps agree the same way -- i.e. the warp goes in the direction the line end points do."""
     import torch.nn.functional as F
-    from linetr_amd import synth
+    from workloads import synth
     H, W = 240, 320
     rs = np.random.RandomState(5)
     m = synth.pixel_homography(rs, H, W, strength=0.3)

@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 import torch
 
-from linetr_amd import parallel, synth
+from linetr_amd import parallel
+from workloads import synth
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)

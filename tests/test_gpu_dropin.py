@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from helpers import BASE_CFG, TOK_KEYS, load, tiny_maps
-from linetr_amd import synth
+from workloads import synth
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from linetr_amd import _native as nat
-from linetr_amd import synth
+from workloads import synth
 from test_gpu_properties import batch_inputs, describe
 
 pytestmark = [pytest.mark.gpu,

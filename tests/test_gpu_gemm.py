@@ -3,7 +3,7 @@ configurations, ragged M, every fused epilogue)."""
 import pytest
 import torch
 
-from linetr_amd import synth
+from workloads import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -118,7 +118,7 @@ def _folded_mlp_reference(sd, prefix, x, n_layers=3):
 def test_fused_posenc_layers_vs_torch(rows):
     """mlp123_kernel (exact-fp32 MFMA, layers 1-3 of both positional encoders) against stock PyTorch fp32 on the same
     rows: ragged row counts around the 32-row MFMA step and the per-wave row split."""
-    from linetr_amd import synth
+    from workloads import synth
     from linetr_amd.engine import Engine
     sd = synth.calibrated_state_dict()
     eng = Engine(sd, "cuda:0")

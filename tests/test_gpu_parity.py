@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from helpers import BASE_CFG, TOK_KEYS, golden_cfg, load, oracle_image, tiny_maps, weights_for
-from linetr_amd import synth
+from workloads import synth
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)

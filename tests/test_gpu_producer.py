@@ -7,7 +7,7 @@ import pytest
 import torch
 from torch import nn
 
-from linetr_amd import synth
+from workloads import synth
 from oracle import linetr_oracle as O
 
 pytestmark = pytest.mark.gpu

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from helpers import BASE_CFG
-from linetr_amd import synth
+from workloads import synth
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)

@@ -1,0 +1,130 @@
+"""GPU fuzz of the tokeniser: a few thousand random detector lines per run through linetr_prefilter_batch + linetr_tokenize,
+EVERY token tensor compared with the CPU oracle (models/line_process.py:100-196 restated in oracle/linetr_oracle.py).
+
+"Line matches bit-exact by index" starts here: the f64 sqrt / division chains of point_on_line, torch.round's half-to-even in
+the score gather, the end-point clip, sub-line chaining and a non-integer token_distance all have to round exactly like
+NumPy / PyTorch-CPU do.  Geometry classes mixed into every image: generic, vertical (dx == 0), horizontal on half-pixel rows
+(token coordinates land on exact .5: the half-to-even case), reversed end points, octave 1, border-grazing end points, and
+lengths of up to five sub-lines."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import TOK_KEYS
+from oracle import linetr_oracle as O
+from workloads import synth
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+HW = (960, 1280)
+BORDER, MIN_LEN = 8, 16
+
+
+def fuzz_lines(seed, n, td, T, hw=HW):
+    """[n,6] detector rows (startX, startY, endX, endY, lineLength, octave), float32-representable like cv2's KeyLines."""
+    rs = np.random.RandomState(seed)
+    H, W = hw
+    lo, hi = float(BORDER), np.array([W - BORDER - 1e-3, H - BORDER - 1e-3])
+    max_len = min(5 * T * td - 1.0, 0.9 * min(H, W))        # up to five sub-lines, inside the image
+    rows = []
+    while len(rows) < n:
+        kind = rs.randint(0, 8)
+        L = rs.uniform(MIN_LEN + 0.5, max_len)
+        sp = np.array([rs.uniform(lo, hi[0]), rs.uniform(lo, hi[1])])
+        if kind == 0:                                        # vertical: dx == 0 exactly
+            ep = sp + np.array([0.0, L if rs.rand() < 0.5 else -L])
+        elif kind == 1:                                      # horizontal on a half-pixel row, integer start: tokens on exact .5 / integers
+            sp = np.array([float(rs.randint(BORDER, W - BORDER)), rs.randint(BORDER, H - BORDER - 1) + 0.5])
+            ep = sp + np.array([float(int(L)), 0.0])
+        elif kind == 2:                                      # end point grazing the right / bottom border (clip of line_process.py:72-74, :114-116)
+            th = rs.uniform(-0.4, 0.4)
+            ep = np.array([W - BORDER - rs.choice([1e-4, 5e-4, 0.3, 0.7]), sp[1] + L * np.sin(th)])
+            sp = np.array([ep[0] - L * np.cos(th), sp[1]])
+        elif kind == 3:                                      # start point exactly on the border
+            th = rs.uniform(0, 2 * np.pi)
+            sp = np.array([float(BORDER), rs.uniform(lo, hi[1])])
+            ep = sp + L * np.array([abs(np.cos(th)), np.sin(th)])
+        else:                                                # generic, both end-point orders
+            th = rs.uniform(0, 2 * np.pi)
+            ep = sp + L * np.array([np.cos(th), np.sin(th)])
+        sp32, ep32 = sp.astype(np.float32).astype(np.float64), ep.astype(np.float32).astype(np.float64)
+        if not (np.all(sp32 >= lo) and np.all(sp32 < hi + 1e-3) and np.all(ep32 >= lo) and np.all(ep32 < hi + 1e-3)):
+            continue
+        octave = int(rs.rand() < 0.25)
+        length = np.float32(np.hypot(*(ep32 - sp32))) / np.float32(2 ** octave)   # cv2 reports the length at the octave's scale
+        if rs.rand() < 0.5:
+            sp32, ep32 = ep32, sp32                          # the detector's end-point order is arbitrary (:212-217)
+        rows.append([sp32[0], sp32[1], ep32[0], ep32[1], float(length), float(octave)])
+    rows = np.asarray(rows, np.float64)
+    # unique lengths: np.argsort's order among EQUAL lengths is CPU-dependent and is not what this test is about
+    full = rows[:, 4] * 2.0 ** rows[:, 5]
+    _, first = np.unique(full, return_index=True)
+    return rows[np.sort(first)]
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from linetr_amd.engine import Engine
+    return Engine(synth.calibrated_state_dict(), "cuda:0", image_shape=list(HW))
+
+
+@pytest.fixture(scope="module")
+def maps():
+    dd, ds = synth.synth_dense_maps(4242, *HW)
+    return dd, ds
+
+
+@pytest.mark.parametrize("td", [8, 12.8, 16])
+@pytest.mark.parametrize("T", [3, 21, 41])
+def test_tokenizer_fuzz_vs_oracle(engine, maps, td, T):
+    dd, ds = maps
+    n_img, per = 3, 210                                                  # 9 configurations x 630 lines = 5670 lines per run
+    rows = [fuzz_lines(1000 * T + int(td * 10) + i, per, td, T) for i in range(n_img)]
+    cfg = dict(min_length=MIN_LEN, token_distance=td, max_tokens=T, remove_borders=BORDER, max_keylines=-1)
+    recs, cu_k, cu_n = engine.prefilter(rows, *HW, remove_borders=BORDER, min_length=MIN_LEN, max_keylines=-1,
+                                        token_distance=td, max_tokens=T)
+    tb = engine.tokenize(recs, cu_k, cu_n, torch.cat([dd] * n_img).cuda(), torch.cat([ds] * n_img).cuda(), token_distance=td,
+                         max_tokens=T, align_corners=False)
+    torch.cuda.synchronize()
+    n_multi = 0
+    for i in range(n_img):
+        want = O.preprocess(synth.array_to_keylines(rows[i]), (1, 1, *HW), dd, ds, cfg, align_corners=False)
+        k0, k1, n0, n1 = tb.cu_k[i], tb.cu_k[i + 1], tb.cu_n[i], tb.cu_n[i + 1]
+        assert want["klines"].shape[1] == k1 - k0 and want["sublines"].shape[1] == n1 - n0
+        s2l = tb.sub2line[n0:n1].cpu().numpy()
+        cnt = np.bincount(s2l, minlength=k1 - k0)
+        n_multi += int((cnt > 1).sum())
+        A = np.zeros((k1 - k0, n1 - n0), np.float32)
+        A[s2l, np.arange(n1 - n0)] = (1.0 / cnt[s2l]).astype(np.float32)
+        got = {"klines": tb.klines[k0:k1], "length_klines": tb.length[k0:k1], "angles": tb.angles[k0:k1],
+               "sublines": tb.sublines[n0:n1], "pnt_sublines": tb.pnt[n0:n1], "mask_sublines": tb.mask[n0:n1][..., None],
+               "resp_sublines": tb.resp[n0:n1][..., None], "angle_sublines": tb.angle_sub[n0:n1],
+               "score_sublines": tb.score[n0:n1][..., None], "mat_klines2sublines": torch.from_numpy(A)}
+        for k in TOK_KEYS:
+            have, ref = got[k].cpu().numpy(), want[k][0].numpy()
+            assert have.shape == ref.shape, (k, have.shape, ref.shape)
+            if "angle" in k:        # host libm vs NumPy cos/sin: last float64 ulp, <= 1.2e-7 after the float32 cast
+                assert np.abs(have - ref).max() <= 1.2e-7, k
+            else:
+                assert np.array_equal(have, ref), (k, td, T, i, np.abs(have - ref).max())
+        err = (tb.desc[n0:n1].cpu() - want["desc_sublines"][0]).abs().max().item()
+        assert err <= 1e-6, err
+    assert n_multi > 0 or T * td > 600, "the fuzz must exercise sub-line chaining"
+
+
+def test_single_image_mat_written_by_the_tokeniser_launch(engine, maps):
+    """mat_klines2sublines out of the tokeniser's own launch (LinetrTokens.mat) == the reference's matrix, chained sub-lines included."""
+    dd, ds = maps
+    rows = fuzz_lines(77, 150, 8, 3)
+    cfg = dict(min_length=MIN_LEN, token_distance=8, max_tokens=3, remove_borders=BORDER, max_keylines=-1)
+    recs, cu_k, cu_n = engine.prefilter([rows], *HW, remove_borders=BORDER, min_length=MIN_LEN, max_keylines=-1,
+                                        token_distance=8, max_tokens=3)
+    tb = engine.tokenize(recs, cu_k, cu_n, dd.cuda(), ds.cuda(), token_distance=8, max_tokens=3, want_mat=True)
+    want = O.preprocess(synth.array_to_keylines(rows), (1, 1, *HW), dd, ds, cfg, align_corners=False)
+    assert np.array_equal(tb.mat.cpu().numpy(), want["mat_klines2sublines"][0].numpy())
+    assert (np.count_nonzero(tb.mat.cpu().numpy(), axis=1) > 1).any()
+    with pytest.raises(ValueError):
+        engine.tokenize(*engine.prefilter([rows, rows], *HW, remove_borders=BORDER, min_length=MIN_LEN, max_keylines=-1,
+                                          token_distance=8, max_tokens=3), torch.cat([dd, dd]).cuda(),
+                        torch.cat([ds, ds]).cuda(), token_distance=8, max_tokens=3, want_mat=True)

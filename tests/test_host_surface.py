@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from helpers import BASE_CFG, load
-from linetr_amd import synth
+from workloads import synth
 from linetr_amd import line_transformer as LT
 from oracle import linetr_oracle as O
 

@@ -9,7 +9,7 @@ import pytest
 
 from helpers import BASE_CFG, load
 from linetr_amd import _native as nat
-from linetr_amd import synth
+from workloads import synth
 from oracle import linetr_oracle as O
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
         LX = nat.lib(nat.EXPERIMENTS_LIB_PATH)
         for name in declared | declared_x:
             assert hasattr(LX, name), name
-    assert L.linetr_abi_version() == 2
+    assert L.linetr_abi_version() == 3
     assert C.sizeof(nat.LineRec) == 80
 
 

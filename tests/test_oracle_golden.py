@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from linetr_amd import synth
+from workloads import synth
 from oracle import linetr_oracle as O
 from helpers import BASE_CFG, TOK_KEYS, golden_cfg, load, oracle_image, tiny_maps, weights_for
 

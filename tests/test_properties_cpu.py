@@ -7,7 +7,7 @@ import torch
 from hypothesis import given, settings, strategies as st
 
 from linetr_amd import _native as nat
-from linetr_amd import synth
+from workloads import synth
 from oracle import linetr_oracle as O
 
 torch.set_grad_enabled(False)

@@ -8,7 +8,7 @@ for spec in "$@"; do
   label="${spec%%:*}"; envs=""
   if [[ "$spec" == *:* ]]; then envs="${spec#*:}"; fi
   ( IFS=','; for kv in $envs; do export "$kv"; done
-    python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-alt-precisions --no-sub-workloads 2>/dev/null | tail -1 > gpurun_out/ab_$label.json )
+    python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sub-workloads 2>/dev/null | tail -1 > gpurun_out/ab_$label.json )
   python - "$label" <<'PY'
 import json, sys
 d = json.load(open(f"gpurun_out/ab_{sys.argv[1]}.json"))

@@ -1,6 +1,6 @@
 for P in 32 16; do for mode in classic st; do
   if [ $mode = classic ]; then export LINETR_SIG_PATH=classic; else unset LINETR_SIG_PATH; fi
-  python bench.py --pairs $P --steps 20 --warmup 3 --no-cpu-baseline --no-alt-precisions --no-sub-workloads 2>/dev/null | tail -1 > gpurun_out/ab_p${P}_$mode.json
+  python bench.py --pairs $P --steps 20 --warmup 3 --no-cpu-baseline --no-sub-workloads 2>/dev/null | tail -1 > gpurun_out/ab_p${P}_$mode.json
   python - $P $mode <<'PY'
 import json, sys
 d = json.load(open(f"gpurun_out/ab_p{sys.argv[1]}_{sys.argv[2]}.json"))

@@ -1,6 +1,6 @@
 import torch, time, sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-from linetr_amd import synth
+from workloads import synth
 from linetr_amd.engine import Engine
 eng = Engine(synth.make_state_dict(0), 'cuda:0')
 keep=[]

@@ -3,7 +3,7 @@ usage: python tools/gemm_clock_probe.py bf16x6 8192 4096 4096 [seconds]"""
 import os, subprocess, sys, threading, time, re
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-from linetr_amd import synth
+from workloads import synth
 from linetr_amd.engine import Engine
 mode = sys.argv[1]; M, N, K = map(int, sys.argv[2:5]); secs = float(sys.argv[5]) if len(sys.argv) > 5 else 4.0
 eng = Engine(synth.make_state_dict(0), 'cuda:0')

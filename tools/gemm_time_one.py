@@ -3,7 +3,7 @@ LINETR_LIB at its ablation builds):   python tools/gemm_time_one.py bf16x6 8192 
 import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-from linetr_amd import synth
+from workloads import synth
 from linetr_amd.engine import Engine
 mode = sys.argv[1]; M, N, K = map(int, sys.argv[2:5])
 eng = Engine(synth.make_state_dict(0), 'cuda:0'); eng.set_precision(mode)

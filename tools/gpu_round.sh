@@ -13,7 +13,7 @@ if has bench; then
   timeout 600 python bench.py --steps 20 --warmup 5 > ${O}_bench.json 2> ${O}_bench.log; echo "bench rc=$?"; cut -c1-900 ${O}_bench.json
 fi
 if has shapes; then   # per-GEMM-shape HIP-event profile of the cfg3 step
-  LINETR_LIB=$PWD/linetr_amd/csrc/liblinetr_hip_experiments.so LINETR_PROFILE_SHAPES=1 timeout 300 python bench.py --steps 10 --no-cpu-baseline --no-alt-precisions --no-sub-workloads > ${O}_bench_shapes.json 2> ${O}_bench_shapes.log
+  LINETR_LIB=$PWD/linetr_amd/csrc/liblinetr_hip_experiments.so LINETR_PROFILE_SHAPES=1 timeout 300 python bench.py --steps 10 --no-cpu-baseline --no-sub-workloads > ${O}_bench_shapes.json 2> ${O}_bench_shapes.log
   python - ${O}_bench_shapes.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
@@ -26,7 +26,7 @@ if has hostprof; then   # where the host side of a cfg3 step goes (cProfile over
 import cProfile, pstats, sys, torch
 sys.argv = ["bench.py"]
 import bench
-from linetr_amd import synth
+from workloads import synth
 from linetr_amd.engine import Engine
 dev = torch.device("cuda:0")
 eng = Engine(synth.calibrated_state_dict(), dev, image_shape=[480, 640])
@@ -60,7 +60,7 @@ fi
 if has prof; then     # rocprofv3 kernel stats, one run per workload
   for wl in cfg3 cfg2 cfg5; do
     timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$wl -o p -- \
-      python bench.py --workload $wl --steps 5 --warmup 2 --settle-s 0.5 --no-cpu-baseline --no-alt-precisions --no-sub-workloads \
+      python bench.py --workload $wl --steps 5 --warmup 2 --settle-s 0.5 --no-cpu-baseline --no-sub-workloads \
       > ${O}_${wl}_bench_under_rocprof.json 2> ${O}_${wl}_prof.log
     f=$(ls gpurun_out/prof_${tag}_$wl/*kernel_stats.csv 2>/dev/null | head -1)
     [ -n "$f" ] && cp "$f" ${O}_${wl}_kernel_stats.csv && head -7 ${O}_${wl}_kernel_stats.csv | cut -c1-150

@@ -4,7 +4,8 @@ import ctypes as C, os, sys, json, subprocess
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import bench
-from linetr_amd import synth, _native
+from linetr_amd import _native
+from workloads import synth
 from linetr_amd.engine import Engine
 eng = Engine(synth.calibrated_state_dict(), 'cuda:0')
 lines, dd, ds, (H, W), T = bench.make_inputs('cfg3', 64, 0, eng.device)

@@ -5,7 +5,7 @@
 tag=${1:-rXX}; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-BENCH="python bench.py --steps 2 --warmup 1 --settle-s 0 --no-cpu-baseline --no-alt-precisions --no-sub-workloads $*"
+BENCH="python bench.py --steps 2 --warmup 1 --settle-s 0 --no-cpu-baseline --no-sub-workloads $*"
 pass() {
   name=$1; shift
   timeout -k 5 120 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$name -o p -- $BENCH > gpurun_out/pmc_$name.log 2>&1
