@@ -422,6 +422,7 @@ extern "C" void linetr_destroy(LinetrHandle* h) {
   if (h->zeros) (void)hipFree(h->zeros);
   if (h->sk_ws) (void)hipFree(h->sk_ws);
   if (h->sk_flags) (void)hipFree(h->sk_flags);
+  if (h->pn_abort) (void)hipHostFree(h->pn_abort);
   for (auto& kv : h->debug_split) (void)hipFree(kv.second);
   delete h;
 }

@@ -395,9 +395,11 @@ struct FwdWs {
   float *a1, *a2, *a3, *a4, *pooled, *att, *fc, *o, *f1, *f2, *l1, *l2, *l3, *l4, *lpos, *zA, *zB, *qkv, *msgp, *msg, *hid;
   unsigned char *zsA, *zsB, *qkvs, *msgs, *hids;   // split-tile images of the signature network's activations (lt_gemm_st.h)
   int* cu;
+  char* pn;                                        // activations + arrival counters of the single-pair persistent network (lt_pairnet.h)
   int64_t total;
 };
-FwdWs fwd_layout(const LinetrModelConfig& c, int N, int64_t rows, int n_images, char* base) {
+FwdWs fwd_layout(const LinetrHandle* h, int N, int64_t rows, int n_images, char* base) {
+  const LinetrModelConfig& c = h->cfg;
   FwdWs w;
   int64_t off = 0;
   auto take = [&](int64_t floats) { float* p = (float*)(base + off); off += align_up(floats * 4, 256); return p; };
@@ -420,6 +422,8 @@ FwdWs fwd_layout(const LinetrModelConfig& c, int N, int64_t rows, int n_images, 
   w.zsA = w.zsB = w.qkvs = w.msgs = w.hids = nullptr;
 #endif
   w.cu = (int*)take(n_images + 1);
+  w.pn = base + off;
+  off += pairnet_ws_bytes(h, N);                   // 0 for batches the path does not take (too many rows)
   w.total = off;
   return w;
 }
@@ -428,7 +432,7 @@ FwdWs fwd_layout(const LinetrModelConfig& c, int N, int64_t rows, int n_images, 
 extern "C" int64_t linetr_forward_workspace_bytes(const LinetrHandle* h, int32_t N, int32_t T) {
   if (!h) return -1;
   // the image count only sizes a tiny prefix-sum array; reserve for the worst case (every sub-line its own image)
-  return fwd_layout(h->cfg, std::max(N, 1), (int64_t)std::max(N, 1) * T, std::max(N, 1), nullptr).total;
+  return fwd_layout(h, std::max(N, 1), (int64_t)std::max(N, 1) * T, std::max(N, 1), nullptr).total;
 }
 
 namespace {
@@ -528,6 +532,10 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   const float cx = c.norm_width / 2.f, cy = c.norm_height / 2.f;           // line_transformer.py:30-32
   const float scale = (float)std::max(c.norm_width, c.norm_height) * 0.7f;
   int e;
+  // a single pair (a few small images): the whole signature network below is ONE persistent launch (lt_pairnet.h); its arrival
+  // counters are zeroed here, far ahead of it on the stream
+  const bool pairnet = !ts.use_side && pairnet_fits(h, n_images, N, h_cu);
+  if (pairnet && (e = pairnet_prepare(h, st, N, w.pn))) return e;
   // ---- word positional encoder up to the last ReLU (a4); its final linear layer is applied after pooling
   const bool fused_mlp = fused_mlp_enabled(c);
   // layers 1-4 in one kernel (lt_tokmlp.h): large batches in the default precision, the reference's channel widths
@@ -688,6 +696,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   }
   }
   // ---- line signature network
+  if (pairnet && !chain) return pairnet_run(h, st, w.zA, d_line_desc, h_cu, n_images, N, w.pn);
   // LINETR_SIG_PATH=st (experiment): activations stay in HBM as split-tile images and every K step travels by LDS-DMA
   // (lt_gemm_st.h, lt_attn_st.h).  Measured at cfg3 on one box: the ST GEMMs are 5-7 % faster than the register-staged
   // ones in isolation, but inside the step the 6-byte activations cost more at the kernel boundaries (the L2 write-back of
@@ -824,7 +833,7 @@ extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const in
   if ((int64_t)N * T > INT32_MAX / 8) return fail(LINETR_E_ARG, "forward: batch too large");
   hipStream_t st = (hipStream_t)stream;
   LT_HIP(hipSetDevice(h->device));
-  FwdWs w = fwd_layout(h->cfg, N, (int64_t)N * T, std::max(N, 1), (char*)d_ws);
+  FwdWs w = fwd_layout(h, N, (int64_t)N * T, std::max(N, 1), (char*)d_ws);
   const int* cu_dev = d_cu;
   if (!cu_dev) {
     LT_HIP(hipMemcpyAsync(w.cu, h_cu, (n_images + 1) * sizeof(int), hipMemcpyHostToDevice, st));
@@ -871,7 +880,7 @@ extern "C" int64_t linetr_describe_workspace_bytes(const LinetrHandle* h, int32_
   if (!h) return -1;
   const int64_t rows = n_real + n_images;
   return desc_layout(n_images, height, width, std::max(N, 1), rows, nullptr).total +
-         fwd_layout(h->cfg, std::max(N, 1), rows, n_images, nullptr).total;
+         fwd_layout(h, std::max(N, 1), rows, n_images, nullptr).total;
 }
 
 extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N, int64_t n_real,
@@ -895,7 +904,7 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
   hipStream_t st = (hipStream_t)stream;
   LT_HIP(hipSetDevice(h->device));
   DescWs dw = desc_layout(n_images, height, width, N, rows, (char*)d_ws);
-  FwdWs w = fwd_layout(h->cfg, N, rows, n_images, (char*)d_ws + dw.fwd_off);
+  FwdWs w = fwd_layout(h, N, rows, n_images, (char*)d_ws + dw.fwd_off);
   const int Hc = height / 8, Wc = width / 8, P = Hc * Wc;
   const int* cu_dev = d_cu;
   if (!cu_dev) {

@@ -54,6 +54,11 @@ struct LinetrHandle {
   float* sk_ws = nullptr;
   unsigned* sk_flags = nullptr;
   unsigned sk_epoch = 0;
+  // single-pair persistent signature network (lt_pairnet.h, linetr_pair.hip)
+  unsigned* pn_abort = nullptr;       // host-mapped word a timed-out launch raises (read by the host before the next launch)
+  unsigned* pn_abort_dev = nullptr;   // the same word as the device sees it
+  bool pn_disabled = false;
+  int n_cu = 0;
   // profiling
   bool profiling = false;
   std::vector<ProfClass> classes;
@@ -110,5 +115,16 @@ struct ProfScope {
 // one GEMM weight of the prepared arena that needs split-precision copies (made on the device by linetr_net.hip)
 struct GemmWSpec { const float* W; int64_t rows; int K; bool st; };
 int make_split_copies(LinetrHandle* H, const std::vector<GemmWSpec>& weights);
+
+// The line-signature network of a single pair (a few small images) as ONE persistent launch (lt_pairnet.h):
+//   pairnet_fits      does this batch take the path (precision, image count, row count)?  h_cu may be NULL (size check only)
+//   pairnet_ws_bytes  bytes of workspace it needs for N rows (0 when N is out of range)
+//   pairnet_prepare   zeroes the arrival counters on the stream (call it EARLY, well ahead of the launch)
+//   pairnet_run       z0 [N,256] -> line_desc [N,256]
+constexpr int PN_MAX_ROWS = 1024;
+bool pairnet_fits(LinetrHandle* h, int n_images, int N, const int32_t* h_cu);
+int64_t pairnet_ws_bytes(const LinetrHandle* h, int N);
+int pairnet_prepare(LinetrHandle* h, hipStream_t st, int N, void* ws);
+int pairnet_run(LinetrHandle* h, hipStream_t st, const float* z0, float* out, const int32_t* h_cu, int n_images, int N, void* ws);
 
 }  // namespace lt

@@ -197,15 +197,22 @@ class Engine:
         return out, cu_k.copy(), cu_n.copy()
 
     def pack(self, klines, length, angles, token_distance, max_tokens, image=0, sub_base=0):
-        """records for already-filtered lines (float64 arrays, reference layout)."""
+        """records for already-filtered lines (float64 arrays, reference layout).  They are written into a pinned staging
+        slot together with the two prefix sums, so that tokenize() uploads them with ONE asynchronous copy."""
         K = len(klines)
-        recs = np.zeros(max(K, 1), dtype=nat.REC_DTYPE)
+        rec_bytes = max(K, 1) * nat.REC_DTYPE.itemsize
+        slot = self._pinned_slot(rec_bytes + 16 + 64)
+        host = slot["buf"].numpy()
+        recs = host[:rec_bytes].view(nat.REC_DTYPE)
         n_out = C.c_int32()
         kl = np.ascontiguousarray(klines, dtype=np.float64)
         ln = np.ascontiguousarray(length, dtype=np.float64)
         an = np.ascontiguousarray(angles, dtype=np.float64)
         nat.check(self._L.linetr_pack_lines(nat.np_ptr(kl), nat.np_ptr(ln), nat.np_ptr(an), K, float(token_distance),
                                             int(max_tokens), int(image), int(sub_base), 0, nat.np_ptr(recs), C.byref(n_out)), self._L)
+        cu = host[rec_bytes:rec_bytes + 16].view(np.int32)
+        cu[:] = (0, K, 0, n_out.value)                     # cu_k | cu_n of the one image
+        self._last_host = {"slot": slot, "recs_ptr": recs.ctypes.data, "rec_bytes": rec_bytes, "B": 1}
         return recs[:K], n_out.value
 
     # ------------------------------------------------------------------ device stages
@@ -230,17 +237,23 @@ class Engine:
             raise ValueError(f"dense_descriptor shape {tuple(dense_desc.shape)} does not match {want} ({dense_layout})")
         dev = self.device
         f = dict(dtype=torch.float32, device=dev)
-        tb = TokenBatch(
-            n_images=B, max_tokens=T, cu_k=np.asarray(cu_k, np.int32), cu_n=np.asarray(cu_n, np.int32), recs=recs,
-            klines=torch.empty((K, 2, 2), **f), length=torch.empty((K,), **f), angles=torch.empty((K, 2), **f),
-            sublines=torch.empty((N, 2, 2), **f), pnt=torch.empty((N, T, 2), **f), mask=torch.empty((N, T + 1), **f),
-            resp=torch.empty((N,), **f), angle_sub=torch.empty((N, 2), **f),
-            desc=torch.empty((N, T, D), **f) if sample_desc else torch.empty((0,), **f),
-            score=torch.empty((N, T), **f), sub2line=torch.empty((N,), dtype=torch.int32, device=dev))
+        if want_mat and B != 1:
+            raise ValueError("want_mat needs a single-image call (the reference's matrix is per image)")
+        # the small token tensors are views of ONE allocation (a dozen torch.empty calls cost ~40 us of host time per image on
+        # the drop-in path); every view starts on a 16-byte boundary
+        shapes = [("klines", (K, 2, 2)), ("length", (K,)), ("angles", (K, 2)), ("sublines", (N, 2, 2)), ("pnt", (N, T, 2)),
+                  ("mask", (N, T + 1)), ("resp", (N,)), ("angle_sub", (N, 2)), ("score", (N, T)), ("sub2line", (N,))]
         if want_mat:
-            if B != 1:
-                raise ValueError("want_mat needs a single-image call (the reference's matrix is per image)")
-            tb.mat = torch.empty((K, N), **f)    # written by extra blocks of the tokeniser's own launch
+            shapes.append(("mat", (K, N)))                  # written by extra blocks of the tokeniser's own launch
+        sizes = [(int(np.prod(sh)) + 3) // 4 * 4 for _, sh in shapes]
+        pool = torch.empty((sum(sizes),), **f)
+        views, o = {}, 0
+        for (name, sh), sz in zip(shapes, sizes):
+            views[name] = pool[o:o + int(np.prod(sh))].view(sh)
+            o += sz
+        views["sub2line"] = views["sub2line"].view(torch.int32)
+        tb = TokenBatch(n_images=B, max_tokens=T, cu_k=np.asarray(cu_k, np.int32), cu_n=np.asarray(cu_n, np.int32), recs=recs,
+                        desc=torch.empty((N, T, D), **f) if sample_desc else torch.empty((0,), **f), **views)
         if K == 0 or N == 0:
             return tb
         last = getattr(self, "_last_host", None)

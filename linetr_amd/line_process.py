@@ -8,7 +8,8 @@ device these raise).  Reference: models/line_process.py (line numbers cited per 
 """
 from __future__ import annotations
 
-import ctypes as C
+import itertools
+import operator
 
 import numpy as np
 import torch
@@ -18,6 +19,9 @@ __all__ = ["filter_by_length", "get_line_dist", "get_angles", "point_on_line", "
 
 
 # ------------------------------------------------------------------------------------------------ host glue (NumPy)
+
+_KEYLINE_FIELDS = operator.attrgetter("startPointX", "startPointY", "endPointX", "endPointY", "lineLength", "octave")
+
 
 def get_line_dist(line):
     """Euclidean length of one [2,2] line (line_process.py:23-26)."""
@@ -55,8 +59,8 @@ def change_cv2_T_np(klines_cv):
     """KeyLine objects -> {'klines' [K,2,2], 'length_klines' [K], 'angles' [K,2]} (float64; line_process.py:203-231)."""
     if len(klines_cv) == 0:
         return {"klines": np.zeros((0, 2, 2)), "length_klines": np.zeros((0,)), "angles": []}
-    raw = np.array([(l.startPointX, l.startPointY, l.endPointX, l.endPointY, l.lineLength, l.octave)
-                    for l in klines_cv], dtype=np.float64)
+    raw = np.fromiter(itertools.chain.from_iterable(map(_KEYLINE_FIELDS, klines_cv)), dtype=np.float64,
+                      count=6 * len(klines_cv)).reshape(-1, 6)
     keep_order = raw[:, 0] < raw[:, 2]
     sp = np.where(keep_order[:, None], raw[:, 0:2], raw[:, 2:4])
     ep = np.where(keep_order[:, None], raw[:, 2:4], raw[:, 0:2])
@@ -69,8 +73,8 @@ def keylines_to_array(klines_cv) -> np.ndarray:
     pre-filter (linetr_prefilter_batch) -- from KeyLine-like objects."""
     if len(klines_cv) == 0:
         return np.zeros((0, 6), dtype=np.float64)
-    return np.asarray([[l.startPointX, l.startPointY, l.endPointX, l.endPointY, l.lineLength, float(l.octave)]
-                       for l in klines_cv], dtype=np.float64)
+    return np.fromiter(itertools.chain.from_iterable(map(_KEYLINE_FIELDS, klines_cv)), dtype=np.float64,
+                       count=6 * len(klines_cv)).reshape(-1, 6)
 
 
 def remove_borders(lines, border, height, width, valid_mask_given=None):

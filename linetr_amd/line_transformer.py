@@ -25,8 +25,8 @@ from torch import nn
 from .engine import Engine
 
 from .line_process import *  # noqa: F401,F403  (the reference's module does the same: models/line_transformer.py:6)
-from .line_process import (change_cv2_T_np, filter_by_length, get_angles, get_dist_matrix, remove_borders,  # noqa: F401
-                           tokenize_into)
+from .line_process import (_token_engine, change_cv2_T_np, filter_by_length, get_angles, get_dist_matrix,  # noqa: F401
+                           remove_borders, tokenize_into)
 
 __all__ = ["LineTransformer", "get_dist_matrix", "change_cv2_T_np", "remove_borders", "filter_by_length",
            "get_angles", "get_line_dist", "point_on_line", "sample_descriptors", "line_tokenizer", "preprocess"]
@@ -117,22 +117,38 @@ class LineTransformer(nn.Module):
 
     def load_state_dict(self, *a, **k):
         self._engine = None
+        self.__dict__["_tracked"] = None
         return super().load_state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):
         self._engine = None
+        self.__dict__["_tracked"] = None
         return super()._apply(fn, *a, **k)
 
     def _weights_version(self):
-        """Changes whenever a parameter / buffer is modified in place (optimizer step, p.data.copy_, fine-tuning): the
-        native engine holds a folded COPY of the weights and must be rebuilt then."""
+        """Changes whenever a parameter / buffer is modified in place through the tensor itself (optimizer step, `with
+        torch.no_grad(): p.copy_(..)`, fine-tuning; writes through the detached alias `p.data` carry their own counter and are
+        NOT seen: call load_state_dict or `.to()` after those), re-bound
+        (p.data = t) or replaced (module.weight = nn.Parameter(...)): the native engine holds a folded COPY of the weights
+        and must be rebuilt then.  The module tree is walked once per engine; every call afterwards re-checks the cached
+        (owner dict, name, tensor) triples -- identity, storage pointer, version counter -- which costs ~40 us instead of the
+        ~340 us of a fresh named_parameters() walk (it runs on every forward of the drop-in path)."""
+        track = self.__dict__.get("_tracked")
+        if track is None:
+            track = []
+            for mod in self.modules():
+                for d in (mod._parameters, mod._buffers):
+                    for name, t in d.items():
+                        if t is not None:
+                            track.append((d, name, t, not t.is_inference()))   # inference tensors keep no version counter
+            self.__dict__["_tracked"] = track
         key = []
-        for t in list(self.parameters()) + list(self.buffers()):
-            try:
-                v = int(t._version)
-            except RuntimeError:          # inference tensors (built / loaded under torch.inference_mode()) keep no counter
-                v = -1
-            key.append((t.data_ptr(), v))     # data_ptr: `p.data = new_tensor` rebinds storage without touching _version
+        for d, name, t, versioned in track:
+            if d.get(name) is not t:                # replaced object: re-walk the tree next time, and report a new version now
+                self.__dict__["_tracked"] = None
+                return ("replaced", id(d.get(name)), len(key))
+            key.append(t.data_ptr())                # data_ptr: `p.data = new_tensor` rebinds storage without touching _version
+            key.append(t._version if versioned else -1)
         return tuple(key)
 
     # the native handle is a ctypes pointer: never pickled / deep-copied, rebuilt on first use instead
@@ -140,6 +156,7 @@ class LineTransformer(nn.Module):
         state = self.__dict__.copy()
         state["_engine"] = None
         state["_engine_key"] = None
+        state["_tracked"] = None
         return state
 
     def __deepcopy__(self, memo):
@@ -148,7 +165,7 @@ class LineTransformer(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = None if k in ("_engine", "_engine_key") else copy.deepcopy(v, memo)
+            new.__dict__[k] = None if k in ("_engine", "_engine_key", "_tracked") else copy.deepcopy(v, memo)
         return new
 
     def engine(self, device=None) -> Engine:
@@ -173,8 +190,8 @@ class LineTransformer(nn.Module):
         """Line tokenisation.  Returns the reference's dict (11 tensor entries, leading batch axis 1)."""
         klines = change_cv2_T_np(klines_cv)
         _, _, height, width = self.config["image_shape"] = image_shape
-        if valid_mask is None:
-            valid_mask = np.ones((height, width))
+        # (the reference builds np.ones((height, width)) for a missing mask, :261-262; an all-ones mask keeps every line, so the
+        # 2.4 MB array is simply not made)
         klines = remove_borders(klines, self.config["remove_borders"], height, width, valid_mask)
         klines = filter_by_length(klines, self.config["min_length"], self.config["max_keylines"])
         K = len(klines["klines"])
@@ -183,7 +200,8 @@ class LineTransformer(nn.Module):
         dd = pred_superpoint.get("dense_descriptor_nhwc")
         if dd is None:
             dd = pred_superpoint["dense_descriptor"]
-        return tokenize_into(klines, self.engine(dd.device), self.config["token_distance"], self.config["max_tokens"],
+        # the tokeniser needs no weights: the weight-less engine of line_process serves it (no weight-version check on this call)
+        return tokenize_into(klines, _token_engine(dd.device), self.config["token_distance"], self.config["max_tokens"],
                              pred_superpoint)
 
     def forward(self, data):

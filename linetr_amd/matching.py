@@ -192,7 +192,9 @@ class Matching(torch.nn.Module):
         K1, N1 = int(mat1.shape[1]), int(mat1.shape[2])
         if K0 == 0 or K1 == 0:
             return np.zeros((1, K0, K1)), np.zeros((1, K0, K1), dtype=np.float32)
-        eng = self.linetransformer.engine(line_desc0.device if line_desc0.is_cuda else None)
+        # the matcher needs no weights: the weight-less engine serves it (no weight-version check on this call)
+        from .line_process import _token_engine
+        eng = _token_engine(line_desc0.device if line_desc0.is_cuda else self.linetransformer._device())
         dev = eng.device
         d0 = line_desc0[0].to(dev).t()      # [N,256] rows: line_desc is a transposed view of exactly that, so no copy
         d1 = line_desc1[0].to(dev).t()

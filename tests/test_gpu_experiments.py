@@ -160,3 +160,44 @@ def test_alternative_signature_paths_equal_the_shipped_one(eng, monkeypatch, pat
     assert alt.shape == plain.shape and alt.shape[0] == 128 * 199
     assert (alt - plain).abs().max().item() <= 2e-6
     assert ((alt.norm(dim=1) - 1).abs() < 1e-5).all()
+
+
+def test_persistent_pair_network_equals_the_launch_chain(eng, monkeypatch):
+    """lt_pairnet.h: the signature network of a few small images as ONE persistent launch (arrival counters, write-through
+    hand-offs) against the ~30-launch chain it replaces (LINETR_NO_PAIRNET=1 in the experiments build).  Same tile arithmetic
+    (the q/k/v GEMM splits K over 8 waves instead of 4: summation order only), so the descriptors agree to fp32 round-off;
+    and the persistent launch is deterministic: repeated runs are bit-identical (a missed hand-off would show as a flicker)."""
+    hw = (480, 640)
+    cases = {"pair": [200, 200], "ragged8": [2, 3, 32, 33, 34, 98, 200, 257], "one_line": [2], "two_tiles": [40]}
+    for name, counts in cases.items():
+        lines = [synth.synth_lines(8100 + i, n, *hw) for i, n in enumerate(counts)]
+        maps = [synth.synth_dense_maps(8100 + i, *hw) for i in range(len(counts))]
+        dd = torch.cat([m[0] for m in maps]).cuda()
+        ds = torch.cat([m[1] for m in maps]).cuda()
+        off = np.concatenate([[0], np.cumsum([len(l) for l in lines])]).astype(np.int32)
+        cat = np.concatenate(lines)
+        monkeypatch.setenv("LINETR_NO_PAIRNET", "1")
+        tb0, chain = describe(eng, cat, off, dd, ds)
+        chain = chain.clone()
+        monkeypatch.delenv("LINETR_NO_PAIRNET", raising=False)
+        eng.set_profiling(True)
+        tb1, pn = describe(eng, cat, off, dd, ds)
+        prof = {e["name"]: e["calls"] for e in eng.get_profile()}
+        eng.set_profiling(False)
+        assert prof.get("pair_net_bf16x6") == 1, (name, prof)
+        assert not any(k.startswith("sig_attn") for k in prof), prof
+        assert tb1.N == tb0.N == chain.shape[0] and torch.isfinite(pn).all()
+        assert (pn - chain).abs().max().item() <= 2e-6, (name, (pn - chain).abs().max().item())
+        first = pn.clone()
+        for _ in range(25):
+            _, again = describe(eng, cat, off, dd, ds)
+            assert torch.equal(again, first), name
+
+
+def test_persistent_pair_network_is_not_taken_for_large_batches(eng):
+    _, cat, off, dd, ds = batch_inputs(16)            # 16 x 199 rows > PN_MAX_ROWS and > 8 images
+    eng.set_profiling(True)
+    describe(eng, cat, off, dd, ds)
+    prof = {e["name"] for e in eng.get_profile()}
+    eng.set_profiling(False)
+    assert "pair_net_bf16x6" not in prof

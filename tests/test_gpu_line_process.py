@@ -29,8 +29,8 @@ def test_preprocess_and_line_tokenizer_as_the_dataset_builder_imports_them():
             want, have = g[f"{t}_{k}"], out[k].cpu().numpy()
             assert have.shape == want.shape and have.dtype == np.float32, k
             assert np.abs(have - want).max() <= (1.2e-7 if "angle" in k else 0), k
-        flat = out["desc_sublines"].cpu().numpy().reshape(-1)
-        assert np.abs(flat[g[f"{t}_desc_sample_idx"]] - g[f"{t}_desc_sample"]).max() <= 1e-6
+        idx = g[f"{t}_desc_sample_idx"]                                                   # [64,2] (sub-line, token) of the frozen samples
+        assert np.abs(out["desc_sublines"][0].cpu().numpy()[idx[:, 0], idx[:, 1]] - g[f"{t}_desc_sample"]).max() <= 1e-6
         # line_tokenizer on its own, the way conv_fixed_size calls it (dataloaders/utils/util_lines.py:713): float64 arrays in
         from models.line_process import change_cv2_T_np, filter_by_length, remove_borders
         lines = filter_by_length(remove_borders(change_cv2_T_np(kl), 8, 480, 640, None), 16, -1)
