@@ -321,6 +321,10 @@ int linetr_debug_from_st(LinetrHandle* h, const void* d_st, int32_t rows, int32_
 int linetr_debug_gemm_st(LinetrHandle* h, const void* d_A1, int32_t K1, const void* d_A2, int32_t K2, const void* d_W,
                          const float* d_bias, const void* d_R, void* d_Yst, float* d_Y, int32_t ldy, int32_t M, int32_t N,
                          int32_t act, void* stream);
+/* Diagnostics of the single-pair persistent signature network (csrc/lt_pairnet.h): the next launches write wall-clock stamps
+ * (100 MHz ticks) per block and stage into d_buf [blocks][4 n_sig_layers + 1][8] = {first unit picked up, its producers seen,
+ * last body done, last unit published, four probes inside the unit}; the caller zeroes the buffer.  NULL switches the stamps off.  tools/pairnet_timeline.py */
+int linetr_debug_pairnet_stamps(LinetrHandle* h, unsigned long long* d_buf);
 #endif  /* LINETR_EXPERIMENTS */
 
 /* ---- multi-GPU: the descriptor all-gather as a C entry point --------------------------------------

@@ -103,6 +103,7 @@ def lib(path=None):
         L.linetr_debug_to_st.argtypes = [vp, vp, i32, i32, i32, vp, vp]
         L.linetr_debug_from_st.argtypes = [vp, vp, i32, i32, vp, i32, vp]
         L.linetr_debug_gemm_st.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        L.linetr_debug_pairnet_stamps.argtypes = [vp, vp]
     L.linetr_allgather_desc.argtypes = [vp, vp, vp, i64, vp]
     L.linetr_set_allgather_fn.argtypes = [vp]
     L.linetr_pack_slab.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, i32, vp, vp]
@@ -127,7 +128,7 @@ EXPORTS = ["linetr_abi_version", "linetr_last_error", "linetr_create", "linetr_d
            "linetr_sample_descriptors", "linetr_pool_distmat_workspace_bytes", "linetr_pool_distmat", "linetr_set_profiling", "linetr_get_profile"]
 
 
-EXPERIMENT_EXPORTS = ["linetr_st_bytes", "linetr_debug_to_st", "linetr_debug_from_st", "linetr_debug_gemm_st"]
+EXPERIMENT_EXPORTS = ["linetr_st_bytes", "linetr_debug_to_st", "linetr_debug_from_st", "linetr_debug_gemm_st", "linetr_debug_pairnet_stamps"]
 
 
 class NativeError(RuntimeError):

@@ -423,7 +423,9 @@ FwdWs fwd_layout(const LinetrHandle* h, int N, int64_t rows, int n_images, char*
 #endif
   w.cu = (int*)take(n_images + 1);
   w.pn = base + off;
+#ifdef LINETR_EXPERIMENTS
   off += pairnet_ws_bytes(h, N);                   // 0 for batches the path does not take (too many rows)
+#endif
   w.total = off;
   return w;
 }
@@ -532,10 +534,12 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   const float cx = c.norm_width / 2.f, cy = c.norm_height / 2.f;           // line_transformer.py:30-32
   const float scale = (float)std::max(c.norm_width, c.norm_height) * 0.7f;
   int e;
-  // a single pair (a few small images): the whole signature network below is ONE persistent launch (lt_pairnet.h); its arrival
-  // counters are zeroed here, far ahead of it on the stream
+  // experiment (LINETR_PAIRNET=1; measured and not shipped): the whole signature network of a single pair as ONE
+  // persistent launch (lt_pairnet.h); its arrival counters are zeroed here, far ahead of it on the stream
+#ifdef LINETR_EXPERIMENTS
   const bool pairnet = !ts.use_side && pairnet_fits(h, n_images, N, h_cu);
   if (pairnet && (e = pairnet_prepare(h, st, N, w.pn))) return e;
+#endif
   // ---- word positional encoder up to the last ReLU (a4); its final linear layer is applied after pooling
   const bool fused_mlp = fused_mlp_enabled(c);
   // layers 1-4 in one kernel (lt_tokmlp.h): large batches in the default precision, the reference's channel widths
@@ -696,7 +700,9 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   }
   }
   // ---- line signature network
+#ifdef LINETR_EXPERIMENTS
   if (pairnet && !chain) return pairnet_run(h, st, w.zA, d_line_desc, h_cu, n_images, N, w.pn);
+#endif
   // LINETR_SIG_PATH=st (experiment): activations stay in HBM as split-tile images and every K step travels by LDS-DMA
   // (lt_gemm_st.h, lt_attn_st.h).  Measured at cfg3 on one box: the ST GEMMs are 5-7 % faster than the register-staged
   // ones in isolation, but inside the step the 6-byte activations cost more at the kernel boundaries (the L2 write-back of

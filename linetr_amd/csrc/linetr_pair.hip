@@ -1,4 +1,7 @@
-// liblinetr_hip.so, translation unit 4 of 4: host side of the single-pair persistent signature network (lt_pairnet.h).
+// Experiments build only (liblinetr_hip_experiments.so): host side of the single-pair persistent signature network (lt_pairnet.h).
+// Measured on MI355X against the launch chain it would replace and NOT shipped: 279-340 us against ~225 us for the
+// signature network of one cfg2 pair.  LINETR_PAIRNET=1 takes the path; tools/pairnet_timeline.py prints its stage timeline.
+#ifdef LINETR_EXPERIMENTS
 #include <algorithm>
 
 #include "lt_handle.h"
@@ -23,7 +26,8 @@ int n_cus(LinetrHandle* h) {
 
 // a batch the persistent network takes: default precision, a few small images, the reference's layer shapes
 bool lt::pairnet_fits(LinetrHandle* h, int n_images, int N, const int32_t* h_cu) {
-  if (h->pn_disabled || h->precision != LINETR_PREC_BF16X6 || LT_XENV("LINETR_NO_PAIRNET")) return false;
+  const char* on = LT_XENV("LINETR_PAIRNET");            // opt-in (read per call: the tests switch it)
+  if (!on || on[0] != '1' || h->pn_disabled || h->precision != LINETR_PREC_BF16X6) return false;
   const int L = (int)h->sig.size();
   if (L < 1 || L > PN_MAX_LAYERS || n_images < 1 || n_images > PN_MAX_IMAGES || N < 1 || N > PN_MAX_ROWS) return false;
   if (h_cu) {
@@ -37,7 +41,7 @@ bool lt::pairnet_fits(LinetrHandle* h, int n_images, int N, const int32_t* h_cu)
 int64_t lt::pairnet_ws_bytes(const LinetrHandle* h, int N) {
   const int L = (int)h->sig.size();
   if (L < 1 || L > PN_MAX_LAYERS || N > PN_MAX_ROWS) return 0;
-  return align_up(pn_ws_floats(std::max(N, 1), L) * 4, 256) + align_up((int64_t)pn_stages(L) * PN_MAX_RT * 4, 256);
+  return align_up(pn_ws_floats(std::max(N, 1), L) * 4, 256) + align_up(pn_cnt_bytes(L), 256);
 }
 
 // the counters live behind the activations; they are zeroed on the stream at the START of forward_core, long before the launch
@@ -59,7 +63,7 @@ int lt::pairnet_prepare(LinetrHandle* h, hipStream_t st, int N, void* ws) {
                               "another long-running kernel?); its descriptors were incomplete.  The path is retired for this handle");
   }
   char* cnt = (char*)ws + align_up(pn_ws_floats(std::max(N, 1), L) * 4, 256);
-  LT_HIP(hipMemsetAsync(cnt, 0, (size_t)pn_stages(L) * PN_MAX_RT * 4, st));
+  LT_HIP(hipMemsetAsync(cnt, 0, (size_t)pn_cnt_bytes(L), st));
   return LINETR_OK;
 }
 
@@ -95,11 +99,21 @@ int lt::pairnet_run(LinetrHandle* h, hipStream_t st, const float* z0, float* out
   a.ws = (float*)ws;
   a.cnt = (int*)((char*)ws + align_up(pn_ws_floats(std::max(N, 1), L) * 4, 256));
   a.abort_word = h->pn_abort_dev;
+  a.stamps = h->pn_stamps;
   // one block per CU and never more: every block must be resident for the arrival counters to be reached
-  const int most_units = rt * 24;
+  const int most_units = rt * 24;        // the widest stage (q/k/v: 24 column tiles per row tile)
   const int grid = std::max(1, std::min(n_cus(h), most_units));
   ProfScope ps(h, st, "pair_net_bf16x6", flops, (double)N * D * 8);
   hipLaunchKernelGGL(pair_net_kernel, dim3(grid), dim3(PN_THREADS), 0, st, a);
   LT_LAUNCH_CHECK();
   return LINETR_OK;
 }
+
+// diagnostics: per-block, per-stage wall-clock stamps of the next pair-network launches are written to d_buf
+// ([blocks][stages][8] uint64, zeroed by the caller; lt_pairnet.h), NULL switches them off again.  tools/pairnet_timeline.py
+extern "C" int linetr_debug_pairnet_stamps(LinetrHandle* h, unsigned long long* d_buf) {
+  if (!h) return fail(LINETR_E_ARG, "null handle");
+  h->pn_stamps = d_buf;
+  return LINETR_OK;
+}
+#endif  // LINETR_EXPERIMENTS

@@ -3,7 +3,7 @@
 //   linetr_core.hip   lifetime (float64 weight preparation), host pre-filter, collective, profiling entry points
 //   linetr_net.hip    tokenise / forward / describe + the GEMM dispatcher and every model kernel
 //   linetr_match.hip  matcher, dense-map producer, slab packing
-//   linetr_pair.hip   the single-pair (latency) descriptor network
+//   linetr_pair.hip   (experiments build only) the single-pair persistent signature network
 #pragma once
 #include <map>
 #include <memory>
@@ -58,6 +58,7 @@ struct LinetrHandle {
   unsigned* pn_abort = nullptr;       // host-mapped word a timed-out launch raises (read by the host before the next launch)
   unsigned* pn_abort_dev = nullptr;   // the same word as the device sees it
   bool pn_disabled = false;
+  unsigned long long* pn_stamps = nullptr;   // diagnostics buffer (experiments build: linetr_debug_pairnet_stamps)
   int n_cu = 0;
   // profiling
   bool profiling = false;
@@ -116,7 +117,7 @@ struct ProfScope {
 struct GemmWSpec { const float* W; int64_t rows; int K; bool st; };
 int make_split_copies(LinetrHandle* H, const std::vector<GemmWSpec>& weights);
 
-// The line-signature network of a single pair (a few small images) as ONE persistent launch (lt_pairnet.h):
+// Experiments build: the line-signature network of a single pair (a few small images) as ONE persistent launch (lt_pairnet.h):
 //   pairnet_fits      does this batch take the path (precision, image count, row count)?  h_cu may be NULL (size check only)
 //   pairnet_ws_bytes  bytes of workspace it needs for N rows (0 when N is out of range)
 //   pairnet_prepare   zeroes the arrival counters on the stream (call it EARLY, well ahead of the launch)

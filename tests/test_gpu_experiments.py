@@ -164,8 +164,8 @@ def test_alternative_signature_paths_equal_the_shipped_one(eng, monkeypatch, pat
 
 def test_persistent_pair_network_equals_the_launch_chain(eng, monkeypatch):
     """lt_pairnet.h: the signature network of a few small images as ONE persistent launch (arrival counters, write-through
-    hand-offs) against the ~30-launch chain it replaces (LINETR_NO_PAIRNET=1 in the experiments build).  Same tile arithmetic
-    (the q/k/v GEMM splits K over 8 waves instead of 4: summation order only), so the descriptors agree to fp32 round-off;
+    hand-offs; LINETR_PAIRNET=1, experiments build: measured and not shipped) against the ~30-launch chain.  Same tile arithmetic
+    (K split over 8 waves in every GEMM, the attention's keys over 8 waves: summation order only), so the descriptors agree to fp32 round-off;
     and the persistent launch is deterministic: repeated runs are bit-identical (a missed hand-off would show as a flicker)."""
     hw = (480, 640)
     cases = {"pair": [200, 200], "ragged8": [2, 3, 32, 33, 34, 98, 200, 257], "one_line": [2], "two_tiles": [40]}
@@ -176,10 +176,10 @@ def test_persistent_pair_network_equals_the_launch_chain(eng, monkeypatch):
         ds = torch.cat([m[1] for m in maps]).cuda()
         off = np.concatenate([[0], np.cumsum([len(l) for l in lines])]).astype(np.int32)
         cat = np.concatenate(lines)
-        monkeypatch.setenv("LINETR_NO_PAIRNET", "1")
+        monkeypatch.delenv("LINETR_PAIRNET", raising=False)
         tb0, chain = describe(eng, cat, off, dd, ds)
         chain = chain.clone()
-        monkeypatch.delenv("LINETR_NO_PAIRNET", raising=False)
+        monkeypatch.setenv("LINETR_PAIRNET", "1")
         eng.set_profiling(True)
         tb1, pn = describe(eng, cat, off, dd, ds)
         prof = {e["name"]: e["calls"] for e in eng.get_profile()}
@@ -194,7 +194,8 @@ def test_persistent_pair_network_equals_the_launch_chain(eng, monkeypatch):
             assert torch.equal(again, first), name
 
 
-def test_persistent_pair_network_is_not_taken_for_large_batches(eng):
+def test_persistent_pair_network_is_not_taken_for_large_batches(eng, monkeypatch):
+    monkeypatch.setenv("LINETR_PAIRNET", "1")
     _, cat, off, dd, ds = batch_inputs(16)            # 16 x 199 rows > PN_MAX_ROWS and > 8 images
     eng.set_profiling(True)
     describe(eng, cat, off, dd, ds)
