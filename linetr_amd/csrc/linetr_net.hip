@@ -757,6 +757,8 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
         // few (image, head) pairs: 32-query blocks whose 4 waves also split the KV range (a single pair spreads over 56 CUs
         // and the critical path is 2 KV chunks instead of 7)
         if (!attn4 && !no_small_attn && (int64_t)n_images * HEADS * cdiv(max_n, 256) < 64)
+          // (r04: an eight-wave form -- one key chunk per wave, K fragments straight from global memory -- measured level with this
+          // one, 12.6 us per launch for a cfg2 pair either way, and was not kept)
           hipLaunchKernelGGL(sig_attn_small_kernel, dim3(n_images, HEADS, cdiv(max_n, 32)), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
         else if (attn4 || max_n <= 128)
           hipLaunchKernelGGL(sig_attn_split_kernel<4>, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);

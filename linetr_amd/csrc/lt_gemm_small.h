@@ -69,6 +69,14 @@ __global__ __launch_bounds__(NWV * 64) void gemm_split_small_kernel(SplitGemmArg
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+  // the epilogue's bias and residual values are fetched NOW: a cold load behind the reduction sits on the critical path of a
+  // kernel that lives for ~5 us (measured inside the persistent-network experiment, DESIGN.md 12: ~1 us per GEMM)
+  const int e_row = tid >> 3, e_c4 = (tid & 7) * 4;
+  const bool e_on = tid < 256 && m0 + e_row < g.M;
+  f32x4 e_bias = f32x4{0.f, 0.f, 0.f, 0.f}, e_res = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (e_on && g.bias) e_bias = *reinterpret_cast<const f32x4*>(g.bias + grp * g.gBias + n0 + e_c4);
+  if (e_on && g.R) e_res = *reinterpret_cast<const f32x4*>(g.R + (int64_t)(m0 + e_row) * g.ldr + n0 + e_c4);
+
   constexpr int GRP = 4;                           // K tiles in flight per wave (registers)
   for (int kt = kt0; kt < kt1; kt += GRP) {
     f32x4 ra[GRP][4], rw[GRP][W_LD];
@@ -135,29 +143,22 @@ __global__ __launch_bounds__(NWV * 64) void gemm_split_small_kernel(SplitGemmArg
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + frow] = acc[r];
   __syncthreads();
-  const int row = tid >> 3, c4 = (tid & 7) * 4;
-  if (tid < 256 && m0 + row < g.M) {
-    const float* bias = g.bias ? g.bias + grp * g.gBias : nullptr;
+  if (e_on) {
     float* Y = g.Y + grp * g.gY;
     f32x4 v;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int o = row * 33 + c4 + c;
+      const int o = e_row * 33 + e_c4 + c;
       float acc4 = red[0][o];
 #pragma unroll
       for (int w = 1; w < NWV; ++w) acc4 += red[w][o];            // fixed order
-      v[c] = acc4;
-      if (bias) v[c] += bias[n0 + c4 + c];
+      v[c] = acc4 + e_bias[c];
       if (g.act == ACT_RELU) v[c] = fmaxf(v[c], 0.f);
       else if (g.act == ACT_GELU) v[c] = 0.5f * v[c] * (1.f + erff(v[c] * 0.70710678118654752440f));
       else if (g.act == ACT_DIST) v[c] = fmaxf(2.f - 2.f * v[c], 0.f);
+      v[c] += e_res[c];
     }
-    if (g.R) {
-      const f32x4 rr = *reinterpret_cast<const f32x4*>(g.R + (int64_t)(m0 + row) * g.ldr + n0 + c4);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] += rr[c];
-    }
-    *reinterpret_cast<f32x4*>(Y + (int64_t)(m0 + row) * g.ldy + n0 + c4) = v;
+    *reinterpret_cast<f32x4*>(Y + (int64_t)(m0 + e_row) * g.ldy + n0 + e_c4) = v;
   }
 }
 

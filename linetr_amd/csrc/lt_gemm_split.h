@@ -764,7 +764,10 @@ inline const char* split_tile_name(const GemmArgs& g, int groups, int pl = 3) {
   // 0.75 ms (0.85 ms with the earlier four-wave layout at 212 VGPRs = 2 waves per SIMD).  For the other shapes the two
   // tiles are level inside the step.
   static const bool no128s = LT_XENV("LINETR_NO_TILE128S") != nullptr;   // tuning aid
-  if (!no128s && pl == 3 && r128 * (g.N / 128) * groups >= 1024 && ((g.K <= 256 && g.N >= 768) || g.K <= 128)) return "128x128s";
+  // r04 (profiles/r04_tiles_probe.txt): with K <= 256 and N >= 768 it already wins from ~400 tiles (9584 rows, cfg5 at 8 pairs:
+  // 9584x1024x256 45.6 vs 55.4 us, 9584x768x256 30.0 vs 31.8 us)
+  const int64_t t128 = r128 * (g.N / 128) * groups;
+  if (!no128s && pl == 3 && ((g.K <= 256 && g.N >= 768 && t128 >= 400) || (g.K <= 128 && t128 >= 1024))) return "128x128s";
   if (g.N % 256 == 0 && r128 * (g.N / 256) * groups >= 140) return "128x256";
   if (g.N % 256 != 0 && (int64_t)cdiv(g.M, 256) * (g.N / 128) * groups >= 192) return "256x128";
   if (r64 * (g.N / 64) * groups <= 768) return "64x64";

@@ -5,6 +5,7 @@ of the hot path is a HIP kernel behind the C ABI (include/linetr_hip.h).
 from __future__ import annotations
 
 import ctypes as C
+import math
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -245,11 +246,11 @@ class Engine:
                   ("mask", (N, T + 1)), ("resp", (N,)), ("angle_sub", (N, 2)), ("score", (N, T)), ("sub2line", (N,))]
         if want_mat:
             shapes.append(("mat", (K, N)))                  # written by extra blocks of the tokeniser's own launch
-        sizes = [(int(np.prod(sh)) + 3) // 4 * 4 for _, sh in shapes]
+        sizes = [(math.prod(sh) + 3) // 4 * 4 for _, sh in shapes]
         pool = torch.empty((sum(sizes),), **f)
         views, o = {}, 0
         for (name, sh), sz in zip(shapes, sizes):
-            views[name] = pool[o:o + int(np.prod(sh))].view(sh)
+            views[name] = pool[o:o + math.prod(sh)].view(sh)
             o += sz
         views["sub2line"] = views["sub2line"].view(torch.int32)
         tb = TokenBatch(n_images=B, max_tokens=T, cu_k=np.asarray(cu_k, np.int32), cu_n=np.asarray(cu_n, np.int32), recs=recs,

@@ -14,8 +14,8 @@ SHAPES = [(9584, 256, 256), (9584, 256, 512), (9584, 512, 512), (9584, 768, 256)
 if len(sys.argv) > 2 and sys.argv[1] == "--child":
     import torch
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-# tuning switches and the non-shipped kernels live in the experiments build of the library
-os.environ.setdefault("LINETR_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "linetr_amd", "csrc", "liblinetr_hip_experiments.so"))
+    # tuning switches and the non-shipped kernels live in the experiments build of the library
+    os.environ.setdefault("LINETR_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "linetr_amd", "csrc", "liblinetr_hip_experiments.so"))
     from workloads import synth
     from linetr_amd.engine import Engine
     eng = Engine(synth.make_state_dict(0), "cuda:0")
@@ -43,6 +43,8 @@ os.environ.setdefault("LINETR_LIB", os.path.join(os.path.dirname(os.path.abspath
             print(f"{M:6d} {N:5d} {K:5d}  {os.environ.get('LINETR_GEMM_TILE', 'auto'):8s} failed: {str(e)[:60]}", flush=True)
 else:
     mode = sys.argv[1] if len(sys.argv) > 1 else "bf16x6"
+    if len(sys.argv) > 2:
+        TILES = sys.argv[2].split(",")
     for tile in ["auto"] + TILES:
         env = dict(os.environ)
         if tile != "auto":
