@@ -218,6 +218,32 @@ class LineTransformer(nn.Module):
         data.update({"line_desc": out.view(B, N, 256).transpose(1, 2)})
         return data
 
+    def forward_many(self, datas):
+        """forward() for several pre-processed images in ONE native call (a var-len batch: the descriptor network of an image never
+        looks at another image, so every dict receives exactly the 'line_desc' forward() would give it, up to fp32 round-off --
+        tests/test_gpu_properties.py).  Halves the launches of a pair; Matching.forward uses it for its two images.  Dicts
+        without lines get default_ret(), like forward()."""
+        live = [d for d in datas if len(d["klines"]) != 0]
+        outs = {id(d): self.default_ret() for d in datas if len(d["klines"]) == 0}
+        if len(live) == 1:
+            outs[id(live[0])] = self.forward(live[0])
+        elif live:
+            T = int(live[0]["pnt_sublines"].shape[2])
+            if any(int(d["sublines"].shape[0]) != 1 or int(d["pnt_sublines"].shape[2]) != T for d in live):
+                for d in live:                       # batched / differently tokenised inputs: one call each
+                    outs[id(d)] = self.forward(d)
+            else:
+                n = [int(d["sublines"].shape[1]) for d in live]
+                cu = np.concatenate([[0], np.cumsum(n)]).astype(np.int32)
+                cat = lambda k, *tail: torch.cat([d[k].reshape(m, *tail) for d, m in zip(live, n)])
+                eng = self.engine(live[0]["sublines"].device if live[0]["sublines"].is_cuda else None)
+                ld = eng.forward_tensors(cat("sublines", 2, 2), cat("pnt_sublines", T, 2), cat("resp_sublines"),
+                                         cat("angle_sublines", 2), cat("desc_sublines", T, 256), cat("score_sublines", T), cu)
+                for i, d in enumerate(live):
+                    d.update({"line_desc": ld[cu[i]:cu[i + 1]].t()[None]})
+                    outs[id(d)] = d
+        return [outs[id(d)] for d in datas]
+
     def subline2keyline(self, distance_sublines, mat_klines2sublines0, mat_klines2sublines1):
         """Mean sub-line distance per key-line pair: (A0 @ D @ A1^T)[None], NumPy in / NumPy out
         (models/line_transformer.py:277-282).  Matrices that come from this package's tokeniser carry their sub-line ->

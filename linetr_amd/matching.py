@@ -50,14 +50,14 @@ class Matching(torch.nn.Module):
         self.lsd = lsd if lsd is not None else _frontend("line_detector", "LSD", config.get("lsd", {}))
         self.linetransformer = LineTransformer(config.get("linetransformer", {}))
 
-    def _describe_lines(self, image, pred_sp, valid_mask):
+    def _tokenize_lines(self, image, pred_sp, valid_mask):
         lt = self.linetransformer
         shape = image.shape
         if self.auto_min_length:                                  # matching.py:30-32
             lt.config["min_length"] = max(16, max(shape) / 40)
             lt.config["token_distance"] = max(8, max(shape) / 80)
         klines_cv = self.lsd.detect_torch(image)
-        return lt(lt.preprocess(klines_cv, shape, pred_sp, valid_mask))
+        return lt.preprocess(klines_cv, shape, pred_sp, valid_mask)
 
     def forward(self, data):
         pred = {}
@@ -66,13 +66,17 @@ class Matching(torch.nn.Module):
             if "keypoints" + s not in data:
                 sp[s] = self.superpoint({"image": data["image" + s]})
                 pred.update({k + s: v for k, v in sp[s].items()})
+        # detect + tokenise each image (matching.py:34-41, :52-59), then describe the images that need it in ONE native call
+        sides, pres = [], []
         for s in ("0", "1"):
             if "klines" + s not in data:
                 img = data["image" + s]
                 if "valid_mask" + s not in data:
                     data["valid_mask" + s] = torch.ones_like(img)   # a tensor: ignored downstream (matching.py:37-40)
-                out = self._describe_lines(img, sp[s], data["valid_mask" + s])
-                pred.update({k + s: v for k, v in out.items()})
+                sides.append(s)
+                pres.append(self._tokenize_lines(img, sp[s], data["valid_mask" + s]))
+        for s, out in zip(sides, self.linetransformer.forward_many(pres)):
+            pred.update({k + s: v for k, v in out.items()})
         data = {**data, **pred}
         for k in data:
             if isinstance(data[k], (list, tuple)):

@@ -188,3 +188,42 @@ def test_matcher_beyond_the_lds_segment_table():
     assert np.array_equal(mat, O.mutual_nn(dist, 0.8, True))      # same argmin rules on the SAME float32 distances
     assert mat[0][5:16, 11990:12001].trace() == 11
     assert np.array_equal(NM.nn_matcher_distmat(dist, 0.8, True), O.mutual_nn(dist, 0.8, True))
+
+
+def test_matcher_segment_table_in_workspace_with_several_pairs_and_pooling(eng):
+    """Three pairs in ONE linetr_match call whose side-1 images have more key-lines than the LDS segment table holds (one pair below
+    the limit rides along): the table of every pair is built once by pair_seg1_kernel in that pair's own scratch region and only
+    read by the pooling blocks.  Sub-lines are pooled in runs of 1-3 on both sides; against the oracle's matcher, pair by pair."""
+    from oracle import linetr_oracle as O
+    rs = np.random.RandomState(5)
+    dims, d0s, d1s, s0s, s1s = [], [], [], [], []
+    for n0, k1 in ((40, 12003), (25, 300), (33, 12500)):
+        runs1 = rs.randint(1, 3, k1)                              # 1-2 sub-lines per key-line on side 1
+        n1 = int(runs1.sum())
+        runs0 = rs.randint(1, 4, n0 // 2)
+        k0, n0 = len(runs0), int(runs0.sum())
+        d0 = rs.standard_normal((n0, 256)).astype(np.float32)
+        d1 = rs.standard_normal((n1, 256)).astype(np.float32)
+        d0 /= np.linalg.norm(d0, axis=1, keepdims=True)
+        d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
+        dims.append((n0, k0, n1, k1))
+        d0s.append(d0); d1s.append(d1)
+        s0s.append(np.repeat(np.arange(k0), runs0).astype(np.int32)); s1s.append(np.repeat(np.arange(k1), runs1).astype(np.int32))
+    cu = lambda v: np.concatenate([[0], np.cumsum(v)]).astype(np.int64)
+    n0s, k0s, n1s, k1s = (np.array([d[i] for d in dims]) for i in range(4))
+    dk, off_dk, m01 = eng.match(torch.from_numpy(np.concatenate(d0s)).cuda(), cu(n0s), torch.from_numpy(np.concatenate(s0s)).cuda(), cu(k0s),
+                                torch.from_numpy(np.concatenate(d1s)).cuda(), cu(n1s), torch.from_numpy(np.concatenate(s1s)).cuda(), cu(k1s), 0.8, True)
+    torch.cuda.synchronize()
+    dk, m01, ck0 = dk.cpu().numpy(), m01.cpu().numpy(), cu(k0s)
+
+    for p, (n0, k0, n1, k1) in enumerate(dims):
+        D = np.clip(2.0 - 2.0 * (d0s[p].astype(np.float64) @ d1s[p].astype(np.float64).T), 0, None)     # models/line_process.py:198-201
+        st0, st1 = np.flatnonzero(np.r_[1, np.diff(s0s[p])]), np.flatnonzero(np.r_[1, np.diff(s1s[p])])
+        Dk = np.add.reduceat(np.add.reduceat(D, st0, axis=0), st1, axis=1) / np.bincount(s0s[p])[:, None] / np.bincount(s1s[p])[None]
+        got_dk = dk[off_dk[p]:off_dk[p + 1]].reshape(k0, k1)
+        assert np.abs(got_dk - Dk).max() < 1e-5                  # subline2keyline with 1 / num_sublines rows (models/line_transformer.py:277-282)
+        want = O.mutual_nn(got_dk[None], 0.8, True)[0]           # same argmin rules on the SAME float32 distances
+        got = np.zeros_like(want)
+        mm = m01[ck0[p]:ck0[p + 1]]
+        got[np.nonzero(mm >= 0)[0], mm[mm >= 0]] = 1
+        assert np.array_equal(got, want), p
