@@ -769,6 +769,9 @@ inline const char* split_tile_name(const GemmArgs& g, int groups, int pl = 3) {
   const int64_t t128 = r128 * (g.N / 128) * groups;
   if (!no128s && pl == 3 && ((g.K <= 256 && g.N >= 768 && t128 >= 400) || (g.K <= 128 && t128 >= 1024))) return "128x128s";
   if (g.N % 256 == 0 && r128 * (g.N / 256) * groups >= 140) return "128x256";
+  // r04 probe, 9584 rows x N = 256 (75 row tiles: too few 128 x 256 blocks): two 128 x 128 s blocks per CU beat the 64 x 64 tile for
+  // K <= 512 (27.7 vs 29.5 us at K = 512, 17.0 vs 18.0 at K = 256); at K = 1024 the tiles are level
+  if (!no128s && pl == 3 && g.K <= 512 && t128 >= 140) return "128x128s";
   if (g.N % 256 != 0 && (int64_t)cdiv(g.M, 256) * (g.N / 128) * groups >= 192) return "256x128";
   if (r64 * (g.N / 64) * groups <= 768) return "64x64";
   if (r64 * (g.N / 128) * groups <= 512) return "64x128";
