@@ -44,7 +44,7 @@ from linetr_amd.engine import Engine  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA
 HBM_PEAK_GBS = 8000.0
-PROFILE_TAG = "r03"             # profiles/<tag>_<workload>_pmc_traffic.json, profiles/<tag>_<workload>_gemm_pmc.json
+PROFILE_TAG = "r04"             # profiles/<tag>_<workload>_pmc_traffic.json, profiles/<tag>_<workload>_gemm_pmc.json
 
 WORKLOADS = {
     # name: (H, W, lines/image, len_lo, len_hi, max_tokens, default pairs per GPU)
@@ -323,6 +323,9 @@ PMC_KERNEL_NAMES = {   # profile class -> kernel symbol prefix in profiles/<tag>
     "sig_qkv_attn_bf16x6": "void lt::sig_qkv_attn_kernel<0>",
     "cls_pool_online": "void lt::cls_pool_online_kernel<1>",
     "gemm_bf16x6_128x64": "void lt::gemm_split_kernel<128, 64, 4, 1, 3, true, 0",
+    "nchw_to_nhwc": "lt::nchw_to_nhwc_kernel",
+    "row_norm": "lt::row_norm_kernel",
+    "sig_attn_bf16x6_small": "lt::sig_attn_small_kernel",
 }
 
 
