@@ -304,16 +304,25 @@ class Engine:
             raise ValueError(f"dense_descriptor shape {tuple(dense_desc.shape)} does not match {want} ({dense_layout})")
         dev = self.device
         f = dict(dtype=torch.float32, device=dev)
-        z = torch.empty((0,), **f)
-        tb = TokenBatch(
-            n_images=B, max_tokens=T, cu_k=np.asarray(cu_k, np.int32), cu_n=np.asarray(cu_n, np.int32), recs=recs,
-            klines=torch.empty((K, 2, 2), **f), length=torch.empty((K,), **f), angles=torch.empty((K, 2), **f),
-            sublines=torch.empty((N, 2, 2), **f), pnt=torch.empty((N, T, 2), **f) if want_tokens else z,
-            mask=torch.empty((N, T + 1), **f) if want_tokens else z, resp=torch.empty((N,), **f),
-            angle_sub=torch.empty((N, 2), **f), desc=torch.empty((N, T, D), **f) if want_tokens else z,
-            score=torch.empty((N, T), **f) if want_tokens else z,
-            sub2line=torch.empty((N,), dtype=torch.int32, device=dev))
-        ld = torch.empty((N, D), **f)
+        # the small outputs and line_desc are views of ONE allocation (every view on a 16-byte boundary): a dozen torch.empty
+        # calls are ~40 us of host time on the latency path of a single pair
+        shapes = [("ld", (N, D)), ("klines", (K, 2, 2)), ("length", (K,)), ("angles", (K, 2)), ("sublines", (N, 2, 2)),
+                  ("resp", (N,)), ("angle_sub", (N, 2)), ("sub2line", (N,))]
+        if want_tokens:
+            shapes += [("pnt", (N, T, 2)), ("mask", (N, T + 1)), ("score", (N, T))]
+        sizes = [(math.prod(sh) + 3) // 4 * 4 for _, sh in shapes]
+        pool = torch.empty((sum(sizes),), **f)
+        views, o = {}, 0
+        for (name, sh), sz in zip(shapes, sizes):
+            views[name] = pool[o:o + math.prod(sh)].view(sh)
+            o += sz
+        views["sub2line"] = views["sub2line"].view(torch.int32)
+        ld = views.pop("ld")
+        z = pool[:0]
+        for name in ("pnt", "mask", "score"):
+            views.setdefault(name, z)
+        tb = TokenBatch(n_images=B, max_tokens=T, cu_k=np.asarray(cu_k, np.int32), cu_n=np.asarray(cu_n, np.int32), recs=recs,
+                        desc=torch.empty((N, T, D), **f) if want_tokens else z, **views)
         if K == 0 or N == 0:
             return tb, ld
         n_real = int(recs["n_tok"][:K].sum())

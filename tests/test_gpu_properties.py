@@ -227,3 +227,23 @@ def test_matcher_segment_table_in_workspace_with_several_pairs_and_pooling(eng):
         mm = m01[ck0[p]:ck0[p + 1]]
         got[np.nonzero(mm >= 0)[0], mm[mm >= 0]] = 1
         assert np.array_equal(got, want), p
+
+
+def test_matcher_fuzz_ties_and_threshold_edges():
+    """nn_matcher_distmat (models/nn_matcher.py:3-31) on 300 random distance matrices drawn from a handful of values, so that ties on
+    rows AND columns, entries exactly at the threshold and all-rejected rows are the norm: first-index argmin, strict `<`, mutual
+    check -- identical by index to the oracle's NumPy restatement; mutual and one-sided."""
+    from linetr_amd import nn_matcher as NM
+    from oracle import linetr_oracle as O
+    rs = np.random.RandomState(2024)
+    vals = np.array([0.0, 0.25, 0.5, 0.79999995, 0.8, 0.80000007, 1.0, 1.5, 4.0], np.float32)
+    for case in range(300):
+        n0, n1 = rs.randint(1, 41), rs.randint(1, 41)
+        d = vals[rs.randint(0, len(vals), (1, n0, n1))]
+        if case % 7 == 0:
+            d[0, rs.randint(0, n0)] = 4.0                        # a row nothing matches
+        mutual = bool(case % 2)
+        thr = float(np.float32(0.8))
+        got = NM.nn_matcher_distmat(d, thr, mutual)
+        want = O.mutual_nn(d, thr, mutual)
+        assert got.dtype == np.float64 and np.array_equal(got, want), (case, n0, n1, mutual)
