@@ -75,8 +75,9 @@ struct PnStage {
   float* Y;
   int lda, lda2, ldy, K, K1, N, act;
   int wide;                 // a unit covers 64 output columns: waves 0-3 / 4-7 take one 32-column tile each and split K four ways
-  // dependency: counters of stage `dep` (-1: none), `target` arrivals per row tile; whole_image: every row tile of the unit's image
-  int dep, target, whole_image;
+  // dependency: counters of stage `dep` (-1: none), `target` arrivals per row tile (a GEMM / norm unit waits for its own row tile,
+  // an attention wave for the row tile that holds its 32 keys)
+  int dep, target;
   // attention / norm
   const float* qkv;
   float* msg;
@@ -101,7 +102,7 @@ __device__ __forceinline__ PnStage pn_decode(const PairNetArgs& a, int s) {
   if (s == 0) { qkv_stage(0); return st; }
   const int t = s - 1, l = t >> 2, k = t & 3;
   if (k == 0) {            // attention of layer l: needs q/k/v of the whole image
-    st.type = PN_ATTN; st.qkv = qkv_of(l); st.msg = msg_of(l); st.dep = s - 1; st.target = PN_WIDE_QKV ? 12 : 24; st.whole_image = 1;
+    st.type = PN_ATTN; st.qkv = qkv_of(l); st.msg = msg_of(l); st.dep = s - 1; st.target = PN_WIDE_QKV ? 12 : 24;
   } else if (k == 1) {     // hid = relu(W1 [z ; msg] + b1)      (merge conv folded into W1)
     st.type = PN_GEMM; st.A = z_of(l); st.lda = 256; st.K1 = 256; st.A2 = msg_of(l); st.lda2 = 256; st.K = 512; st.N = 512;
     st.W = a.layer[l].W1; st.bias = a.layer[l].b1; st.Y = hid_of(l); st.ldy = 512; st.act = ACT_RELU; st.dep = s - 1; st.target = 4;
@@ -131,6 +132,8 @@ __device__ __forceinline__ void pn_store16(__amdgpu_buffer_rsrc_t r, int byte_of
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, byte_off, 0, /*sc1*/ 16);
 }
 
+// (The diagnostics stamps inside the units add `(value == 12345.f)` of a just-computed register to the clock: always 0, but it ties
+// the clock read behind the arithmetic it is meant to time.)
 // thread 0 of the block: wait until *c >= target; false on abort / timeout.  The poll is a relaxed agent-scope load (L2-served,
 // ~0.3 us apart); the clock and the host-mapped abort word (a PCIe round trip) are only looked at every few hundred polls.
 __device__ __forceinline__ bool pn_poll(const int* c, int target, unsigned* abort_word) {
@@ -317,10 +320,9 @@ __device__ __noinline__ bool pn_gemm_unit(const PnStage& st, int row0, int nrows
 // in sig_attn_small_kernel; the eight partial (m, l, O) are merged through LDS in wave order.
 // ---------------------------------------------------------------------------------------------
 constexpr int PN_VT_BYTES = DH * PN_ATL_RV;                       // 12 800 per wave
-__device__ __noinline__ bool pn_attn_unit(const PnStage& st, int n0, int Ni, int q0, int head, const int* dep_cnt, int n_dep,
+__device__ __noinline__ bool pn_attn_unit(const PnStage& st, int n0, int Ni, int q0, int head, const int* dep_cnt,
                                              unsigned* abort_word, unsigned char* lds, int* s_ok, unsigned long long* stamp, PnTouch touch) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  (void)n_dep;
   unsigned tv[2];
   pn_touch_issue(touch, tv);
   if (tid == 0) *s_ok = 1;
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(PN_THREADS) void pair_net_kernel(const PairNetArgs 
     unsigned long long* stamp = a.stamps ? a.stamps + ((int64_t)blockIdx.x * n_stages + s) * 8 : nullptr;
     if (stamp && threadIdx.x == 0 && stamp[0] == 0) stamp[0] = wall_clock64();            // first unit of the stage picked up
     if (st.type == PN_GEMM) ok = pn_gemm_unit(st, n0 + lrow, nrows, sub * (st.wide ? 64 : 32), dep ? dep + rt * PN_CNT_STRIDE : nullptr, st.target, a.abort_word, lds, &s_ok, stamp, touch);
-    else if (st.type == PN_ATTN) ok = pn_attn_unit(st, n0, Ni, lrow, sub, dep + a.img_rt0[img] * PN_CNT_STRIDE, a.img_rt0[img + 1] - a.img_rt0[img], a.abort_word, lds, &s_ok, stamp, touch);
+    else if (st.type == PN_ATTN) ok = pn_attn_unit(st, n0, Ni, lrow, sub, dep + a.img_rt0[img] * PN_CNT_STRIDE, a.abort_word, lds, &s_ok, stamp, touch);
     else ok = pn_norm_unit(st, n0 + lrow, nrows, dep + rt * PN_CNT_STRIDE, a.abort_word, &s_ok, stamp);
     if (!ok) return;
     if (stamp && threadIdx.x == 0) stamp[2] = wall_clock64();                              // body done ([1]: dependency seen)
