@@ -149,9 +149,9 @@ extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* 
         hipLaunchKernelGGL(pair_seg1_kernel, dim3(cdiv(max_n1, 2048), P), dim3(256), 0, st, tab, d_s2l1, d_scr);
         LT_LAUNCH_CHECK();
       }
-      hipLaunchKernelGGL(pair_pool_kernel, dim3(max_chunks, P), dim3(256),
-                         (size_t)((seg1_global ? 0 : max_k1) + PM_ROWS + 2) * sizeof(int), st, tab, d_s2l0, d_s2l1, d_dist, d_dk,
-                         d_scr, seg1_global);
+      const int cache_dk = max_k1 <= PM_CACHE_K1;
+      hipLaunchKernelGGL(pair_pool_kernel, dim3(max_chunks, P), dim3(256), pair_pool_lds(max_k1, seg1_global, cache_dk), st, tab, d_s2l0,
+                         d_s2l1, d_dist, d_dk, d_scr, seg1_global, cache_dk);
       LT_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(pair_final_kernel, dim3(P), dim3(256), 0, st, tab, thr, mutual, d_match01, d_scr);
@@ -234,9 +234,10 @@ extern "C" int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_
       hipLaunchKernelGGL(pair_seg1_kernel, dim3(cdiv(n1, 2048), 1), dim3(256), 0, st, tab, (const int*)(base + o_id1), (int*)(base + o_scr));
       LT_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(pair_pool_kernel, dim3(pd->chunks, 1), dim3(256), (size_t)((seg1_global ? 0 : n1) + PM_ROWS + 2) * sizeof(int),
+    const int cache_dk = n1 <= PM_CACHE_K1;
+    hipLaunchKernelGGL(pair_pool_kernel, dim3(pd->chunks, 1), dim3(256), pair_pool_lds(n1, seg1_global, cache_dk),
                        st, tab, (const int*)(base + o_id0), (const int*)(base + o_id1), d_dist, (float*)(base + o_dk),
-                       (int*)(base + o_scr), seg1_global);
+                       (int*)(base + o_scr), seg1_global, cache_dk);
     LT_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(pair_final_kernel, dim3(1), dim3(256), 0, st, tab, thr, mutual, d_match01, (int*)(base + o_scr));
@@ -269,8 +270,9 @@ extern "C" int linetr_pool_distmat(LinetrHandle* h, const float* d_dist, int32_t
     hipLaunchKernelGGL(pair_seg1_kernel, dim3(cdiv(n1, 2048), 1), dim3(256), 0, st, tab, d_s2l1, (int*)d_ws);
     LT_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(pair_pool_kernel, dim3(pd->chunks, 1), dim3(256), (size_t)((seg1_global ? 0 : k1) + PM_ROWS + 2) * sizeof(int), st,
-                     tab, d_s2l0, d_s2l1, d_dist, d_dk, (int*)d_ws, seg1_global);
+  const int cache_dk = k1 <= PM_CACHE_K1;
+  hipLaunchKernelGGL(pair_pool_kernel, dim3(pd->chunks, 1), dim3(256), pair_pool_lds(k1, seg1_global, cache_dk), st,
+                     tab, d_s2l0, d_s2l1, d_dist, d_dk, (int*)d_ws, seg1_global, cache_dk);
   LT_LAUNCH_CHECK();
   return LINETR_OK;
 }

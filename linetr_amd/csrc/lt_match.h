@@ -30,6 +30,11 @@ struct PairTable {
 
 constexpr int PM_ROWS = 16;         // key-line rows of Dk per block of pair_pool_kernel
 constexpr int PM_MAX_K1 = 12000;    // up to here the seg1 table of a pair lives in the block's LDS (48 KB); beyond, in the workspace
+constexpr int PM_CACHE_K1 = 896;    // up to here the block's PM_ROWS pooled rows are kept in LDS as well (61 KB with the tables: under the 64 KB a launch gets without opting in)
+// dynamic LDS of pair_pool_kernel
+inline size_t pair_pool_lds(int max_k1, int seg1_global, int cache_dk) {
+  return (size_t)((seg1_global ? 0 : max_k1 + 1) + PM_ROWS + 2 + (cache_dk ? PM_ROWS * max_k1 : 0)) * sizeof(int);
+}
 
 // D[a][b] = max(2 - 2 * <d0[a], d1[b]>, 0), fp32 MFMA, 64x64 tile per block, K = 256.
 // grid (tiles_b, tiles_a, pair)
@@ -127,8 +132,8 @@ __global__ __launch_bounds__(256) void pair_seg1_kernel(const PairTable pairs, c
 
 __global__ __launch_bounds__(256) void pair_pool_kernel(const PairTable pairs, const int* __restrict__ s2l0,
                                                         const int* __restrict__ s2l1, const float* __restrict__ dist,
-                                                        float* __restrict__ dk_out, int* __restrict__ scratch, int seg1_global) {
-  extern __shared__ int pm_lds[];                    // seg1[k1+1] | seg0[PM_ROWS+1]   (seg1_global: seg0 only)
+                                                        float* __restrict__ dk_out, int* __restrict__ scratch, int seg1_global, int cache_dk) {
+  extern __shared__ int pm_lds[];                    // seg1[k1+1] | seg0[PM_ROWS+2] | (cache_dk) pooled rows [PM_ROWS][k1]   (seg1_global: no seg1)
   const PairDesc pd = pairs.get(blockIdx.y);
   const int chunk = blockIdx.x;
   if (chunk >= pd.chunks || pd.k1 <= 0) return;
@@ -158,24 +163,47 @@ __global__ __launch_bounds__(256) void pair_pool_kernel(const PairTable pairs, c
   const float* Dp = dist + pd.off_d;
   float* Dk = dk_out + pd.off_dk + (int64_t)i0 * pd.k1;
   const int total = rows * pd.k1;
-  for (int e = tid; e < total; e += 256) {
-    const int r = e / pd.k1, j = e - r * pd.k1;
-    const int a0 = seg0[r], a1 = seg0[r + 1], b0 = seg1[j], b1 = seg1[j + 1];
-    float v;
-    if (a1 - a0 == 1 && b1 - b0 == 1) {
-      v = Dp[(int64_t)a0 * pd.n1 + b0];
-    } else {  // (A0 @ D) @ A1^T with A rows = 1/num_sublines
-      const float w0 = 1.f / (float)(a1 - a0), w1 = 1.f / (float)(b1 - b0);
-      v = 0.f;
-      for (int b = b0; b < b1; ++b) {
-        float t = 0.f;
-        for (int a = a0; a < a1; ++a) t += w0 * Dp[(int64_t)a * pd.n1 + b];
-        v += t * w1;
+  // the pooled rows also stay in LDS when they fit (cache_dk: the caller sized the dynamic LDS for PM_ROWS x k1 floats): both
+  // argmin passes below then read LDS instead of the Dk rows this block has just stored
+  float* dkc = cache_dk ? reinterpret_cast<float*>(pm_lds + (seg1_global ? 0 : pd.k1 + 1) + PM_ROWS + 2) : nullptr;
+  // four elements per thread and pass: their distance loads are independent and in flight together (one element per pass exposed a
+  // full L2 round trip per iteration: 13 dependent round trips for a 199 x 199 pair)
+  for (int e0 = tid; e0 < total; e0 += 256 * 4) {
+    float v[4];
+    int seg[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = min(e0 + u * 256, total - 1);
+      const int r = e / pd.k1, j = e - r * pd.k1;
+      seg[u][0] = seg0[r]; seg[u][1] = seg0[r + 1]; seg[u][2] = seg1[j]; seg[u][3] = seg1[j + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = Dp[(int64_t)seg[u][0] * pd.n1 + seg[u][2]];      // the whole answer for 1 x 1 segments
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int a0 = seg[u][0], a1 = seg[u][1], b0 = seg[u][2], b1 = seg[u][3];
+      if (a1 - a0 != 1 || b1 - b0 != 1) {  // (A0 @ D) @ A1^T with A rows = 1/num_sublines
+        const float w0 = 1.f / (float)(a1 - a0), w1 = 1.f / (float)(b1 - b0);
+        float acc = 0.f;
+        for (int b = b0; b < b1; ++b) {
+          float t = 0.f;
+          for (int a = a0; a < a1; ++a) t += w0 * Dp[(int64_t)a * pd.n1 + b];
+          acc += t * w1;
+        }
+        v[u] = acc;
       }
     }
-    Dk[e] = v;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * 256;
+      if (e < total) {
+        Dk[e] = v[u];
+        if (dkc) dkc[e] = v[u];
+      }
+    }
   }
   __syncthreads();
+  const float* Dr = dkc ? dkc : Dk;       // where the argmin passes read the pooled rows
   int* row_arg = scratch + pd.off_seg;
   float* row_min = reinterpret_cast<float*>(row_arg + pd.k0);
   float* part_val = reinterpret_cast<float*>(row_arg + 2 * pd.k0 + pd.k1) + (int64_t)chunk * pd.k1;
@@ -185,7 +213,7 @@ __global__ __launch_bounds__(256) void pair_pool_kernel(const PairTable pairs, c
     for (int r = wave; r < rows; r += 4) {
       float best = INFINITY; int arg = 0x7fffffff;
       for (int j = lane; j < pd.k1; j += 64) {
-        const float v = fmaxf(Dk[(int64_t)r * pd.k1 + j], 0.f);
+        const float v = fmaxf(Dr[(int64_t)r * pd.k1 + j], 0.f);
         if (v < best) { best = v; arg = j; }       // ascending j per lane: strict < keeps the first
       }
 #pragma unroll
@@ -200,7 +228,7 @@ __global__ __launch_bounds__(256) void pair_pool_kernel(const PairTable pairs, c
   for (int j = tid; j < pd.k1; j += 256) {
     float best = INFINITY; int arg = 0;
     for (int r = 0; r < rows; ++r) {
-      const float v = fmaxf(Dk[(int64_t)r * pd.k1 + j], 0.f);
+      const float v = fmaxf(Dr[(int64_t)r * pd.k1 + j], 0.f);
       if (v < best) { best = v; arg = i0 + r; }
     }
     part_val[j] = best;
