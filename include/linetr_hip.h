@@ -79,9 +79,11 @@ typedef struct {
   float* angle_sub;   /* [N,2]     angle_sublines                                   */
   float* desc;        /* [N,T,256] desc_sublines                                    */
   float* score;       /* [N,T]     score_sublines                                   */
-  float* mat;         /* [K,N]     mat_klines2sublines (models/line_process.py:160-165): 1/num_sublines over a key-line's own */
-                      /*           sub-lines, 0 elsewhere.  Optional (NULL = not written); single-image calls only -- it is    */
-                      /*           written by extra blocks of the tokeniser's own launch                                    */
+  float* mat;         /* mat_klines2sublines (models/line_process.py:160-165): per image a [K_i,N_i] block, 1/num_sublines  */
+                      /*           over a key-line's own sub-lines and 0 elsewhere, the blocks back to back (image i at float     */
+                      /*           offset sum_{j<i} K_j N_j).  Optional (NULL = not written); calls of up to 8 images -- the rows   */
+                      /*           are written by extra blocks of the tokeniser's own launch                                  */
+  const int32_t* h_cu_klines; /* HOST prefix sums [n_images+1] of key-lines per image; needed with `mat` when n_images > 1     */
 } LinetrTokens;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

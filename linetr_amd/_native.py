@@ -37,7 +37,7 @@ assert REC_DTYPE.itemsize == C.sizeof(LineRec) == 80
 
 class Tokens(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("klines", "length", "angles", "sublines", "pnt", "mask", "resp",
-                                          "angle_sub", "desc", "score", "mat")]
+                                          "angle_sub", "desc", "score", "mat", "h_cu_klines")]
 
 
 class ProfileEntry(C.Structure):

@@ -303,6 +303,26 @@ int lt::make_split_copies(LinetrHandle* H, const std::vector<GemmWSpec>& weights
 // tokenise
 // =============================================================================================
 
+namespace {
+// where each image's mat_klines2sublines block goes (LinetrTokens.mat); cu_sub may be NULL for a single image
+int k2s_table(const LinetrTokens& out, int n_images, int K, int N, const int32_t* h_cu_sub, K2sTable& tab, const char* who) {
+  tab = K2sTable{};
+  if (!out.mat) return 0;
+  if (n_images > K2S_MAX_IMAGES) return fail(LINETR_E_ARG, "%s: mat_klines2sublines is written for calls of up to %d images", who, K2S_MAX_IMAGES);
+  if (n_images == 1) { tab.img[0] = K2sImage{0, N, 0}; return 0; }
+  if (!out.h_cu_klines || !h_cu_sub) return fail(LINETR_E_ARG, "%s: mat_klines2sublines of several images needs the host prefix sums of key-lines and sub-lines", who);
+  if (out.h_cu_klines[n_images] != K) return fail(LINETR_E_ARG, "%s: h_cu_klines does not end at K", who);
+  int64_t off = 0;
+  for (int i = 0; i < n_images; ++i) {
+    const int ki = out.h_cu_klines[i + 1] - out.h_cu_klines[i], ni = h_cu_sub[i + 1] - h_cu_sub[i];
+    if (ki < 0 || ni < 0) return fail(LINETR_E_ARG, "%s: prefix sums not monotone", who);
+    tab.img[i] = K2sImage{off, ni, h_cu_sub[i]};
+    off += (int64_t)ki * ni;
+  }
+  return 0;
+}
+}  // namespace
+
 extern "C" int64_t linetr_tokenize_workspace_bytes(int32_t n_images, int32_t height, int32_t width, int32_t N) {
   const int64_t P = (int64_t)(height / 8) * (width / 8);
   return align_up(n_images * P * D * 4, 256) + align_up((int64_t)std::max(N, 1) * 4, 256) + 256;
@@ -317,7 +337,9 @@ extern "C" int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int
       !out.score || (out.desc && !d_dense_desc))
     return fail(LINETR_E_ARG, "tokenize: null pointer");
   if (T < 1 || T > 4096 || height % 8 || width % 8) return fail(LINETR_E_ARG, "tokenize: bad max_tokens / image size");
-  if (out.mat && n_images != 1) return fail(LINETR_E_ARG, "tokenize: mat_klines2sublines is written for single-image calls only");
+  if (out.mat && n_images != 1) return fail(LINETR_E_ARG, "tokenize: mat_klines2sublines of several images: use linetr_describe (it has the sub-line prefix sums)");
+  K2sTable k2s;
+  if (int e = k2s_table(out, n_images, K, N, nullptr, k2s, "tokenize")) return e;
   if (ws_bytes < linetr_tokenize_workspace_bytes(n_images, height, width, N))
     return fail(LINETR_E_WORKSPACE, "tokenize: workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -336,7 +358,7 @@ extern "C" int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int
     // (with out.mat: K more blocks write the rows of mat_klines2sublines in the same launch)
     hipLaunchKernelGGL(tokenize_kernel, dim3(N + (out.mat ? K : 0)), dim3(64), 0, st, d_recs, s2l_g, N, td, T, height, width,
                        d_dense_score, out.sublines, out.pnt, out.mask, out.resp, out.angle_sub, out.score, (float*)nullptr,
-                       (float*)nullptr, 0, (int64_t)0, out.mat);
+                       (float*)nullptr, 0, (int64_t)0, out.mat, k2s);
     LT_LAUNCH_CHECK();
   }
   if (out.desc) {
@@ -904,7 +926,8 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
   if (T < 1 || T > 4096 || height % 8 || width % 8) return fail(LINETR_E_ARG, "describe: bad max_tokens / image size");
   if (n_real < N || n_real > (int64_t)N * T) return fail(LINETR_E_ARG, "describe: implausible real-token count");
   if (out.desc && !out.pnt) return fail(LINETR_E_ARG, "describe: out.desc requires out.pnt");
-  if (out.mat && n_images != 1) return fail(LINETR_E_ARG, "describe: mat_klines2sublines is written for single-image calls only");
+  K2sTable k2s;
+  if (int e = k2s_table(out, n_images, K, N, h_cu, k2s, "describe")) return e;
   if (ws_bytes < linetr_describe_workspace_bytes(h, n_images, height, width, N, n_real))
     return fail(LINETR_E_WORKSPACE, "describe: workspace too small");
   const int64_t rows = n_real + n_images;
@@ -946,7 +969,7 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
     // (the last cdiv(n_images, 64) blocks write the per-image padding rows of the compact token list)
     hipLaunchKernelGGL(tokenize_kernel, dim3(N + cdiv(n_images, 64) + (out.mat ? K : 0)), dim3(64), 0, st, d_recs, dw.s2l_g, N, td, T,
                        height, width, d_dense_score, sublines, out.pnt, out.mask, resp, angle_sub, out.score, dw.cpnt, dw.cscore,
-                       n_images, (int64_t)n_real, out.mat);
+                       n_images, (int64_t)n_real, out.mat, k2s);
     LT_LAUNCH_CHECK();
   }
   if (use_side) {

@@ -79,6 +79,12 @@ __global__ void line_fill_kernel(const LinetrLineRec* __restrict__ recs, int K, 
   }
 }
 
+// mat_klines2sublines of a small batch: where every image's [K_i][N_i] block starts (floats), its row length and the batch-wide index
+// of its first sub-line.  Travels in the kernel arguments.
+constexpr int K2S_MAX_IMAGES = 8;
+struct K2sImage { int64_t off; int n_sub; int sub_base; };
+struct K2sTable { K2sImage img[K2S_MAX_IMAGES]; };
+
 // point at arclength `d` from sp along sp->ep in the reference's slope form, float64, no FMA
 // contraction (models/line_process.py:43-57).
 __device__ __forceinline__ void walk_along(const double sp[2], const double ep[2], double d, double& x, double& y) {
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(64) void tokenize_kernel(
     int height, int width, const float* __restrict__ dense_score, float* __restrict__ sublines,
     float* __restrict__ pnt, float* __restrict__ mask, float* __restrict__ resp,
     float* __restrict__ angle_sub, float* __restrict__ score, float* __restrict__ cpnt,
-    float* __restrict__ cscore, int n_pad_images, int64_t first_pad, float* __restrict__ mat_k2s) {
+    float* __restrict__ cscore, int n_pad_images, int64_t first_pad, float* __restrict__ mat_k2s, const K2sTable k2s) {
 #pragma clang fp contract(off)
   const int n = blockIdx.x;
   if (n >= N) {
@@ -121,13 +127,16 @@ __global__ __launch_bounds__(64) void tokenize_kernel(
       }
       return;
     }
-    // one more block per key-line (single-image calls only): its row of mat_klines2sublines [K][N], 1 / num_sublines over the
-    // key-line's own sub-lines and 0 elsewhere (line_process.py:160-165; Python's 1/num is a float64 quotient stored as float32)
+    // one more block per key-line (calls of up to K2S_MAX_IMAGES images): its row of the image's mat_klines2sublines [K_i][N_i],
+    // 1 / num_sublines over the key-line's own sub-lines and 0 elsewhere (line_process.py:160-165; Python's 1/num is a float64
+    // quotient stored as float32)
     const int k = n - N - pad_blocks;
     const LinetrLineRec r = recs[k];
-    float* row = mat_k2s + (int64_t)k * N;
+    const K2sImage im = k2s.img[r.image];
+    float* row = mat_k2s + im.off + (int64_t)r.line_local * im.n_sub;
     const float w = (float)(1.0 / (double)r.n_sub);
-    for (int j = threadIdx.x; j < N; j += 64) row[j] = (j >= r.first_sub && j < r.first_sub + r.n_sub) ? w : 0.f;
+    const int j0 = r.first_sub - im.sub_base;
+    for (int j = threadIdx.x; j < im.n_sub; j += 64) row[j] = (j >= j0 && j < j0 + r.n_sub) ? w : 0.f;
     return;
   }
   const LinetrLineRec r = recs[sub2line_g[n]];

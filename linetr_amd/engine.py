@@ -44,7 +44,7 @@ class TokenBatch:
     desc: torch.Tensor        # [N,T,256]
     score: torch.Tensor       # [N,T]
     sub2line: torch.Tensor    # [N] int32, key-line index inside the image
-    mat: torch.Tensor = None  # [K,N] mat_klines2sublines (single-image tokenise calls with want_mat=True)
+    mat: torch.Tensor = None  # mat_klines2sublines with want_mat=True: [K,N] for one image, the flat per-image blocks for a batch (mat_of)
     extra: dict = field(default_factory=dict)
 
     @property
@@ -54,6 +54,13 @@ class TokenBatch:
     @property
     def N(self):
         return int(self.cu_n[-1])
+
+    def mat_of(self, i: int) -> torch.Tensor:
+        """mat_klines2sublines [K_i,N_i] of image i (describe(..., want_mat=True))."""
+        k = np.diff(self.cu_k).astype(np.int64)
+        n = np.diff(self.cu_n).astype(np.int64)
+        off = int((k[:i] * n[:i]).sum())
+        return self.mat.reshape(-1)[off:off + int(k[i] * n[i])].view(int(k[i]), int(n[i]))
 
     def c_tokens(self) -> nat.Tokens:
         t = nat.Tokens()
@@ -216,6 +223,35 @@ class Engine:
         self._last_host = {"slot": slot, "recs_ptr": recs.ctypes.data, "rec_bytes": rec_bytes, "B": 1}
         return recs[:K], n_out.value
 
+    def pack_many(self, lines, token_distance, max_tokens):
+        """pack() for several images of one batch (each entry: {'klines', 'length_klines', 'angles'} float64, already filtered and
+        ordered): one pinned blob  records | cu_k | cu_n, laid out like prefilter()'s, so describe() uploads it with one async copy."""
+        B = len(lines)
+        ks = [len(l["klines"]) for l in lines]
+        K = int(sum(ks))
+        rec_bytes = max(K, 1) * nat.REC_DTYPE.itemsize
+        slot = self._pinned_slot(rec_bytes + 8 * (B + 1) + 64)
+        host = slot["buf"].numpy()
+        recs = host[:rec_bytes].view(nat.REC_DTYPE)
+        cu_k = host[rec_bytes:rec_bytes + 4 * (B + 1)].view(np.int32)
+        cu_n = host[rec_bytes + 4 * (B + 1):rec_bytes + 8 * (B + 1)].view(np.int32)
+        cu_k[0] = cu_n[0] = 0
+        tok = 0
+        n_out = C.c_int32()
+        for i, l in enumerate(lines):
+            k0 = int(cu_k[i])
+            kl = np.ascontiguousarray(l["klines"], dtype=np.float64)
+            ln = np.ascontiguousarray(l["length_klines"], dtype=np.float64)
+            an = np.ascontiguousarray(l["angles"], dtype=np.float64)
+            nat.check(self._L.linetr_pack_lines(nat.np_ptr(kl), nat.np_ptr(ln), nat.np_ptr(an), ks[i], float(token_distance),
+                                                int(max_tokens), i, int(cu_n[i]), tok, nat.np_ptr(recs[k0:k0 + max(ks[i], 1)]),
+                                                C.byref(n_out)), self._L)
+            cu_k[i + 1] = k0 + ks[i]
+            cu_n[i + 1] = cu_n[i] + n_out.value
+            tok += int(recs["n_tok"][k0:k0 + ks[i]].sum())
+        self._last_host = {"slot": slot, "recs_ptr": recs.ctypes.data, "rec_bytes": rec_bytes, "B": B}
+        return recs[:K], cu_k.copy(), cu_n.copy()
+
     # ------------------------------------------------------------------ device stages
     def tokenize(self, recs, cu_k, cu_n, dense_desc, dense_score, *, token_distance, max_tokens, align_corners=False,
                  sample_desc=True, dense_layout="nchw", want_mat=False) -> TokenBatch:
@@ -283,7 +319,7 @@ class Engine:
         return tb
 
     def describe(self, recs, cu_k, cu_n, dense_desc, dense_score, *, token_distance, max_tokens, align_corners=False,
-                 want_tokens=False, dense_layout="nchw"):
+                 want_tokens=False, dense_layout="nchw", want_mat=False):
         """Fused tokenise + descriptor network for a batch (linetr_describe): real tokens only, descriptors sampled
         on the fly.  Returns (TokenBatch, line_desc [N,256]).  With want_tokens=False the dense [N,T,...] token
         tensors (pnt / mask / score / desc) are not materialised (zero-sized in the TokenBatch)."""
@@ -310,6 +346,8 @@ class Engine:
                   ("resp", (N,)), ("angle_sub", (N, 2)), ("sub2line", (N,))]
         if want_tokens:
             shapes += [("pnt", (N, T, 2)), ("mask", (N, T + 1)), ("score", (N, T))]
+        if want_mat:     # the per-image [K_i,N_i] blocks back to back, written by extra blocks of the tokeniser's launch (<= 8 images)
+            shapes.append(("mat", (int((np.diff(np.asarray(cu_k, np.int64)) * np.diff(np.asarray(cu_n, np.int64))).sum()),)))
         sizes = [(math.prod(sh) + 3) // 4 * 4 for _, sh in shapes]
         pool = torch.empty((sum(sizes),), **f)
         views, o = {}, 0
@@ -330,6 +368,11 @@ class Engine:
         ct = tb.c_tokens()
         if not want_tokens:
             ct.pnt = ct.mask = ct.desc = ct.score = None
+        cu_k32 = np.ascontiguousarray(cu_k, dtype=np.int32)
+        if want_mat:
+            ct.h_cu_klines = cu_k32.ctypes.data
+            if B == 1:
+                tb.mat = tb.mat.view(K, N)
         nbytes = self._L.linetr_describe_workspace_bytes(self._h, B, H, W, N, n_real)
         ws = self._workspace(getattr(self, "_ws_tag", None) or "desc", nbytes)
         cu = np.ascontiguousarray(cu_n, dtype=np.int32)

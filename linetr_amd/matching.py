@@ -50,14 +50,50 @@ class Matching(torch.nn.Module):
         self.lsd = lsd if lsd is not None else _frontend("line_detector", "LSD", config.get("lsd", {}))
         self.linetransformer = LineTransformer(config.get("linetransformer", {}))
 
-    def _tokenize_lines(self, image, pred_sp, valid_mask):
+    def _describe_fused(self, data, sp, sides, detected):
+        """Both images of a pair through ONE fused native call (linetr_describe: tokeniser + descriptor network on the real tokens,
+        every tensor of the reference's dict materialised, mat_klines2sublines from the same launch): 45 launches instead of 2 x 44,
+        and the pair's GEMMs see 398 rows instead of twice 199.  The NumPy glue -- and with it the reference's ordering of equal
+        lengths -- is untouched; descriptors equal the per-image path's to fp32 round-off (tests/test_gpu_dropin.py).
+        Returns the two dicts (preprocess + forward of models/line_transformer.py:225-275), or None when the pair does not
+        qualify (an image without lines, maps of different shapes or not on the device)."""
+        from .line_process import change_cv2_T_np, filter_by_length, remove_borders
         lt = self.linetransformer
-        shape = image.shape
-        if self.auto_min_length:                                  # matching.py:30-32
-            lt.config["min_length"] = max(16, max(shape) / 40)
-            lt.config["token_distance"] = max(8, max(shape) / 80)
-        klines_cv = self.lsd.detect_torch(image)
-        return lt.preprocess(klines_cv, shape, pred_sp, valid_mask)
+        imgs = [data["image" + s] for s in sides]
+        shape = tuple(imgs[0].shape)
+        nhwc = all(sp[s].get("dense_descriptor_nhwc") is not None for s in sides)
+        key = "dense_descriptor_nhwc" if nhwc else "dense_descriptor"
+        dds, dss = [sp[s][key] for s in sides], [sp[s]["dense_score"] for s in sides]
+        if tuple(imgs[1].shape) != shape or not all(t.is_cuda for t in dds + dss) or dds[0].shape != dds[1].shape:
+            return None
+        _, _, height, width = lt.config["image_shape"] = shape   # (LineTransformer.preprocess writes it too: line_transformer.py:258)
+        c = lt.config
+        td, T = c["token_distance"], c["max_tokens"]
+        lines = []
+        for s in sides:
+            kl = change_cv2_T_np(detected[s])
+            kl = filter_by_length(remove_borders(kl, c["remove_borders"], height, width, data["valid_mask" + s]), c["min_length"],
+                                  c["max_keylines"])
+            lines.append(kl)
+        if any(len(kl["klines"]) == 0 for kl in lines):
+            return None
+        eng = lt.engine(dds[0].device)
+        recs, cu_k, cu_n = eng.pack_many(lines, td, T)
+        align = int(torch.__version__[2]) > 2                     # the reference's own version switch (line_process.py:93)
+        tb, ld = eng.describe(recs, cu_k, cu_n, torch.cat(dds), torch.cat(dss), token_distance=td, max_tokens=T,
+                              align_corners=align, want_tokens=True, dense_layout="nhwc" if nhwc else "nchw", want_mat=True)
+        outs = []
+        for i in range(2):
+            k0, k1, n0, n1 = int(cu_k[i]), int(cu_k[i + 1]), int(cu_n[i]), int(cu_n[i + 1])
+            mat = tb.mat_of(i)[None]
+            mat._linetr_sub2line = tb.sub2line[n0:n1]
+            outs.append({"klines": tb.klines[k0:k1][None], "length_klines": tb.length[k0:k1][None], "angles": tb.angles[k0:k1][None],
+                         "sublines": tb.sublines[n0:n1][None], "pnt_sublines": tb.pnt[n0:n1][None],
+                         "mask_sublines": tb.mask[n0:n1][None, :, :, None], "resp_sublines": tb.resp[n0:n1][None, :, None],
+                         "angle_sublines": tb.angle_sub[n0:n1][None], "desc_sublines": tb.desc[n0:n1][None],
+                         "score_sublines": tb.score[n0:n1][None, :, :, None], "mat_klines2sublines": mat,
+                         "line_desc": ld[n0:n1].t()[None]})
+        return outs
 
     def forward(self, data):
         pred = {}
@@ -66,16 +102,22 @@ class Matching(torch.nn.Module):
             if "keypoints" + s not in data:
                 sp[s] = self.superpoint({"image": data["image" + s]})
                 pred.update({k + s: v for k, v in sp[s].items()})
-        # detect + tokenise each image (matching.py:34-41, :52-59), then describe the images that need it in ONE native call
-        sides, pres = [], []
-        for s in ("0", "1"):
-            if "klines" + s not in data:
-                img = data["image" + s]
-                if "valid_mask" + s not in data:
-                    data["valid_mask" + s] = torch.ones_like(img)   # a tensor: ignored downstream (matching.py:37-40)
-                sides.append(s)
-                pres.append(self._tokenize_lines(img, sp[s], data["valid_mask" + s]))
-        for s, out in zip(sides, self.linetransformer.forward_many(pres)):
+        # detect + tokenise + describe the images that need it (matching.py:34-41, :52-59)
+        sides = [s for s in ("0", "1") if "klines" + s not in data]
+        for s in sides:
+            if "valid_mask" + s not in data:
+                data["valid_mask" + s] = torch.ones_like(data["image" + s])   # a tensor: ignored downstream (matching.py:37-40)
+        lt = self.linetransformer
+        if sides and self.auto_min_length:                        # matching.py:30-32
+            shape = data["image" + sides[0]].shape
+            lt.config["min_length"] = max(16, max(shape) / 40)
+            lt.config["token_distance"] = max(8, max(shape) / 80)
+        detected = {s: self.lsd.detect_torch(data["image" + s]) for s in sides}
+        outs = self._describe_fused(data, sp, sides, detected) if len(sides) == 2 else None
+        if outs is None:     # one image (anchor cached), an image without lines, host tensors: image by image, described together
+            pres = [lt.preprocess(detected[s], data["image" + s].shape, sp[s], data["valid_mask" + s]) for s in sides]
+            outs = lt.forward_many(pres)
+        for s, out in zip(sides, outs):
             pred.update({k + s: v for k, v in out.items()})
         data = {**data, **pred}
         for k in data:

@@ -401,3 +401,46 @@ def test_training_time_batched_forward_golden():
     # batch element b equals the same image pushed through alone (the signature attention is per image)
     alone = m({k: v[1:2].clone() for k, v in batch.items() if k != "line_desc"})
     assert (alone["line_desc"][0] - res["line_desc"][1]).abs().max().item() < 2e-6
+
+
+def test_matching_forward_fused_pair_equals_the_per_image_path(monkeypatch):
+    """Matching.forward sends the two images of a pair through ONE fused native call (Matching._describe_fused); every entry of the
+    reference's dict must be what the per-image path (preprocess + forward per image) returns: token tensors bit for bit, descriptors
+    to fp32 round-off, matches and key order identical.  Also: a pair with a line-less image falls back without detecting twice."""
+    from models.matching import Matching
+    g = load("cfg2_pair")
+
+    def build(lines):
+        mt = Matching({"auto_min_length": False, "linetransformer": {**LT_CFG}},
+                      superpoint=FakeSuperPoint([int(g["a_seed"]), int(g["b_seed"])]), lsd=FakeLSD(lines))
+        mt.linetransformer.load_state_dict(synth.to_torch_state_dict(synth.calibrated_state_dict()))
+        return mt.eval().to("cuda")
+    img = torch.zeros(1, 1, 480, 640, device="cuda")
+    fused_calls = []
+    orig = Matching._describe_fused
+    monkeypatch.setattr(Matching, "_describe_fused", lambda self, *a: fused_calls.append(1) or orig(self, *a))
+    fused = build([g["a_lines"], g["b_lines"]])({"image0": img, "image1": img.clone()})
+    assert fused_calls == [1]
+    monkeypatch.setattr(Matching, "_describe_fused", lambda self, *a: None)
+    plain = build([g["a_lines"], g["b_lines"]])({"image0": img, "image1": img.clone()})
+    assert list(fused.keys()) == list(plain.keys())
+    for k in plain:
+        a, b = fused[k], plain[k]
+        if not torch.is_tensor(a):
+            continue
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+        if k.startswith("line_desc"):
+            assert (a - b).abs().max().item() < 5e-6, k
+            assert np.abs(a.cpu().numpy() - g[("a" if k.endswith("0") else "b") + "_line_desc"]).max() < 1e-4
+        elif k == "matching_scores_l":
+            assert (a - b).abs().max().item() < 1e-5
+        else:
+            assert torch.equal(a.cpu(), b.cpu()), k
+    assert np.array_equal(fused["matches_l"].numpy(), g["pair_M"])
+    assert hasattr(fused["mat_klines2sublines0"], "_linetr_sub2line")
+    # one image without a single usable line: the per-image path takes over, the detector is asked once per image
+    monkeypatch.setattr(Matching, "_describe_fused", orig)
+    short = np.array([[100.0, 100.0, 105.0, 100.0, 5.0, 0.0]])
+    mt = build([g["a_lines"], short])
+    out = mt({"image0": img, "image1": img.clone()})
+    assert mt.lsd.sets == [] and out["line_desc1"].shape == (1, 256, 0) and out["matches_l"].shape == (1, 199, 0)
