@@ -124,31 +124,34 @@ class Matching(torch.nn.Module):
             if isinstance(data[k], (list, tuple)):
                 data[k] = torch.stack(data[k])
 
-        # point matches (models/nn_matcher.py:33-42 on the device; the descriptors never leave it)
+        # point matches (models/nn_matcher.py:33-42) and line matches (D -> key-line pooling -> mutual NN, matching.py:77-84): both are
+        # queued on the device first, then ONE synchronisation brings the four result arrays to the host
+        from .line_process import _token_engine
         d0, d1 = data["descriptors0"][0].detach(), data["descriptors1"][0].detach()
-        if d0.is_cuda and d0.shape[0] == 256 and d0.shape[1] > 0 and d1.shape[1] > 0:
-            eng = self._engine_for(d0.device)
+        thr_l = self.linetransformer.config["nn_threshold"]
+        line_args = (data["line_desc0"], data["mat_klines2sublines0"], data["line_desc1"], data["mat_klines2sublines1"], thr_l)
+        on_dev = d0.is_cuda and d0.shape[0] == 256 and d0.shape[1] > 0 and d1.shape[1] > 0
+        lines_q = self._queue_line_match(*line_args) if on_dev else None
+        if on_dev and lines_q is not None:
+            eng = _token_engine(d0.device)                        # the matchers need no weights (and no weight-version check)
             dist, m01 = eng.match_points(d0, d1, float(np.float32(self.superpoint.config["nn_threshold"])), True)
-            m01_h, dist_h = eng.to_host(m01, dist)
+            dk, m01_l, K0, K1 = lines_q
+            m01_h, dist_h, m01_lh, dk_h = eng.to_host(m01, dist, m01_l, dk)
             m_p, d_p = match01_to_matrix(m01_h, int(d1.shape[1])), dist_h[None]
-        else:   # empty sets / host tensors: the NumPy-in, NumPy-out surface function
-            m_p, d_p = nn_matcher(d0.cpu().numpy(), d1.cpu().numpy(), self.superpoint.config["nn_threshold"], is_mutual_NN=True)
+            m_l, d_l = match01_to_matrix(m01_lh, K1), dk_h.reshape(1, K0, K1)
+        else:   # empty sets / host tensors: the NumPy-in, NumPy-out surface functions, one after the other
+            if on_dev:
+                dist, m01 = _token_engine(d0.device).match_points(d0, d1, float(np.float32(self.superpoint.config["nn_threshold"])), True)
+                m01_h, dist_h = _token_engine(d0.device).to_host(m01, dist)
+                m_p, d_p = match01_to_matrix(m01_h, int(d1.shape[1])), dist_h[None]
+            else:
+                m_p, d_p = nn_matcher(d0.cpu().numpy(), d1.cpu().numpy(), self.superpoint.config["nn_threshold"], is_mutual_NN=True)
+            m_l, d_l = self.match_lines(*line_args)
         pred["matches_p"] = torch.from_numpy(m_p)
         pred["matching_scores_p"] = torch.from_numpy(d_p)
-
-        # line matches: D -> key-line pooling -> mutual NN in one native call
-        m_l, d_l = self.match_lines(data["line_desc0"], data["mat_klines2sublines0"], data["line_desc1"],
-                                    data["mat_klines2sublines1"], self.linetransformer.config["nn_threshold"])
         pred["matches_l"] = torch.from_numpy(m_l)
         pred["matching_scores_l"] = torch.from_numpy(d_l)
         return pred
-
-    def _engine_for(self, device):
-        try:
-            return self.linetransformer.engine(device)
-        except RuntimeError:      # LineTransformer still on the CPU: the matcher needs no weights
-            from .line_process import _token_engine
-            return _token_engine(device)
 
     def forward_batch(self, pairs):
         """Batched counterpart of forward() (section 8(f)-3: the reference's surface is one pair per call).
@@ -232,12 +235,13 @@ class Matching(torch.nn.Module):
             preds.append(pred)
         return preds
 
-    def match_lines(self, line_desc0, mat0, line_desc1, mat1, thr):
-        """(matches [1,K0,K1] float64, Dk [1,K0,K1] float32) as NumPy, like matching.py:77-84."""
+    def _queue_line_match(self, line_desc0, mat0, line_desc1, mat1, thr):
+        """Queues get_dist_matrix + subline2keyline + nn_matcher_distmat of one pair on the device (asynchronous).
+        Returns (Dk flat, match01, K0, K1) as device tensors, or None when a side has no key-line."""
         K0, N0 = int(mat0.shape[1]), int(mat0.shape[2])
         K1, N1 = int(mat1.shape[1]), int(mat1.shape[2])
         if K0 == 0 or K1 == 0:
-            return np.zeros((1, K0, K1)), np.zeros((1, K0, K1), dtype=np.float32)
+            return None
         # the matcher needs no weights: the weight-less engine serves it (no weight-version check on this call)
         from .line_process import _token_engine
         eng = _token_engine(line_desc0.device if line_desc0.is_cuda else self.linetransformer._device())
@@ -254,5 +258,15 @@ class Matching(torch.nn.Module):
             s1 = mat1[0].to(dev).argmax(dim=0).to(torch.int32)
         dk, _, m01 = eng.match(d0, np.array([0, N0]), s0, np.array([0, K0]), d1, np.array([0, N1]), s1,
                                np.array([0, K1]), float(np.float32(thr)), True)
-        m01_h, dk_h = eng.to_host(m01, dk)   # one synchronisation for both results
+        return dk, m01, K0, K1
+
+    def match_lines(self, line_desc0, mat0, line_desc1, mat1, thr):
+        """(matches [1,K0,K1] float64, Dk [1,K0,K1] float32) as NumPy, like matching.py:77-84."""
+        q = self._queue_line_match(line_desc0, mat0, line_desc1, mat1, thr)
+        if q is None:
+            K0, K1 = int(mat0.shape[1]), int(mat1.shape[1])
+            return np.zeros((1, K0, K1)), np.zeros((1, K0, K1), dtype=np.float32)
+        dk, m01, K0, K1 = q
+        from .line_process import _token_engine
+        m01_h, dk_h = _token_engine(dk.device).to_host(m01, dk)   # one synchronisation for both results
         return match01_to_matrix(m01_h, K1), dk_h.reshape(1, K0, K1)
