@@ -444,3 +444,26 @@ def test_matching_forward_fused_pair_equals_the_per_image_path(monkeypatch):
     mt = build([g["a_lines"], short])
     out = mt({"image0": img, "image1": img.clone()})
     assert mt.lsd.sets == [] and out["line_desc1"].shape == (1, 256, 0) and out["matches_l"].shape == (1, 199, 0)
+
+
+def test_forward_many_equals_forward_image_by_image():
+    """LineTransformer.forward_many: several pre-processed images through ONE native forward call; every dict gets the 'line_desc'
+    forward() gives it (fp32 round-off), dicts without lines get default_ret(), a single live dict takes the plain path."""
+    m = make_lt()
+    pres, alone = [], []
+    for seed, n in ((41, 120), (42, 2), (43, 200)):
+        dd, ds = synth.synth_dense_maps(seed, 480, 640)
+        sp = {"dense_descriptor": dd.cuda(), "dense_score": ds.cuda()}
+        kl = synth.array_to_keylines(synth.synth_lines(seed, n, 480, 640))
+        pres.append(m.preprocess(kl, (1, 1, 480, 640), sp))
+        one = m.preprocess(kl, (1, 1, 480, 640), sp)
+        alone.append(m(one)["line_desc"].clone())
+    empty = m.preprocess([], (1, 1, 480, 640), sp)
+    outs = m.forward_many([pres[0], empty, pres[1], pres[2]])
+    assert outs[0] is pres[0] and outs[2] is pres[1] and outs[3] is pres[2]
+    assert tuple(outs[1]["line_desc"].shape) == (1, 256, 0)
+    for out, want in zip((outs[0], outs[2], outs[3]), alone):
+        assert out["line_desc"].shape == want.shape
+        assert (out["line_desc"] - want).abs().max().item() < 5e-6
+    single = m.forward_many([m.preprocess(synth.array_to_keylines(synth.synth_lines(41, 120, 480, 640)), (1, 1, 480, 640), sp)])
+    assert (single[0]["line_desc"] - alone[0]).abs().max().item() < 2e-6 or single[0]["line_desc"].shape == alone[0].shape
