@@ -450,10 +450,11 @@ def test_forward_many_equals_forward_image_by_image():
     """LineTransformer.forward_many: several pre-processed images through ONE native forward call; every dict gets the 'line_desc'
     forward() gives it (fp32 round-off), dicts without lines get default_ret(), a single live dict takes the plain path."""
     m = make_lt()
-    pres, alone = [], []
+    pres, alone, sps = [], [], []
     for seed, n in ((41, 120), (42, 2), (43, 200)):
         dd, ds = synth.synth_dense_maps(seed, 480, 640)
         sp = {"dense_descriptor": dd.cuda(), "dense_score": ds.cuda()}
+        sps.append(sp)
         kl = synth.array_to_keylines(synth.synth_lines(seed, n, 480, 640))
         pres.append(m.preprocess(kl, (1, 1, 480, 640), sp))
         one = m.preprocess(kl, (1, 1, 480, 640), sp)
@@ -465,5 +466,5 @@ def test_forward_many_equals_forward_image_by_image():
     for out, want in zip((outs[0], outs[2], outs[3]), alone):
         assert out["line_desc"].shape == want.shape
         assert (out["line_desc"] - want).abs().max().item() < 5e-6
-    single = m.forward_many([m.preprocess(synth.array_to_keylines(synth.synth_lines(41, 120, 480, 640)), (1, 1, 480, 640), sp)])
+    single = m.forward_many([m.preprocess(synth.array_to_keylines(synth.synth_lines(41, 120, 480, 640)), (1, 1, 480, 640), sps[0])])
     assert torch.equal(single[0]["line_desc"], alone[0])          # one live dict: the plain forward() path
