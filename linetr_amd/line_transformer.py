@@ -8,7 +8,7 @@ parameters; tokenisation, the descriptor network and the matcher run in liblinet
 
 Reference behaviour mirrored here (file:line in the reference checkout):
   * config dict merged over default_config and mutated by callers (models/line_transformer.py:187-206)
-  * mode == 'test' loads <pkg>/weights/LineTR_weight.pth strictly and prints a message (:220-223)
+  * mode == 'test' loads weights/LineTR_weight.pth (next to the `models/` shim, or in this package) strictly and prints a message (:220-223)
   * preprocess(): cv2 KeyLines -> arrays -> remove_borders -> filter_by_length -> tokeniser (:251-275; the module-level
     functions live in linetr_amd.line_process, as in the reference);
     writes config['image_shape'] = image_shape (:258); ndarray valid masks honoured, tensors ignored
@@ -107,9 +107,26 @@ class LineTransformer(nn.Module):
         self._engine = None
         self._engine_key = None
         if c["mode"] == "test":
-            path = Path(__file__).parent / "weights/LineTR_weight.pth"
-            self.load_state_dict(torch.load(path))
+            self.load_state_dict(torch.load(self._weight_file()))
             print("Loaded Line-Transformer model")
+
+    @staticmethod
+    def _weight_file():
+        """The authors' checkpoint.  The reference loads <its models package>/weights/LineTR_weight.pth
+        (models/line_transformer.py:220-221); after the drop-in that file still sits next to the `models/` shim, so it is looked
+        for there first, then in this package, then under $LINETR_WEIGHTS."""
+        import os
+        import sys
+        cands = []
+        shim = sys.modules.get("models")
+        for base in list(getattr(shim, "__path__", [])) + [str(Path(__file__).parent)]:
+            cands.append(Path(base) / "weights/LineTR_weight.pth")
+        if os.environ.get("LINETR_WEIGHTS"):
+            cands.append(Path(os.environ["LINETR_WEIGHTS"]))
+        for p in cands:
+            if p.exists():
+                return p
+        raise FileNotFoundError("LineTR_weight.pth not found; looked in: " + ", ".join(str(p) for p in cands))
 
     # -- native engine management ---------------------------------------------------------------
     def _device(self):

@@ -28,7 +28,24 @@ def test_state_dict_layout_and_config():
 
 def test_mode_test_requires_weight_file():
     with pytest.raises(FileNotFoundError):
-        LT.LineTransformer({})           # mode == 'test' -> <pkg>/weights/LineTR_weight.pth (absent blob)
+        LT.LineTransformer({})           # mode == 'test' -> weights/LineTR_weight.pth (absent blob)
+
+
+def test_mode_test_finds_the_checkpoint_where_the_reference_keeps_it(tmp_path, monkeypatch, capsys):
+    """models/line_transformer.py:220-223: mode 'test' loads <models package>/weights/LineTR_weight.pth strictly and prints a message.
+    After the drop-in that directory belongs to the `models/` shim, so that is where the file is looked for first; $LINETR_WEIGHTS last."""
+    import models
+    sd = LT.LineTransformer({"mode": "train"}).state_dict()
+    w = tmp_path / "models" / "weights"
+    w.mkdir(parents=True)
+    torch.save(sd, w / "LineTR_weight.pth")
+    monkeypatch.setattr(models, "__path__", [str(tmp_path / "models")] + list(models.__path__))
+    m = LT.LineTransformer({})
+    assert "Loaded Line-Transformer model" in capsys.readouterr().out
+    assert all(torch.equal(v, sd[k]) for k, v in m.state_dict().items())
+    monkeypatch.setattr(models, "__path__", list(models.__path__)[1:])
+    monkeypatch.setenv("LINETR_WEIGHTS", str(w / "LineTR_weight.pth"))
+    LT.LineTransformer({"mode": "test"})
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check")
