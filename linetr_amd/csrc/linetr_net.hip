@@ -309,7 +309,10 @@ int k2s_table(const LinetrTokens& out, int n_images, int K, int N, const int32_t
   tab = K2sTable{};
   if (!out.mat) return 0;
   if (n_images > K2S_MAX_IMAGES) return fail(LINETR_E_ARG, "%s: mat_klines2sublines is written for calls of up to %d images", who, K2S_MAX_IMAGES);
-  if (n_images == 1) { tab.img[0] = K2sImage{0, N, 0}; return 0; }
+  if (n_images == 1) {   // whatever image index the caller's records carry, it is this one image
+    for (int i = 0; i < K2S_MAX_IMAGES; ++i) tab.img[i] = K2sImage{0, N, 0};
+    return 0;
+  }
   if (!out.h_cu_klines || !h_cu_sub) return fail(LINETR_E_ARG, "%s: mat_klines2sublines of several images needs the host prefix sums of key-lines and sub-lines", who);
   if (out.h_cu_klines[n_images] != K) return fail(LINETR_E_ARG, "%s: h_cu_klines does not end at K", who);
   int64_t off = 0;

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void tokenize_kernel(
     // quotient stored as float32)
     const int k = n - N - pad_blocks;
     const LinetrLineRec r = recs[k];
-    const K2sImage im = k2s.img[r.image];
+    const K2sImage im = k2s.img[r.image & (K2S_MAX_IMAGES - 1)];
     float* row = mat_k2s + im.off + (int64_t)r.line_local * im.n_sub;
     const float w = (float)(1.0 / (double)r.n_sub);
     const int j0 = r.first_sub - im.sub_base;
