@@ -1,3 +1,5 @@
+"""Wall time and cProfile of `Matching.forward` (the call the reference's scripts make per pair: match_line_pairs.py:90, demo_LineTR.py:207)
+through the models.* shim, with KeyLines and SuperPoint outputs injected.   python tools/matching_forward_hostprof.py   (on the GPU box)"""
 import cProfile, pstats, sys, os, torch, numpy as np, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import bench
