@@ -1,0 +1,74 @@
+"""Descriptor / match parity soak: P random pairs (random line counts, seeds, both dense layouts) described as ONE batch on the GPU and
+matched, against the CPU oracle pair by pair: max |descriptor - oracle|, line matches identical by index, smallest argmin margin.
+    python tools/parity_soak.py [pairs]      (on the GPU box)"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from linetr_amd.engine import Engine  # noqa: E402
+from oracle import linetr_oracle as O  # noqa: E402
+from workloads import synth  # noqa: E402
+
+
+def main():
+    P = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    torch.set_grad_enabled(False)
+    torch.set_num_threads(8)
+    hw = (480, 640)
+    cfg = dict(min_length=16, token_distance=8, max_tokens=21, remove_borders=8, max_keylines=-1)
+    sdn = synth.calibrated_state_dict()
+    sd = synth.to_torch_state_dict(sdn)
+    eng = Engine(sdn, "cuda:0")
+    rs = np.random.RandomState(2026)
+    lines, maps = [], []
+    for i in range(2 * P):
+        seed = 70000 + i
+        lines.append(synth.synth_lines(seed, int(rs.randint(12, 320)), *hw))
+        maps.append(synth.synth_dense_maps(seed, *hw))
+    dd = torch.cat([m[0] for m in maps]).cuda()
+    ds = torch.cat([m[1] for m in maps]).cuda()
+    off = np.concatenate([[0], np.cumsum([len(l) for l in lines])]).astype(np.int32)
+    kw = dict(remove_borders=8, min_length=16, max_keylines=-1, token_distance=8, max_tokens=21)
+    tb, ld = eng.describe_lines(np.concatenate(lines), off, dd, ds, **kw)
+    tb2, ld2 = eng.describe_lines(np.concatenate(lines), off, dd.permute(0, 2, 3, 1).contiguous(), ds, dense_layout="nhwc", **kw)
+    n, k = np.diff(tb.cu_n), np.diff(tb.cu_k)
+    cs = lambda v: np.concatenate([[0], np.cumsum(v)]).astype(np.int64)
+    i0 = torch.cat([torch.arange(tb.cu_n[i], tb.cu_n[i + 1]) for i in range(0, 2 * P, 2)]).cuda()
+    i1 = torch.cat([torch.arange(tb.cu_n[i], tb.cu_n[i + 1]) for i in range(1, 2 * P, 2)]).cuda()
+    dk, off_dk, m01 = eng.match(ld[i0], cs(n[0::2]), tb.sub2line[i0], cs(k[0::2]), ld[i1], cs(n[1::2]), tb.sub2line[i1], cs(k[1::2]), 0.8, True)
+    torch.cuda.synchronize()
+    ld_c, m01_c, dk_c, ck0 = ld.cpu().numpy(), m01.cpu().numpy(), dk.cpu().numpy(), cs(k[0::2])
+    worst = worst_dk = 0.0
+    bad_pairs, margin, n_match, t0 = 0, np.inf, 0, time.time()
+    for p in range(P):
+        outs = []
+        for s in range(2):
+            i = 2 * p + s
+            o = O.preprocess(synth.array_to_keylines(lines[i]), (1, 1, *hw), maps[i][0], maps[i][1], cfg)
+            o = O.forward(sd, o, hw)
+            worst = max(worst, float(np.abs(ld_c[tb.cu_n[i]:tb.cu_n[i + 1]].T - o["line_desc"][0].numpy()).max()))
+            outs.append(o)
+        M, Dk = O.match_lines(outs[0]["line_desc"], outs[1]["line_desc"], outs[0]["mat_klines2sublines"][0], outs[1]["mat_klines2sublines"][0], 0.8)
+        K0, K1 = M.shape[1], M.shape[2]
+        got = np.zeros_like(M[0])
+        mm = m01_c[ck0[p]:ck0[p] + K0]
+        got[np.nonzero(mm >= 0)[0], mm[mm >= 0]] = 1
+        bad_pairs += int(not np.array_equal(got, M[0]))
+        n_match += int(got.sum())
+        worst_dk = max(worst_dk, float(np.abs(dk_c[off_dk[p]:off_dk[p + 1]].reshape(K0, K1) - Dk[0]).max()))
+        for d in (Dk[0], Dk[0].T):
+            if d.shape[1] >= 2:
+                two = np.partition(d, 1, axis=1)[:, :2]
+                margin = min(margin, float((two[:, 1] - two[:, 0]).min()))
+    print(f"{P} pairs, {int(tb.N)} descriptors, {n_match} line matches: max |desc - oracle| = {worst:.2e}, max |Dk - oracle| = {worst_dk:.2e}, "
+          f"pairs with a differing match matrix = {bad_pairs}, smallest argmin margin = {margin:.2e}, NHWC-fed vs NCHW-fed descriptors "
+          f"max diff = {(ld - ld2).abs().max().item():.1e}  (oracle time {time.time() - t0:.0f} s)")
+
+
+if __name__ == "__main__":
+    main()
