@@ -107,7 +107,8 @@ void linetr_destroy(LinetrHandle* h);
  * :6-21) on one image.  h_lines6 = [K,6] rows (startX,startY,endX,endY,lineLength,octave).
  * h_valid_mask: NULL (== the reference's non-ndarray mask, i.e. ignored) or [height,width] float64.
  * max_keylines follows the reference's slice semantics ([:max_keylines], so -1 drops the shortest).
- * Ties in length are ordered by descending original index (== a stable ascending argsort, reversed).
+ * Ties in length are ordered by descending original index (== a stable ascending argsort, reversed); linetr_prefilter_tied_images
+ * reports them, for hosts that want NumPy's order instead.
  * Writes up to `capacity` records (first_sub/n_tok/n_sub/image filled as by linetr_pack_lines;
  * `sub_base` / `tok_base` = number of sub-lines / real tokens of the images that precede this one in the batch) and
  * returns K' in *k_out, the number of sub-lines of this image in *n_out.  LINETR_E_ASSERT if a token distance
@@ -129,6 +130,15 @@ int linetr_prefilter_batch(const double* h_lines6, const int32_t* h_line_off, in
                            const double* const* h_valid_masks, double token_distance, int32_t max_tokens,
                            int32_t n_threads, LinetrLineRec* h_recs, int32_t capacity, int32_t* h_cu_k,
                            int32_t* h_cu_n);
+
+/* Which images of the LAST linetr_prefilter / linetr_prefilter_batch call on the calling thread had two candidates of EQUAL
+ * length in front of the length sort (models/line_process.py:15-16): there the reference's order -- np.argsort, an unstable,
+ * CPU-dispatched sort -- is whatever NumPy does on the host, and a tie across the [:max_keylines] cut even changes the set.
+ * Writes up to `capacity` image indices (ascending; 0 for linetr_prefilter) and returns their number.  A host that has NumPy
+ * re-orders exactly those images with it and re-packs them through linetr_pack_lines (linetr_amd/engine.py prefilter,
+ * tie_order="numpy"), which makes the batched path identical by index to the reference on that machine; every other image
+ * has a unique order. */
+int32_t linetr_prefilter_tied_images(int32_t* h_images, int32_t capacity);
 
 /* Same record packing for lines that were already filtered/sorted by the caller (the Python shim
  * keeps NumPy's own argsort so that tie order is the reference's on the same machine).

@@ -73,6 +73,8 @@ def lib(path=None):
     L.linetr_prefilter.argtypes = [vp, i32, i32, i32, i32, f64, i32, vp, f64, i32, i32, i32, i32, vp, i32, C.POINTER(i32),
                                    C.POINTER(i32)]
     L.linetr_prefilter_batch.argtypes = [vp, vp, i32, i32, i32, i32, f64, i32, vp, f64, i32, i32, vp, i32, vp, vp]
+    L.linetr_prefilter_tied_images.argtypes = [vp, i32]
+    L.linetr_prefilter_tied_images.restype = i32
     L.linetr_pack_lines.argtypes = [vp, vp, vp, i32, f64, i32, i32, i32, i32, vp, C.POINTER(i32)]
     L.linetr_describe_workspace_bytes.argtypes = [vp, i32, i32, i32, i32, i64]
     L.linetr_describe_workspace_bytes.restype = i64
@@ -122,7 +124,7 @@ def lib(path=None):
 
 
 EXPORTS = ["linetr_abi_version", "linetr_last_error", "linetr_create", "linetr_destroy", "linetr_prefilter",
-           "linetr_prefilter_batch", "linetr_pack_lines", "linetr_tokenize_workspace_bytes", "linetr_tokenize", "linetr_forward_workspace_bytes",
+           "linetr_prefilter_batch", "linetr_prefilter_tied_images", "linetr_pack_lines", "linetr_tokenize_workspace_bytes", "linetr_tokenize", "linetr_forward_workspace_bytes",
            "linetr_forward", "linetr_describe_workspace_bytes", "linetr_describe", "linetr_match_workspace_bytes", "linetr_match", "linetr_match_gathered", "linetr_match_points",
            "linetr_match_distmat", "linetr_match_distmat_workspace_bytes", "linetr_superpoint_heads", "linetr_set_precision", "linetr_get_precision", "linetr_debug_posenc", "linetr_debug_gemm", "linetr_allgather_desc", "linetr_set_allgather_fn", "linetr_pack_slab", "linetr_sample_descriptors_workspace_bytes",
            "linetr_sample_descriptors", "linetr_pool_distmat_workspace_bytes", "linetr_pool_distmat", "linetr_set_profiling", "linetr_get_profile"]

@@ -486,9 +486,11 @@ extern "C" int linetr_pack_lines(const double* h_klines, const double* h_length,
 // lines and returns where to write them: straight into the caller's record array on the single-thread path (a record is 80 bytes;
 // the earlier form copied every survivor three times).
 struct KeptLine { double sp[2], ep[2], length; };
+// images of the last pre-filter call on this thread whose sorted candidates held equal lengths (linetr_prefilter_tied_images)
+static thread_local std::vector<int32_t> g_tied_images;
 template <class Emit>
 static void prefilter_core(const double* L, int32_t K, int32_t height, int32_t width, int32_t border,
-                           double min_length, int32_t max_keylines, const double* vm, Emit emit) {
+                           double min_length, int32_t max_keylines, const double* vm, bool* tied, Emit emit) {
   static thread_local std::vector<KeptLine> keep;
   static thread_local std::vector<std::pair<double, int>> order;
   keep.clear();
@@ -525,6 +527,10 @@ static void prefilter_core(const double* L, int32_t K, int32_t height, int32_t w
   order.resize(keep.size());
   for (size_t i = 0; i < keep.size(); ++i) order[i] = {keep[i].length, (int)i};
   std::stable_sort(order.begin(), order.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
+  // equal lengths anywhere among the candidates (a tie across the [:max_keylines] cut changes the SET, not only the order)
+  *tied = false;
+  for (size_t i = 1; i < order.size(); ++i)
+    if (order[i].first == order[i - 1].first) { *tied = true; break; }
   int64_t n_keep = (int64_t)order.size();
   if (max_keylines < 0) n_keep = std::max<int64_t>(0, n_keep + max_keylines);                // python slice [:m]
   else n_keep = std::min<int64_t>(n_keep, max_keylines);
@@ -545,10 +551,13 @@ extern "C" int linetr_prefilter(const double* L, int32_t K, int32_t height, int3
                                 int32_t capacity, int32_t* k_out, int32_t* n_out) {
   if (K < 0 || (K > 0 && !L) || !k_out || !n_out) return fail(LINETR_E_ARG, "null argument");
   int64_t n_sel = -1;
-  prefilter_core(L, K, height, width, border, min_length, max_keylines, vm, [&](int64_t n) -> LinetrLineRec* {
+  bool tied = false;
+  g_tied_images.clear();
+  prefilter_core(L, K, height, width, border, min_length, max_keylines, vm, &tied, [&](int64_t n) -> LinetrLineRec* {
     n_sel = n;
     return n <= capacity ? h_recs : nullptr;
   });
+  if (tied) g_tied_images.push_back(0);
   if (n_sel > capacity) return fail(LINETR_E_CAPACITY, "prefilter: %lld lines exceed capacity %d", (long long)n_sel, capacity);
   int cur = sub_base, tcur = tok_base;
   for (int64_t i = 0; i < n_sel; ++i)
@@ -571,15 +580,18 @@ extern "C" int linetr_prefilter_batch(const double* L, const int32_t* off, int32
   cu_k[0] = cu_n[0] = 0;
   int cur = 0, tcur = 0;
   int64_t k = 0;
+  g_tied_images.clear();
   if (chunks == 1) {
     // a single pair / a few images: no hand-off, and the survivors are written where they stay
     for (int i = 0; i < B; ++i) {
       int64_t n_sel = -1;
+      bool tied = false;
       prefilter_core(L + (size_t)off[i] * 6, off[i + 1] - off[i], height, width, border, min_length, max_keylines,
-                     vms ? vms[i] : nullptr, [&](int64_t n) -> LinetrLineRec* {
+                     vms ? vms[i] : nullptr, &tied, [&](int64_t n) -> LinetrLineRec* {
                        n_sel = n;
                        return k + n <= capacity ? h_recs + k : nullptr;
                      });
+      if (tied) g_tied_images.push_back(i);
       if (k + n_sel > capacity) return fail(LINETR_E_CAPACITY, "prefilter_batch: more than %d surviving lines", capacity);
       for (int64_t j = 0; j < n_sel; ++j)
         if (int e = pack_one(h_recs[k + j], td, T, i, (int)j, cur, tcur)) return e;
@@ -590,16 +602,22 @@ extern "C" int linetr_prefilter_batch(const double* L, const int32_t* off, int32
     return LINETR_OK;
   }
   std::vector<std::vector<LinetrLineRec>> sel(B);
+  std::vector<char> tied_img(B, 0);
   auto work = [&](int c) {
     const int i0 = (int)((int64_t)B * c / chunks), i1 = (int)((int64_t)B * (c + 1) / chunks);
-    for (int i = i0; i < i1; ++i)
+    for (int i = i0; i < i1; ++i) {
+      bool tied = false;
       prefilter_core(L + (size_t)off[i] * 6, off[i + 1] - off[i], height, width, border, min_length, max_keylines,
-                     vms ? vms[i] : nullptr, [&](int64_t n) -> LinetrLineRec* {
+                     vms ? vms[i] : nullptr, &tied, [&](int64_t n) -> LinetrLineRec* {
                        sel[i].resize(n);
                        return sel[i].data();
                      });
+      tied_img[i] = tied;
+    }
   };
   pool.run(chunks, work);
+  for (int i = 0; i < B; ++i)
+    if (tied_img[i]) g_tied_images.push_back(i);
   for (int i = 0; i < B; ++i) {
     if (k + (int64_t)sel[i].size() > capacity)
       return fail(LINETR_E_CAPACITY, "prefilter_batch: more than %d surviving lines", capacity);
@@ -611,6 +629,12 @@ extern "C" int linetr_prefilter_batch(const double* L, const int32_t* off, int32
     cu_n[i + 1] = cur;
   }
   return LINETR_OK;
+}
+
+extern "C" int32_t linetr_prefilter_tied_images(int32_t* h_images, int32_t capacity) {
+  const int32_t n = (int32_t)g_tied_images.size();
+  for (int32_t i = 0; i < n && i < capacity && h_images; ++i) h_images[i] = g_tied_images[i];
+  return n;
 }
 
 // =============================================================================================

@@ -70,6 +70,30 @@ class TokenBatch:
         return t
 
 
+def repack_like_numpy(L, recs, cu_k, cu_n, i, rows, height, width, border, min_length, max_keylines, token_distance,
+                      max_tokens, valid_mask=None):
+    """Image i of a pre-filtered batch holds equal lengths: redo a1-a3 the way the per-image path does (NumPy's own argsort,
+    models/line_process.py:6-21) and overwrite the image's records in place.  Equal lengths mean equal token counts, so the
+    number of key-lines / sub-lines / tokens of the image -- and every later image's offsets -- stay as they are."""
+    from . import line_process as lp
+    vm = np.asarray(valid_mask, dtype=np.float64) if valid_mask is not None else None
+    kl = lp.filter_by_length(lp.remove_borders(lp.lines_from_rows(rows.copy()), border, height, width, vm), min_length,
+                             max_keylines)
+    k0, k1 = int(cu_k[i]), int(cu_k[i + 1])
+    if len(kl["klines"]) != k1 - k0:
+        raise RuntimeError(f"pre-filter: NumPy keeps {len(kl['klines'])} lines of image {i}, the native pass {k1 - k0}")
+    if k1 == k0:
+        return
+    n_out = C.c_int32()
+    tok = int(recs["first_tok"][k0])
+    n_tok = int(recs["n_tok"][k0:k1].sum())
+    a, b, c = (np.ascontiguousarray(kl[k], dtype=np.float64) for k in ("klines", "length_klines", "angles"))
+    nat.check(L.linetr_pack_lines(nat.np_ptr(a), nat.np_ptr(b), nat.np_ptr(c), k1 - k0, float(token_distance), int(max_tokens), i,
+                                  int(cu_n[i]), tok, nat.np_ptr(recs[k0:k1]), C.byref(n_out)), L)
+    if n_out.value != int(cu_n[i + 1] - cu_n[i]) or int(recs["n_tok"][k0:k1].sum()) != n_tok:
+        raise RuntimeError(f"pre-filter: re-ordering image {i} changed its sub-line / token count")
+
+
 class Engine:
     """One native model instance on one GPU."""
 
@@ -164,9 +188,17 @@ class Engine:
         return slot
 
     def prefilter(self, lines6, height, width, *, remove_borders, min_length, max_keylines, token_distance,
-                  max_tokens, valid_masks=None, offsets=None, n_threads=0):
+                  max_tokens, valid_masks=None, offsets=None, n_threads=0, tie_order="numpy"):
         """a1-a3 for a batch.  `lines6` is a list of [K_i,6] float64 arrays, or one concatenated [sum K,6] array
-        with `offsets` [B+1].  Returns (recs, cu_k, cu_n); recs lives in pinned memory ready for an async H2D."""
+        with `offsets` [B+1].  Returns (recs, cu_k, cu_n); recs lives in pinned memory ready for an async H2D.
+
+        tie_order: the length sort of models/line_process.py:15-16 is np.argsort, whose order among EQUAL lengths is NumPy's
+        business (unstable, CPU-dispatched).  "numpy" (default): the images the native pre-filter reports as holding equal
+        lengths (linetr_prefilter_tied_images; rare with a real detector) are re-ordered with NumPy itself and re-packed, so the
+        batched path gives the reference's rows on this machine, like the per-image path does.  "stable": keep the native order
+        (stable ascending argsort, reversed) -- machine-independent."""
+        if tie_order not in ("numpy", "stable"):
+            raise ValueError("tie_order must be 'numpy' or 'stable'")
         if offsets is None:
             lens = [len(l) for l in lines6]
             offsets = np.zeros(len(lens) + 1, dtype=np.int32)
@@ -199,6 +231,13 @@ class Engine:
                                                  int(remove_borders), float(min_length), int(max_keylines), vm_ptrs,
                                                  float(token_distance), int(max_tokens), int(n_threads),
                                                  nat.np_ptr(recs), cap, nat.np_ptr(cu_k), nat.np_ptr(cu_n)), self._L)
+        if tie_order == "numpy":
+            tied = np.empty(max(B, 1), dtype=np.int32)
+            n_tied = self._L.linetr_prefilter_tied_images(nat.np_ptr(tied), B)
+            for i in tied[:n_tied].tolist():
+                repack_like_numpy(self._L, recs, cu_k, cu_n, i, cat[offsets[i]:offsets[i + 1]], int(height), int(width),
+                                  remove_borders, min_length, max_keylines, token_distance, max_tokens,
+                                  valid_masks[i] if valid_masks is not None else None)
         K = int(cu_k[-1])
         out = recs[:K]
         self._last_host = {"slot": slot, "recs_ptr": recs.ctypes.data, "rec_bytes": rec_bytes, "B": B}

@@ -59,8 +59,14 @@ def change_cv2_T_np(klines_cv):
     """KeyLine objects -> {'klines' [K,2,2], 'length_klines' [K], 'angles' [K,2]} (float64; line_process.py:203-231)."""
     if len(klines_cv) == 0:
         return {"klines": np.zeros((0, 2, 2)), "length_klines": np.zeros((0,)), "angles": []}
-    raw = np.fromiter(itertools.chain.from_iterable(map(_KEYLINE_FIELDS, klines_cv)), dtype=np.float64,
-                      count=6 * len(klines_cv)).reshape(-1, 6)
+    return lines_from_rows(np.fromiter(itertools.chain.from_iterable(map(_KEYLINE_FIELDS, klines_cv)), dtype=np.float64,
+                                       count=6 * len(klines_cv)).reshape(-1, 6))
+
+
+def lines_from_rows(raw):
+    """change_cv2_T_np for detector lines that are already [K,6] rows (startX, startY, endX, endY, lineLength, octave)."""
+    if len(raw) == 0:
+        return {"klines": np.zeros((0, 2, 2)), "length_klines": np.zeros((0,)), "angles": []}
     keep_order = raw[:, 0] < raw[:, 2]
     sp = np.where(keep_order[:, None], raw[:, 0:2], raw[:, 2:4])
     ep = np.where(keep_order[:, None], raw[:, 2:4], raw[:, 0:2])

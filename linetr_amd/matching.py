@@ -160,8 +160,8 @@ class Matching(torch.nn.Module):
         LSD still run per image (out-of-scope front-ends); line tokenisation + description of ALL 2P images is ONE
         fused native call (linetr_prefilter_batch + linetr_describe) and the line matching of all P pairs is ONE
         linetr_match call.  Returns a list of P dicts with the keys forward() produces, except that the dense
-        per-token tensors (pnt/mask/desc/score_sublines) are not materialised.  Key-line order follows the native
-        pre-filter (ties in length: stable), everything else is identical to forward()."""
+        per-token tensors (pnt/mask/desc/score_sublines) are not materialised.  Key-line order is forward()'s: the native
+        pre-filter sorts, and images that hold equal lengths are ordered by NumPy's own argsort (Engine.prefilter, tie_order)."""
         from .line_process import keylines_to_array
         lt = self.linetransformer
         P = len(pairs)

@@ -312,26 +312,36 @@ def test_forward_batch_on_the_golden_pair():
 
 
 def test_prefilter_tie_order_native_vs_numpy():
-    """Equal-length lines: the batched native pre-filter orders ties stable-argsort-reversed (documented deviation,
-    DESIGN.md section 8); NumPy's argsort on this host may order them differently.  Either way the SET of key-lines and
-    every descriptor is the same -- only the row order of tied lines may differ -- and with all lengths distinct the two
-    paths agree row for row."""
+    """Equal-length lines: by default the batched pre-filter hands the images that hold ties to NumPy's own argsort
+    (Engine.prefilter tie_order="numpy"), so its rows are the per-image path's -- the reference's on this host -- row for row;
+    tie_order="stable" keeps the native, machine-independent order (stable argsort reversed), where only tied rows may sit
+    elsewhere.  The descriptors follow the rows."""
     from linetr_amd.engine import Engine
     from linetr_amd.line_transformer import change_cv2_T_np, filter_by_length, remove_borders
     eng = Engine(synth.calibrated_state_dict(), "cuda:0")
     rows = synth.synth_lines(77, 40, 480, 640)
-    rows[5, 4] = rows[9, 4] = rows[21, 4] = 20.0            # three lines of equal detector length (<= their geometric length)
-    recs, cu_k, cu_n = eng.prefilter([rows], 480, 640, remove_borders=8, min_length=16, max_keylines=-1,
-                                     token_distance=8, max_tokens=21)
+    rows[[5, 9, 21, 30, 31, 33], 4] = 20.0                  # six lines of equal detector length (<= their geometric length)
+    other = synth.synth_lines(78, 40, 480, 640)             # an image without ties in the same batch
+    kw = dict(remove_borders=8, min_length=16, max_keylines=-1, token_distance=8, max_tokens=21)
     kl = change_cv2_T_np(synth.array_to_keylines(rows))
     kl = filter_by_length(remove_borders(kl, 8, 480, 640, np.ones((480, 640))), 16, -1)
-    nat = np.stack([recs["sp"], recs["ep"]], axis=1)
-    assert nat.shape == kl["klines"].shape
+    recs, cu_k, cu_n = eng.prefilter([other, rows], 480, 640, **kw)
+    mine = recs[cu_k[1]:cu_k[2]]
+    assert np.array_equal(np.stack([mine["sp"], mine["ep"]], axis=1), kl["klines"])
+    assert np.array_equal(mine["length"], kl["length_klines"]) and np.array_equal(mine["angle"], kl["angles"])
+    stable, _, _ = eng.prefilter([other, rows], 480, 640, tie_order="stable", **kw)
+    nat = np.stack([stable["sp"], stable["ep"]], axis=1)[cu_k[1]:cu_k[2]]
     key = lambda a: sorted(map(tuple, a.reshape(len(a), -1).tolist()))
     assert key(nat) == key(kl["klines"])
-    assert np.array_equal(recs["length"], kl["length_klines"])           # lengths are sorted identically
     tied = np.isin(kl["length_klines"], [20.0])
     assert np.array_equal(nat[~tied], kl["klines"][~tied])
+    assert np.array_equal(stable[:cu_k[1]], recs[:cu_k[1]])                 # the tie-free image is the native pass's either way
+    # end to end: forward_batch rows == forward rows on the tied image
+    dd, ds = synth.synth_dense_maps(77, 480, 640)
+    do, so = synth.synth_dense_maps(78, 480, 640)
+    tb, ld = eng.describe_lines(np.concatenate([other, rows]), np.array([0, 40, 80], np.int32), torch.cat([do, dd]).cuda(),
+                                torch.cat([so, ds]).cuda(), **kw)
+    assert np.array_equal(tb.klines[tb.cu_k[1]:tb.cu_k[2]].cpu().numpy(), kl["klines"].astype(np.float32))
 
 
 def test_matching_wraps_the_host_superpoint(monkeypatch):

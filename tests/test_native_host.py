@@ -119,3 +119,48 @@ def test_pack_lines_matches_prefilter():
     assert n2.value == n
     for f in nat.REC_DTYPE.names:
         assert np.array_equal(out[f], recs[f]), f
+
+
+def test_equal_lengths_are_reported_and_reordered_like_numpy():
+    """Equal detector lengths: linetr_prefilter_tied_images names the images, and engine.repack_like_numpy gives them the
+    order (and, across the [:max_keylines] cut, the set) NumPy's argsort gives the reference on this host
+    (models/line_process.py:15-18); images without ties are untouched."""
+    from linetr_amd import engine, line_process as lp
+    L = nat.lib()
+    H, W, td, T = 480, 640, 8.0, 21
+    imgs = [synth.synth_lines(300 + i, 60, H, W) for i in range(6)]
+    for i, idx in ((1, (3, 11, 17, 40)), (4, (0, 59))):          # images 1 and 4: groups of equal lengths
+        imgs[i][list(idx), 4] = 18.0 + i
+    imgs[4][30:40, 4] = 25.0                                      # a larger group: unstable sorts scramble these
+    cat = np.ascontiguousarray(np.concatenate(imgs))
+    off = np.arange(7, dtype=np.int32) * 60
+    for max_k in (-1, 50):                                        # 50: image 4's group of ten straddles nothing, -1 drops the shortest
+        recs = np.zeros(len(cat), dtype=nat.REC_DTYPE)
+        cu_k, cu_n = np.zeros(7, np.int32), np.zeros(7, np.int32)
+        nat.check(L.linetr_prefilter_batch(nat.np_ptr(cat), nat.np_ptr(off), 6, H, W, 8, 16.0, max_k, None, td, T, 1,
+                                           nat.np_ptr(recs), len(recs), nat.np_ptr(cu_k), nat.np_ptr(cu_n)))
+        tied = np.full(6, -1, np.int32)
+        assert L.linetr_prefilter_tied_images(nat.np_ptr(tied), 6) == 2 and tied[:2].tolist() == [1, 4]
+        assert L.linetr_prefilter_tied_images(None, 0) == 2       # a query for the count alone
+        before = recs.copy()
+        for i in (1, 4):
+            engine.repack_like_numpy(L, recs, cu_k, cu_n, i, cat[off[i]:off[i + 1]], H, W, 8, 16.0, max_k, td, T)
+        for i in range(6):
+            want = lp.filter_by_length(lp.remove_borders(lp.lines_from_rows(imgs[i].copy()), 8, H, W, None), 16.0, max_k)
+            r = recs[cu_k[i]:cu_k[i + 1]]
+            assert np.array_equal(r["sp"], want["klines"][:, 0]) and np.array_equal(r["ep"], want["klines"][:, 1]), i
+            assert np.array_equal(r["length"], want["length_klines"])
+            assert np.array_equal(r["first_sub"], cu_n[i] + np.concatenate([[0], np.cumsum(r["n_sub"])[:-1]]))
+            assert (r["image"] == i).all() and np.array_equal(r["line_local"], np.arange(len(r)))
+            if i not in (1, 4):
+                assert np.array_equal(r, before[cu_k[i]:cu_k[i + 1]])
+        assert np.array_equal(recs["first_tok"][:cu_k[-1]], np.concatenate([[0], np.cumsum(recs["n_tok"][:cu_k[-1]])[:-1]]))
+    # a single image through linetr_prefilter: index 0; a tie-free call clears the report
+    k, n = C.c_int32(), C.c_int32()
+    one = np.zeros(60, dtype=nat.REC_DTYPE)
+    nat.check(L.linetr_prefilter(nat.np_ptr(np.ascontiguousarray(imgs[4])), 60, H, W, 8, 16.0, -1, None, td, T, 0, 0, 0,
+                                 nat.np_ptr(one), 60, C.byref(k), C.byref(n)))
+    assert L.linetr_prefilter_tied_images(nat.np_ptr(tied), 6) == 1 and tied[0] == 0
+    nat.check(L.linetr_prefilter(nat.np_ptr(np.ascontiguousarray(imgs[0])), 60, H, W, 8, 16.0, -1, None, td, T, 0, 0, 0,
+                                 nat.np_ptr(one), 60, C.byref(k), C.byref(n)))
+    assert L.linetr_prefilter_tied_images(nat.np_ptr(tied), 6) == 0
