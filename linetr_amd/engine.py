@@ -630,21 +630,39 @@ class Engine:
                                                         int(nhwc), out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), self._L)
         return out
 
-    def to_host(self, *tensors):
-        """Device tensors -> NumPy arrays with ONE stream synchronisation: every tensor is copied asynchronously into a cached
-        pinned staging buffer, then the stream is waited for once (`.cpu()` per tensor would synchronise per tensor)."""
+    def to_host_async(self, *tensors):
+        """Queues the device -> host copies of `tensors` into a pinned staging buffer on the current stream and returns a ticket for
+        collect().  Nothing is waited for: a result that is ready early (the point matcher's, queued before the line branch) travels
+        while the device works on what was queued behind it."""
         sizes = [t.numel() * t.element_size() for t in tensors]
-        offs = np.concatenate([[0], np.cumsum([(b + 255) // 256 * 256 for b in sizes])]).astype(np.int64)
-        stage = self.__dict__.get("_host_stage")
-        if stage is None or stage.numel() < int(offs[-1]):
-            stage = self._host_stage = torch.empty(int(offs[-1]) * 2 + 4096, dtype=torch.uint8, pin_memory=True)
+        offs = [0]
+        for b in sizes:
+            offs.append(offs[-1] + (b + 255) // 256 * 256)
+        ring = self.__dict__.setdefault("_host_ring", {"i": 0, "bufs": [None] * 4})
+        ring["i"] = (ring["i"] + 1) % len(ring["bufs"])
+        stage = ring["bufs"][ring["i"]]
+        if stage is None or stage.numel() < offs[-1]:
+            stage = ring["bufs"][ring["i"]] = torch.empty(offs[-1] * 2 + 4096, dtype=torch.uint8, pin_memory=True)
         views = []
         for t, o, b in zip(tensors, offs[:-1], sizes):
-            v = stage[int(o):int(o) + b].view(t.dtype).view(t.shape)
+            v = stage[o:o + b].view(t.dtype).view(t.shape)
             v.copy_(t.contiguous(), non_blocking=True)
             views.append(v)
-        torch.cuda.current_stream(self.device).synchronize()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return views, ev
+
+    @staticmethod
+    def collect(ticket):
+        """Waits for a to_host_async ticket and returns its tensors as NumPy arrays (copies: the staging buffer is reused)."""
+        views, ev = ticket
+        ev.synchronize()
         return [v.numpy().copy() for v in views]
+
+    def to_host(self, *tensors):
+        """Device tensors -> NumPy arrays with ONE synchronisation: every tensor is copied asynchronously into a pinned staging
+        buffer, then the copies are waited for once (`.cpu()` per tensor would synchronise per tensor)."""
+        return self.collect(self.to_host_async(*tensors))
 
     def match_points(self, desc0_cn: torch.Tensor, desc1_cn: torch.Tensor, thr, mutual=True):
         """nn_matcher on [256,n] descriptors; returns (dist [n0,n1] device, match01 [n0] device)."""

@@ -63,15 +63,18 @@ def change_cv2_T_np(klines_cv):
                                        count=6 * len(klines_cv)).reshape(-1, 6))
 
 
-def lines_from_rows(raw):
-    """change_cv2_T_np for detector lines that are already [K,6] rows (startX, startY, endX, endY, lineLength, octave)."""
+def lines_from_rows(raw, with_angles=True):
+    """change_cv2_T_np for detector lines that are already [K,6] rows (startX, startY, endX, endY, lineLength, octave).
+    with_angles=False leaves 'angles' empty ([K,0]) for callers that go on to filter_by_length, which recomputes them from the
+    clipped, filtered, ordered lines anyway (line_process.py:20)."""
     if len(raw) == 0:
         return {"klines": np.zeros((0, 2, 2)), "length_klines": np.zeros((0,)), "angles": []}
     keep_order = raw[:, 0] < raw[:, 2]
     sp = np.where(keep_order[:, None], raw[:, 0:2], raw[:, 2:4])
     ep = np.where(keep_order[:, None], raw[:, 2:4], raw[:, 0:2])
     klines = np.stack([sp, ep], axis=1)
-    return {"klines": klines, "length_klines": raw[:, 4] * np.exp2(raw[:, 5]), "angles": get_angles(klines)}
+    return {"klines": klines, "length_klines": raw[:, 4] * np.exp2(raw[:, 5]),
+            "angles": get_angles(klines) if with_angles else np.empty((len(klines), 0))}
 
 
 def keylines_to_array(klines_cv) -> np.ndarray:
@@ -128,17 +131,42 @@ def _token_engine(device):
     return eng
 
 
-def tokenize_into(klines, eng, token_distance, max_tokens, pred_superpoint):
+def prefilter_tokenize(klines_cv, height, width, border, min_length, max_sublines, token_distance, max_tokens, pred_superpoint,
+                       mask=None):
+    """change_cv2_T_np -> remove_borders -> filter_by_length -> line_tokenizer of ONE image (line_process.py:203-231, :59-84, :6-21,
+    :100-196) with a1-a3 on the native pre-filter: bit-identical to the NumPy functions above on klines / lengths / order (equal
+    lengths: NumPy's own argsort decides, Engine.prefilter tie_order), ~20 us instead of ~75.  The angles are NumPy's, computed on
+    the filtered lines as filter_by_length does (:20): libm's cos / sin may differ from NumPy's in the last ulp.  An ndarray mask
+    is honoured, anything else ignored (:76).  Returns the reference's dict (the NumPy functions' own, empty one when no line
+    survives)."""
+    if len(klines_cv) == 0:
+        return filter_by_length(remove_borders(change_cv2_T_np(klines_cv), border, height, width, mask), min_length, max_sublines)
+    dd = pred_superpoint.get("dense_descriptor_nhwc")
+    if dd is None:
+        dd = pred_superpoint["dense_descriptor"]
+    eng = _token_engine(dd.device)
+    vm = [mask] if isinstance(mask, np.ndarray) else None
+    recs, cu_k, cu_n = eng.prefilter([keylines_to_array(klines_cv)], height, width, remove_borders=border, min_length=min_length,
+                                     max_keylines=max_sublines, token_distance=token_distance, max_tokens=max_tokens, valid_masks=vm)
+    if cu_k[1] == 0:
+        return filter_by_length(remove_borders(change_cv2_T_np(klines_cv), border, height, width, mask), min_length, max_sublines)
+    recs["angle"] = get_angles(np.stack([recs["sp"], recs["ep"]], axis=1))
+    return tokenize_into({}, eng, token_distance, max_tokens, pred_superpoint, packed=(recs, int(cu_n[1])))
+
+
+def tokenize_into(klines, eng, token_distance, max_tokens, pred_superpoint, packed=None):
     """line_tokenizer body shared by the module-level function and LineTransformer.preprocess: fills the reference's dict
-    (line_process.py:182-196; 11 tensor entries with a leading batch axis of 1) from ONE native tokeniser call."""
-    K = len(klines["klines"])
+    (line_process.py:182-196; 11 tensor entries with a leading batch axis of 1) from ONE native tokeniser call.
+    `packed`: (records, number of sub-lines) when the lines are already packed (prefilter_tokenize); `klines` is then the empty
+    dict to fill."""
     ds = pred_superpoint["dense_score"]
     # a producer that also hands out the channel-last map (linetr_amd.superpoint.FusedHeadSuperPoint) saves the
     # NCHW -> NHWC pass; the reference's key is used otherwise
     layout = "nhwc" if pred_superpoint.get("dense_descriptor_nhwc") is not None else "nchw"
     dd = pred_superpoint["dense_descriptor_nhwc" if layout == "nhwc" else "dense_descriptor"]
     td, T = token_distance, max_tokens
-    recs, N = eng.pack(klines["klines"], klines["length_klines"], klines["angles"], td, T)
+    recs, N = packed if packed is not None else eng.pack(klines["klines"], klines["length_klines"], klines["angles"], td, T)
+    K = len(recs)
     align = int(torch.__version__[2]) > 2   # the reference's own version switch (line_process.py:93)
     tb = eng.tokenize(recs, np.array([0, K], np.int32), np.array([0, N], np.int32), dd, ds, token_distance=td,
                       max_tokens=T, align_corners=align, dense_layout=layout, want_mat=True)
@@ -176,13 +204,12 @@ def line_tokenizer(klines, token_distance, max_tokens, pred_superpoint, image_sh
 def preprocess(klines_cv, image_shape, pred_superpoint, mask=None, conf={}):
     """line_process.py:233-260 (the dataset builder's entry point; the model's own is LineTransformer.preprocess)."""
     conf = {"min_length": 16, "max_sublines": 256, "token_distance": 8, "max_tokens": 21, "remove_borders": 0, **conf}
-    klines = change_cv2_T_np(klines_cv)
     height, width = image_shape
-    klines = remove_borders(klines, conf["remove_borders"], height, width, mask)
-    klines = filter_by_length(klines, conf["min_length"], conf["max_sublines"])
-    if len(klines["klines"]) == 0:
-        return klines
-    return line_tokenizer(klines, conf["token_distance"], conf["max_tokens"], pred_superpoint, image_shape)
+    ds = pred_superpoint["dense_score"]
+    if (int(ds.shape[-2]), int(ds.shape[-1])) != (int(height), int(width)):
+        raise ValueError(f"preprocess: image_shape {tuple(image_shape)} does not match dense_score {tuple(ds.shape)}")
+    return prefilter_tokenize(klines_cv, height, width, conf["remove_borders"], conf["min_length"], conf["max_sublines"],
+                              conf["token_distance"], conf["max_tokens"], pred_superpoint, mask)
 
 
 def sample_descriptors(keypoints, descriptors, s: int = 8):

@@ -26,7 +26,7 @@ from .engine import Engine
 
 from .line_process import *  # noqa: F401,F403  (the reference's module does the same: models/line_transformer.py:6)
 from .line_process import (_token_engine, change_cv2_T_np, filter_by_length, get_angles, get_dist_matrix,  # noqa: F401
-                           remove_borders, tokenize_into)
+                           prefilter_tokenize, remove_borders, tokenize_into)
 
 __all__ = ["LineTransformer", "get_dist_matrix", "change_cv2_T_np", "remove_borders", "filter_by_length",
            "get_angles", "get_line_dist", "point_on_line", "sample_descriptors", "line_tokenizer", "preprocess"]
@@ -205,21 +205,12 @@ class LineTransformer(nn.Module):
     # -- reference surface ------------------------------------------------------------------------
     def preprocess(self, klines_cv, image_shape, pred_superpoint, valid_mask=None):
         """Line tokenisation.  Returns the reference's dict (11 tensor entries, leading batch axis 1)."""
-        klines = change_cv2_T_np(klines_cv)
         _, _, height, width = self.config["image_shape"] = image_shape
         # (the reference builds np.ones((height, width)) for a missing mask, :261-262; an all-ones mask keeps every line, so the
-        # 2.4 MB array is simply not made)
-        klines = remove_borders(klines, self.config["remove_borders"], height, width, valid_mask)
-        klines = filter_by_length(klines, self.config["min_length"], self.config["max_keylines"])
-        K = len(klines["klines"])
-        if K == 0:
-            return klines
-        dd = pred_superpoint.get("dense_descriptor_nhwc")
-        if dd is None:
-            dd = pred_superpoint["dense_descriptor"]
-        # the tokeniser needs no weights: the weight-less engine of line_process serves it (no weight-version check on this call)
-        return tokenize_into(klines, _token_engine(dd.device), self.config["token_distance"], self.config["max_tokens"],
-                             pred_superpoint)
+        # 2.4 MB array is simply not made.)  The tokeniser needs no weights: the weight-less engine of line_process serves it.
+        c = self.config
+        return prefilter_tokenize(klines_cv, height, width, c["remove_borders"], c["min_length"], c["max_keylines"],
+                                  c["token_distance"], c["max_tokens"], pred_superpoint, valid_mask)
 
     def forward(self, data):
         if len(data["klines"]) == 0:

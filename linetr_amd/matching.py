@@ -53,11 +53,11 @@ class Matching(torch.nn.Module):
     def _describe_fused(self, data, sp, sides, detected):
         """Both images of a pair through ONE fused native call (linetr_describe: tokeniser + descriptor network on the real tokens,
         every tensor of the reference's dict materialised, mat_klines2sublines from the same launch): 45 launches instead of 2 x 44,
-        and the pair's GEMMs see 398 rows instead of twice 199.  The NumPy glue -- and with it the reference's ordering of equal
-        lengths -- is untouched; descriptors equal the per-image path's to fp32 round-off (tests/test_gpu_dropin.py).
+        and the pair's GEMMs see 398 rows instead of twice 199.  Every tensor of the two dicts equals the per-image path's bit for bit
+        except the descriptors (fp32 round-off: other GEMM tiles for 398 rows; tests/test_gpu_dropin.py).
         Returns the two dicts (preprocess + forward of models/line_transformer.py:225-275), or None when the pair does not
         qualify (an image without lines, maps of different shapes or not on the device)."""
-        from .line_process import change_cv2_T_np, filter_by_length, remove_borders
+        from .line_process import get_angles, keylines_to_array
         lt = self.linetransformer
         imgs = [data["image" + s] for s in sides]
         shape = tuple(imgs[0].shape)
@@ -69,30 +69,35 @@ class Matching(torch.nn.Module):
         _, _, height, width = lt.config["image_shape"] = shape   # (LineTransformer.preprocess writes it too: line_transformer.py:258)
         c = lt.config
         td, T = c["token_distance"], c["max_tokens"]
-        lines = []
-        for s in sides:
-            kl = change_cv2_T_np(detected[s])
-            kl = filter_by_length(remove_borders(kl, c["remove_borders"], height, width, data["valid_mask" + s]), c["min_length"],
-                                  c["max_keylines"])
-            lines.append(kl)
-        if any(len(kl["klines"]) == 0 for kl in lines):
-            return None
+        # a1-a3 (change_cv2_T_np, remove_borders, filter_by_length: line_process.py:203-231, :59-84, :6-21) by the native pre-filter, which
+        # is bit-identical to the NumPy glue on klines / lengths / order (images that hold EQUAL lengths are re-ordered by NumPy's own
+        # argsort: Engine.prefilter, tie_order); the angles are NumPy's, computed per image as filter_by_length does (:20), because
+        # libm's cos / sin may differ from NumPy's in the last ulp
+        masks = [data["valid_mask" + s] if isinstance(data["valid_mask" + s], np.ndarray) else None for s in sides]
         eng = lt.engine(dds[0].device)
-        recs, cu_k, cu_n = eng.pack_many(lines, td, T)
+        recs, cu_k, cu_n = eng.prefilter([keylines_to_array(detected[s]) for s in sides], height, width,
+                                         remove_borders=c["remove_borders"], min_length=c["min_length"], max_keylines=c["max_keylines"],
+                                         token_distance=td, max_tokens=T, valid_masks=masks if any(m is not None for m in masks) else None)
+        if cu_k[1] == 0 or cu_k[2] == cu_k[1]:
+            return None
+        for i in range(2):
+            r = recs[cu_k[i]:cu_k[i + 1]]
+            r["angle"] = get_angles(np.stack([r["sp"], r["ep"]], axis=1))
         align = int(torch.__version__[2]) > 2                     # the reference's own version switch (line_process.py:93)
         tb, ld = eng.describe(recs, cu_k, cu_n, torch.cat(dds), torch.cat(dss), token_distance=td, max_tokens=T,
                               align_corners=align, want_tokens=True, dense_layout="nhwc" if nhwc else "nchw", want_mat=True)
         outs = []
-        for i in range(2):
-            k0, k1, n0, n1 = int(cu_k[i]), int(cu_k[i + 1]), int(cu_n[i]), int(cu_n[i + 1])
+        for i in range(2):      # one indexing call per entry (a torch view costs ~2 us of host time; there are 24 of them)
+            k = slice(int(cu_k[i]), int(cu_k[i + 1]))
+            n = slice(int(cu_n[i]), int(cu_n[i + 1]))
             mat = tb.mat_of(i)[None]
-            mat._linetr_sub2line = tb.sub2line[n0:n1]
-            outs.append({"klines": tb.klines[k0:k1][None], "length_klines": tb.length[k0:k1][None], "angles": tb.angles[k0:k1][None],
-                         "sublines": tb.sublines[n0:n1][None], "pnt_sublines": tb.pnt[n0:n1][None],
-                         "mask_sublines": tb.mask[n0:n1][None, :, :, None], "resp_sublines": tb.resp[n0:n1][None, :, None],
-                         "angle_sublines": tb.angle_sub[n0:n1][None], "desc_sublines": tb.desc[n0:n1][None],
-                         "score_sublines": tb.score[n0:n1][None, :, :, None], "mat_klines2sublines": mat,
-                         "line_desc": ld[n0:n1].t()[None]})
+            mat._linetr_sub2line = tb.sub2line[n]
+            outs.append({"klines": tb.klines[None, k], "length_klines": tb.length[None, k], "angles": tb.angles[None, k],
+                         "sublines": tb.sublines[None, n], "pnt_sublines": tb.pnt[None, n],
+                         "mask_sublines": tb.mask[None, n, :, None], "resp_sublines": tb.resp[None, n, None],
+                         "angle_sublines": tb.angle_sub[None, n], "desc_sublines": tb.desc[None, n],
+                         "score_sublines": tb.score[None, n, :, None], "mat_klines2sublines": mat,
+                         "line_desc": ld[None, n].transpose(1, 2)})
         return outs
 
     def forward(self, data):
@@ -102,6 +107,17 @@ class Matching(torch.nn.Module):
             if "keypoints" + s not in data:
                 sp[s] = self.superpoint({"image": data["image" + s]})
                 pred.update({k + s: v for k, v in sp[s].items()})
+        # The point matcher (models/nn_matcher.py:33-42) needs nothing but SuperPoint's descriptors: it is queued now and runs on the
+        # device underneath the host glue of the line branch; its results come to the host with the line matcher's, at the end.
+        from .line_process import _token_engine
+        d0, d1 = ((sp[s]["descriptors"] if s in sp else data["descriptors" + s])[0].detach() for s in ("0", "1"))
+        on_dev = d0.is_cuda and d0.dim() == 2 and d0.shape[0] == 256 and d0.shape[1] > 0 and d1.shape[1] > 0
+        thr_p = self.superpoint.config["nn_threshold"]
+        points_q = None
+        if on_dev:
+            eng_m = _token_engine(d0.device)                      # the matchers need no weights (and no weight-version check)
+            dist, m01 = eng_m.match_points(d0, d1, float(np.float32(thr_p)), True)
+            points_q = eng_m.to_host_async(m01, dist)             # the 1 MB distance matrix travels while the line branch runs
         # detect + tokenise + describe the images that need it (matching.py:34-41, :52-59)
         sides = [s for s in ("0", "1") if "klines" + s not in data]
         for s in sides:
@@ -119,33 +135,26 @@ class Matching(torch.nn.Module):
             outs = lt.forward_many(pres)
         for s, out in zip(sides, outs):
             pred.update({k + s: v for k, v in out.items()})
-        data = {**data, **pred}
-        for k in data:
-            if isinstance(data[k], (list, tuple)):
-                data[k] = torch.stack(data[k])
+        data = {**data, **pred}    # (the reference also stacks list entries of this local dict, matching.py:62-64: nothing below reads one)
 
-        # point matches (models/nn_matcher.py:33-42) and line matches (D -> key-line pooling -> mutual NN, matching.py:77-84): both are
-        # queued on the device first, then ONE synchronisation brings the four result arrays to the host
-        from .line_process import _token_engine
-        d0, d1 = data["descriptors0"][0].detach(), data["descriptors1"][0].detach()
+        # line matches (D -> key-line pooling -> mutual NN, matching.py:77-84) are queued behind the descriptors; then ONE
+        # synchronisation brings the four result arrays of both matchers to the host
         thr_l = self.linetransformer.config["nn_threshold"]
         line_args = (data["line_desc0"], data["mat_klines2sublines0"], data["line_desc1"], data["mat_klines2sublines1"], thr_l)
-        on_dev = d0.is_cuda and d0.shape[0] == 256 and d0.shape[1] > 0 and d1.shape[1] > 0
         lines_q = self._queue_line_match(*line_args) if on_dev else None
         if on_dev and lines_q is not None:
-            eng = _token_engine(d0.device)                        # the matchers need no weights (and no weight-version check)
-            dist, m01 = eng.match_points(d0, d1, float(np.float32(self.superpoint.config["nn_threshold"])), True)
             dk, m01_l, K0, K1 = lines_q
-            m01_h, dist_h, m01_lh, dk_h = eng.to_host(m01, dist, m01_l, dk)
+            lines_t = eng_m.to_host_async(m01_l, dk)
+            m01_h, dist_h = eng_m.collect(points_q)               # ready long ago: copied out while the line matcher runs
+            m01_lh, dk_h = eng_m.collect(lines_t)
             m_p, d_p = match01_to_matrix(m01_h, int(d1.shape[1])), dist_h[None]
             m_l, d_l = match01_to_matrix(m01_lh, K1), dk_h.reshape(1, K0, K1)
         else:   # empty sets / host tensors: the NumPy-in, NumPy-out surface functions, one after the other
             if on_dev:
-                dist, m01 = _token_engine(d0.device).match_points(d0, d1, float(np.float32(self.superpoint.config["nn_threshold"])), True)
-                m01_h, dist_h = _token_engine(d0.device).to_host(m01, dist)
+                m01_h, dist_h = eng_m.collect(points_q)
                 m_p, d_p = match01_to_matrix(m01_h, int(d1.shape[1])), dist_h[None]
             else:
-                m_p, d_p = nn_matcher(d0.cpu().numpy(), d1.cpu().numpy(), self.superpoint.config["nn_threshold"], is_mutual_NN=True)
+                m_p, d_p = nn_matcher(d0.cpu().numpy(), d1.cpu().numpy(), thr_p, is_mutual_NN=True)
             m_l, d_l = self.match_lines(*line_args)
         pred["matches_p"] = torch.from_numpy(m_p)
         pred["matching_scores_p"] = torch.from_numpy(d_p)

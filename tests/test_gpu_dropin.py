@@ -448,6 +448,21 @@ def test_matching_forward_fused_pair_equals_the_per_image_path(monkeypatch):
             assert torch.equal(a.cpu(), b.cpu()), k
     assert np.array_equal(fused["matches_l"].numpy(), g["pair_M"])
     assert hasattr(fused["mat_klines2sublines0"], "_linetr_sub2line")
+    # equal detector lengths (NumPy's argsort decides the rows) and an ndarray valid mask (honoured, line_process.py:76-80): the fused
+    # call -- native pre-filter, NumPy only for the tied image and the angles -- still returns the per-image path's tensors
+    a_tied = g["a_lines"].copy()
+    a_tied[[3, 17, 40, 41, 90, 150], 4] = 21.0
+    vm = np.ones((480, 640))
+    vm[:, :150] = 0
+    monkeypatch.setattr(Matching, "_describe_fused", orig)
+    f2 = build([a_tied, g["b_lines"]])({"image0": img, "image1": img.clone(), "valid_mask0": vm})
+    monkeypatch.setattr(Matching, "_describe_fused", lambda self, *a: None)
+    p2 = build([a_tied, g["b_lines"]])({"image0": img, "image1": img.clone(), "valid_mask0": vm})
+    assert 0 < f2["klines0"].shape[1] < 199
+    for k in p2:
+        if torch.is_tensor(p2[k]) and not k.startswith("line_desc") and k != "matching_scores_l":
+            assert torch.equal(f2[k].cpu(), p2[k].cpu()), k
+    assert (f2["line_desc0"] - p2["line_desc0"]).abs().max().item() < 5e-6
     # one image without a single usable line: the per-image path takes over, the detector is asked once per image
     monkeypatch.setattr(Matching, "_describe_fused", orig)
     short = np.array([[100.0, 100.0, 105.0, 100.0, 5.0, 0.0]])
