@@ -90,8 +90,16 @@ def test_module_built_under_inference_mode_and_rebound_weights():
     assert torch.equal(m2(pre2)["line_desc"], ref)
     p = m2.final_proj.weight
     p.data = -p.data.clone()                       # new storage, version counter untouched
-    flipped = m2(pre2)["line_desc"]
+    flipped = m2(pre2)["line_desc"].clone()
     assert not torch.allclose(flipped, ref, atol=1e-3)
+    with torch.no_grad():
+        m2.final_proj.weight.mul_(-1.0)            # in place: same storage, version counter bumped
+    assert torch.equal(m2(pre2)["line_desc"], ref)
+    m2.final_proj.weight = torch.nn.Parameter(-m2.final_proj.weight.detach().clone())   # a replaced Parameter object
+    assert torch.equal(m2(pre2)["line_desc"], flipped)
+    eng = m2._engine
+    m2(pre2)
+    assert m2._engine is eng                       # nothing changed: the engine is kept
 
 
 class FakeSuperPoint(torch.nn.Module):

@@ -20,7 +20,7 @@ def wrap(owner, name, label=None):
             acc[lab] += time.perf_counter() - t0
     setattr(owner, name, g)
 
-for n in ("describe", "pack_many", "match", "match_points", "to_host", "_upload_recs"):
+for n in ("describe", "prefilter", "pack_many", "match", "match_points", "to_host_async", "_upload_recs"):
     wrap(E.Engine, n, "Engine." + n)
 for n in ("lines_from_rows", "keylines_to_array", "remove_borders", "filter_by_length", "get_angles"):
     wrap(LP, n)
@@ -29,6 +29,11 @@ wrap(M.Matching, "_describe_fused", "Matching._describe_fused")
 wrap(M.Matching, "_queue_line_match", "Matching._queue_line_match")
 wrap(LT.LineTransformer, "engine", "LineTransformer.engine (weight-version check)")
 wrap(torch, "ones_like", "torch.ones_like (valid_mask)")
+wrap(torch, "cat", "torch.cat (the two dense maps side by side)")
+wrap(torch, "empty", "torch.empty")
+from linetr_amd import _native as nat
+for n in ("linetr_describe", "linetr_prefilter_batch", "linetr_match", "linetr_match_points"):
+    wrap(nat.lib(), n, "native " + n)
 
 dev = torch.device("cuda:0")
 eng = E.Engine(synth.calibrated_state_dict(), dev)
