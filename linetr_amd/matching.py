@@ -211,29 +211,45 @@ class Matching(torch.nn.Module):
         cs = lambda v: np.concatenate([[0], np.cumsum(v)]).astype(np.int32)
         dk, off_dk, m01 = eng.match(ld[idx0], cs(n[0::2]), tb.sub2line[idx0], cs(k[0::2]), ld[idx1], cs(n[1::2]),
                                     tb.sub2line[idx1], cs(k[1::2]), float(np.float32(c["nn_threshold"])), True)
-        dk_h, m01_h = dk.cpu().numpy(), m01.cpu().numpy()
+        # point matcher of every pair queued behind the line matcher; ONE synchronisation brings everything to the host
+        descs = []
+        for sp in sp_out:
+            v = sp["descriptors"]
+            descs.append((torch.stack(list(v)) if isinstance(v, (list, tuple)) else v)[0].detach())
+        thr_p = self.superpoint.config["nn_threshold"]
+        pts_on_dev = all(d.is_cuda and d.dim() == 2 and d.shape[0] == 256 and d.shape[1] > 0 for d in descs)
+        pts = [eng.match_points(descs[2 * p], descs[2 * p + 1], float(np.float32(thr_p)), True) for p in range(P)] if pts_on_dev else []
+        host = eng.to_host(dk, m01, *[t for dist, mp in pts for t in (mp, dist)])
+        dk_h, m01_h = host[0], host[1]
         ck0 = cs(k[0::2])
+        # mat_klines2sublines of all 2P images in one buffer (line_process.py:168-180: row = key-line, 1 / num_sublines at its
+        # sub-lines; the float64 quotient rounded to float32): indices from the host records, one scatter on the device
+        recs = tb.recs
+        K_all, N_all = int(cu_k[-1]), int(cu_n[-1])
+        blk = np.concatenate([[0], np.cumsum(k.astype(np.int64) * n.astype(np.int64))])
+        A_flat = torch.zeros((int(blk[-1]),), device=dev)
+        if N_all:
+            rec_of_sub = np.repeat(np.arange(K_all), recs["n_sub"][:K_all])
+            img_s = recs["image"][:K_all][rec_of_sub].astype(np.int64)
+            flat = blk[img_s] + recs["line_local"][:K_all][rec_of_sub].astype(np.int64) * n[img_s] + (np.arange(N_all) - cu_n[img_s])
+            vals = (1.0 / recs["n_sub"][:K_all][rec_of_sub].astype(np.float64)).astype(np.float32)
+            A_flat[torch.from_numpy(flat).to(dev)] = torch.from_numpy(vals).to(dev)
         preds = []
         for p in range(P):
             pred = {}
             for s, img_i in (("0", 2 * p), ("1", 2 * p + 1)):
                 pred.update({key + s: v for key, v in sp_out[img_i].items()})
-                k0, k1, n0, n1 = cu_k[img_i], cu_k[img_i + 1], cu_n[img_i], cu_n[img_i + 1]
-                K, N = int(k1 - k0), int(n1 - n0)
-                s2l = tb.sub2line[n0:n1].long()
-                A = torch.zeros((K, N), device=dev)
-                if N:
-                    cnt = torch.bincount(s2l, minlength=K).clamp(min=1)
-                    A[s2l, torch.arange(N, device=dev)] = (1.0 / cnt.double())[s2l].float()
-                pred.update({"klines" + s: tb.klines[k0:k1][None], "length_klines" + s: tb.length[k0:k1][None],
-                             "angles" + s: tb.angles[k0:k1][None], "sublines" + s: tb.sublines[n0:n1][None],
-                             "resp_sublines" + s: tb.resp[n0:n1][None, :, None],
-                             "angle_sublines" + s: tb.angle_sub[n0:n1][None],
-                             "line_desc" + s: ld[n0:n1].t()[None], "mat_klines2sublines" + s: A[None]})
-            desc0 = torch.stack(list(pred["descriptors0"]))[0] if isinstance(pred["descriptors0"], (list, tuple)) else pred["descriptors0"][0]
-            desc1 = torch.stack(list(pred["descriptors1"]))[0] if isinstance(pred["descriptors1"], (list, tuple)) else pred["descriptors1"][0]
-            m_p, d_p = nn_matcher(desc0.detach().cpu().numpy(), desc1.detach().cpu().numpy(),
-                                  self.superpoint.config["nn_threshold"], is_mutual_NN=True)
+                kk, nn = slice(int(cu_k[img_i]), int(cu_k[img_i + 1])), slice(int(cu_n[img_i]), int(cu_n[img_i + 1]))
+                A = A_flat[int(blk[img_i]):int(blk[img_i + 1])].view(int(k[img_i]), int(n[img_i]))[None]
+                A._linetr_sub2line = tb.sub2line[nn]
+                pred.update({"klines" + s: tb.klines[None, kk], "length_klines" + s: tb.length[None, kk],
+                             "angles" + s: tb.angles[None, kk], "sublines" + s: tb.sublines[None, nn],
+                             "resp_sublines" + s: tb.resp[None, nn, None], "angle_sublines" + s: tb.angle_sub[None, nn],
+                             "line_desc" + s: ld[None, nn].transpose(1, 2), "mat_klines2sublines" + s: A})
+            if pts_on_dev:
+                m_p, d_p = match01_to_matrix(host[2 + 2 * p], int(descs[2 * p + 1].shape[1])), host[3 + 2 * p][None]
+            else:
+                m_p, d_p = nn_matcher(descs[2 * p].cpu().numpy(), descs[2 * p + 1].cpu().numpy(), thr_p, is_mutual_NN=True)
             pred["matches_p"], pred["matching_scores_p"] = torch.from_numpy(m_p), torch.from_numpy(d_p)
             K0, K1 = int(k[2 * p]), int(k[2 * p + 1])
             pred["matches_l"] = torch.from_numpy(match01_to_matrix(m01_h[ck0[p]:ck0[p] + K0], K1))
