@@ -188,6 +188,13 @@ class LineTransformer(nn.Module):
         return new
 
     def engine(self, device=None) -> Engine:
+        if self.training:
+            # train.py:127 puts the reference in train mode: BatchNorm batch statistics, dropout, autograd (out
+            # of scope).  The native network folds BatchNorm(eval) into the convolutions -- running it for a module in train mode
+            # would silently return validation-mode descriptors without gradients.
+            raise RuntimeError("linetr_amd.LineTransformer is in train mode: this build provides the inference forward only "
+                               "(BatchNorm running statistics, no dropout, no autograd).  Call .eval() -- the reference's scripts "
+                               "and its validation loop do (match_line_pairs.py:75, demo_LineTR.py:154, train.py:133)")
         dev = torch.device(device) if device is not None else self._device()
         if dev.type != "cuda":
             raise RuntimeError("LineTransformer (linetr_amd) runs on a HIP device only: move the module with "

@@ -55,6 +55,9 @@ def test_no_cpu_fallback():
             "resp_sublines": torch.zeros(1, 3, 1), "angle_sublines": torch.zeros(1, 3, 2),
             "desc_sublines": torch.zeros(1, 3, 21, 256), "score_sublines": torch.zeros(1, 3, 21, 1),
             "mask_sublines": torch.ones(1, 3, 22, 1)}
+    with pytest.raises(RuntimeError, match="train mode"):      # a module left in train mode (train.py:127) is refused, not silently
+        m(data)                                                # run with BatchNorm(eval) and without dropout
+    m.eval()
     with pytest.raises(RuntimeError, match="HIP device"):
         m(data)
     from linetr_amd.nn_matcher import nn_matcher_distmat
