@@ -468,12 +468,15 @@ def sub_workload(eng, name, device, settle_s, repeat=1, brief=False):
         out["inputs"] = f"the {pairs // repeat}-pair set repeated {repeat}x"
     if not brief:        # argmin margins of this workload's own matches
         margs = pipe.match_args(tb, ld)
-        dk, off_dk, m01, _ok0 = eng.match_offsets(*margs, LINE_CFG["nn_threshold"], True)
+        dk, off_dk, m01, off_k0 = eng.match_offsets(*margs, LINE_CFG["nn_threshold"], True)
         out["argmin"] = argmin_margins(dk, off_dk, margs[2])
         out["matches_per_step"] = int((m01 >= 0).sum().item())
+        if repeat == 1:     # the workload's own descriptors and matches against the CPU oracle (cfg2: 1 pair, cfg5: 8 pairs)
+            out["oracle_check"] = oracle_check(lines, lambda i: nhwc[i].permute(2, 0, 1)[None].contiguous().cpu(), ds, hw,
+                                               tuple(eng.cfg["image_shape"][-2:]), T, ld, tb,
+                                               m01, dk, off_dk, off_k0, pairs)
     if pairs == 1:      # single pair: strict latency (submit, wait, repeat) of describe and of describe + match
         margs = pipe.match_args(tb, ld)
-        out["oracle_check"] = oracle_check_pair(lines, dd_nchw, ds, hw, T, ld, tb, m01, dk)
         lat, lat_m = [], []
         for _ in range(5):
             pipe.describe(); eng.match_offsets(*margs, LINE_CFG["nn_threshold"], True)
@@ -537,26 +540,39 @@ def argmin_margins(dk, off_dk, dims):
             "argmins_checked": n}
 
 
-def oracle_check_pair(lines, dd_nchw, ds, hw, T, ld, tb, m01, dk):
-    """cfg2 only, outside every timed region: the pair's descriptors and line matches against the CPU oracle on the same
-    inputs (the oracle is the checker here, never the thing measured)."""
+def oracle_check(lines, dense_nchw_of, ds, hw, norm_hw, T, ld, tb, m01, dk, off_dk, off_k0, pairs):
+    """Outside every timed region (cfg2: the pair; cfg5: its 8 pairs, where the argmin margins are smallest): descriptors and
+    line matches of the workload's own inputs against the CPU oracle (the oracle is the checker here, never the thing
+    measured).  dense_nchw_of(i) -> image i's [1,256,H/8,W/8] map on the CPU.  norm_hw: the shape the ENGINE normalises key-line
+    coordinates with -- the constructor-time config['image_shape'], not the image's (models/line_transformer.py:206, :238)."""
     from oracle import linetr_oracle as O
     sd = synth.to_torch_state_dict(synth.calibrated_state_dict())
     cfg = dict(LINE_CFG, max_tokens=T)
-    outs = []
-    with torch.no_grad():
-        for i in range(2):
-            o = O.preprocess(synth.array_to_keylines(lines[i]), (1, 1, *hw), dd_nchw[i:i + 1].cpu(), ds[i:i + 1].cpu(), cfg)
-            outs.append(O.forward(sd, o, hw))
-        M, Dk = O.match_lines(outs[0]["line_desc"], outs[1]["line_desc"], outs[0]["mat_klines2sublines"][0],
-                              outs[1]["mat_klines2sublines"][0], LINE_CFG["nn_threshold"])
-    ld_c, cu = ld.cpu().numpy(), tb.cu_n
-    err = max(float(np.abs(ld_c[cu[i]:cu[i + 1]].T - outs[i]["line_desc"][0].numpy()).max()) for i in range(2))
-    got = np.zeros_like(M[0])
-    m = m01.cpu().numpy()
-    got[np.nonzero(m >= 0)[0], m[m >= 0]] = 1
-    return {"matches_identical_to_oracle": bool(np.array_equal(got, M[0])), "matches": int(got.sum()),
-            "max_abs_desc_err_vs_oracle": err, "max_abs_dk_err_vs_oracle": float(np.abs(dk.cpu().numpy().reshape(Dk[0].shape) - Dk[0]).max())}
+    ld_c, cu, m_all, dk_all = ld.cpu().numpy(), tb.cu_n, m01.cpu().numpy(), dk.cpu().numpy()
+    err = err_dk = 0.0
+    differing = n_match = 0
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(8, nt))          # the oracle's small GEMMs run slower on 128 threads than on 8
+    try:
+        with torch.no_grad():
+            for p in range(pairs):
+                outs = []
+                for i in (2 * p, 2 * p + 1):
+                    o = O.preprocess(synth.array_to_keylines(lines[i]), (1, 1, *hw), dense_nchw_of(i), ds[i:i + 1].cpu(), cfg)
+                    outs.append(O.forward(sd, o, norm_hw))
+                    err = max(err, float(np.abs(ld_c[cu[i]:cu[i + 1]].T - outs[-1]["line_desc"][0].numpy()).max()))
+                M, Dk = O.match_lines(outs[0]["line_desc"], outs[1]["line_desc"], outs[0]["mat_klines2sublines"][0],
+                                      outs[1]["mat_klines2sublines"][0], LINE_CFG["nn_threshold"])
+                got = np.zeros_like(M[0])
+                m = m_all[int(off_k0[p]):int(off_k0[p + 1])]
+                got[np.nonzero(m >= 0)[0], m[m >= 0]] = 1
+                differing += int(not np.array_equal(got, M[0]))
+                n_match += int(got.sum())
+                err_dk = max(err_dk, float(np.abs(dk_all[int(off_dk[p]):int(off_dk[p + 1])].reshape(Dk[0].shape) - Dk[0]).max()))
+    finally:
+        torch.set_num_threads(nt)
+    return {"pairs_checked": pairs, "matches_identical_to_oracle": differing == 0, "pairs_with_a_differing_match_matrix": differing,
+            "matches": n_match, "max_abs_desc_err_vs_oracle": err, "max_abs_dk_err_vs_oracle": err_dk}
 
 
 class _StubSuperPoint(torch.nn.Module):

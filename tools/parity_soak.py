@@ -1,6 +1,6 @@
 """Descriptor / match parity soak: P random pairs (random line counts, seeds, both dense layouts) described as ONE batch on the GPU and
 matched, against the CPU oracle pair by pair: max |descriptor - oracle|, line matches identical by index, smallest argmin margin.
-    python tools/parity_soak.py [pairs]      (on the GPU box)"""
+    python tools/parity_soak.py [pairs] [cfg3|cfg5]      (on the GPU box; cfg5 = the long-line workload's shape: 1280 x 960, 300-600 lines of 40-327 px, 41 tokens)"""
 import os
 import sys
 import time
@@ -17,23 +17,24 @@ from workloads import synth  # noqa: E402
 
 def main():
     P = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    big = len(sys.argv) > 2 and sys.argv[2] == "cfg5"
     torch.set_grad_enabled(False)
     torch.set_num_threads(8)
-    hw = (480, 640)
-    cfg = dict(min_length=16, token_distance=8, max_tokens=21, remove_borders=8, max_keylines=-1)
+    hw = (960, 1280) if big else (480, 640)
+    cfg = dict(min_length=16, token_distance=8, max_tokens=41 if big else 21, remove_borders=8, max_keylines=-1)
     sdn = synth.calibrated_state_dict()
     sd = synth.to_torch_state_dict(sdn)
-    eng = Engine(sdn, "cuda:0")
+    eng = Engine(sdn, "cuda:0", image_shape=list(hw))
     rs = np.random.RandomState(2026)
     lines, maps = [], []
     for i in range(2 * P):
         seed = 70000 + i
-        lines.append(synth.synth_lines(seed, int(rs.randint(12, 320)), *hw))
+        lines.append(synth.synth_lines(seed, int(rs.randint(300, 601)), *hw, 40.0, 327.0) if big else synth.synth_lines(seed, int(rs.randint(12, 320)), *hw))
         maps.append(synth.synth_dense_maps(seed, *hw))
     dd = torch.cat([m[0] for m in maps]).cuda()
     ds = torch.cat([m[1] for m in maps]).cuda()
     off = np.concatenate([[0], np.cumsum([len(l) for l in lines])]).astype(np.int32)
-    kw = dict(remove_borders=8, min_length=16, max_keylines=-1, token_distance=8, max_tokens=21)
+    kw = dict(remove_borders=8, min_length=cfg["min_length"], max_keylines=-1, token_distance=cfg["token_distance"], max_tokens=cfg["max_tokens"])
     tb, ld = eng.describe_lines(np.concatenate(lines), off, dd, ds, **kw)
     tb2, ld2 = eng.describe_lines(np.concatenate(lines), off, dd.permute(0, 2, 3, 1).contiguous(), ds, dense_layout="nhwc", **kw)
     n, k = np.diff(tb.cu_n), np.diff(tb.cu_k)
