@@ -1013,6 +1013,11 @@ def main():
     pair_match_ms = (time.perf_counter() - t0) / reps / pairs * 1e3
     n_matches = int((m01 >= 0).sum().item())
     argmin = argmin_margins(dk, off_dk, margs[2])
+    # the step's own descriptors and line matches against the CPU oracle on the same inputs (outside every timed region; N = 1 only,
+    # skipped together with the CPU baseline): "line matches bit-exact by index" on the benchmark's input, not only on fixtures
+    oracle_chk = None
+    if world == 1 and not args.no_cpu_baseline:
+        oracle_chk = oracle_check(lines, lambda i: dd_nchw[i:i + 1].cpu(), ds, hw, (H, W), T, ld, tb, m01, dk, off_dk, _ok0, pairs)
     # ... and for ONE pair at a time (latency of get_dist_matrix + subline2keyline + nn_matcher_distmat)
     one_args = (margs[0], margs[1], margs[2][:1], margs[3][:1], margs[4][:1], margs[5][:1], margs[6][:1])
     for _ in range(3):
@@ -1070,7 +1075,7 @@ def main():
         "collective_backend": (None if world == 1 else os.environ.get("LINETR_BENCH_BACKEND", "nccl")),
         "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and hasattr(torch.cuda, "nccl") else None),
         "pair_match_ms": round(pair_match_ms, 4), "pair_match_latency_ms": round(pair_match_latency_ms, 4),
-        "matches_per_step": n_matches, "argmin": argmin,
+        "matches_per_step": n_matches, "argmin": argmin, "oracle_check": oracle_chk,
         "whole_step": {**whole_step_executed(prof, prof_steps, ms_per_step),
                        "survey_algorithmic_gflop_per_step": round(alg_flops_step / 1e9, 1),
                        "survey_note": "SURVEY 8(d)'s formula counts the reference's graph; exact algebra (K-projection fold, "
