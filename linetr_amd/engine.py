@@ -646,11 +646,12 @@ class Engine:
         offs = [0]
         for b in sizes:
             offs.append(offs[-1] + (b + 255) // 256 * 256)
-        ring = self.__dict__.setdefault("_host_ring", {"i": 0, "bufs": [None] * 4})
-        ring["i"] = (ring["i"] + 1) % len(ring["bufs"])
-        stage = ring["bufs"][ring["i"]]
+        ring = self.__dict__.setdefault("_host_ring", {"i": 0, "bufs": [None] * 4, "gen": [0] * 4})
+        i = ring["i"] = (ring["i"] + 1) % len(ring["bufs"])
+        ring["gen"][i] += 1                       # a ticket on this slot that was never collected is stale from here on
+        stage = ring["bufs"][i]
         if stage is None or stage.numel() < offs[-1]:
-            stage = ring["bufs"][ring["i"]] = torch.empty(offs[-1] * 2 + 4096, dtype=torch.uint8, pin_memory=True)
+            stage = ring["bufs"][i] = torch.empty(offs[-1] * 2 + 4096, dtype=torch.uint8, pin_memory=True)
         views = []
         for t, o, b in zip(tensors, offs[:-1], sizes):
             v = stage[o:o + b].view(t.dtype).view(t.shape)
@@ -658,13 +659,18 @@ class Engine:
             views.append(v)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        return views, ev
+        return views, ev, ring["gen"], i, ring["gen"][i]
 
     @staticmethod
     def collect(ticket):
-        """Waits for a to_host_async ticket and returns its tensors as NumPy arrays (copies: the staging buffer is reused)."""
-        views, ev = ticket
+        """Waits for a to_host_async ticket and returns its tensors as NumPy arrays (copies: the staging buffer is reused).
+        At most three younger tickets may be taken before a ticket is collected (a ring of four staging buffers): a ticket whose
+        buffer has been handed out again raises instead of returning another call's data."""
+        views, ev, gens, i, gen = ticket
         ev.synchronize()
+        if gens[i] != gen:
+            raise RuntimeError("to_host_async ticket collected too late: its staging buffer has been reused (collect within three "
+                               "younger tickets)")
         return [v.numpy().copy() for v in views]
 
     def to_host(self, *tensors):

@@ -247,3 +247,23 @@ def test_matcher_fuzz_ties_and_threshold_edges():
         got = NM.nn_matcher_distmat(d, thr, mutual)
         want = O.mutual_nn(d, thr, mutual)
         assert got.dtype == np.float64 and np.array_equal(got, want), (case, n0, n1, mutual)
+
+
+def test_async_host_tickets_deliver_their_own_data_and_refuse_stale_ones():
+    """Engine.to_host_async / collect (the drop-in path's result transport): tickets collected out of order give their own
+    tensors; one whose staging buffer has been handed out again raises instead of returning another call's data."""
+    from linetr_amd.engine import Engine
+    eng = Engine.heads_only("cuda:0")
+    ts = [torch.full((257, 3), float(i), device="cuda") for i in range(4)]
+    idx = [torch.arange(5, device="cuda", dtype=torch.int32) + i for i in range(4)]
+    tickets = [eng.to_host_async(ts[i], idx[i]) for i in range(4)]
+    for i in (2, 0, 3, 1):
+        a, b = eng.collect(tickets[i])
+        assert a.dtype == np.float32 and (a == i).all() and np.array_equal(b, np.arange(5) + i)
+    old = eng.to_host_async(ts[0])
+    for _ in range(4):
+        eng.to_host_async(ts[1])
+    with pytest.raises(RuntimeError, match="staging buffer has been reused"):
+        eng.collect(old)
+    (h,) = eng.to_host(ts[3])
+    assert (h == 3).all()
