@@ -289,6 +289,7 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
 
   // ---- signature layers --------------------------------------------------------------------------
   H->sig.resize(cfg->n_sig_layers);
+  std::vector<std::vector<double>> sig_qkv_d, sig_bqkv_d, sig_w2_d, sig_b2_d;   // kept for the W2 + next-projection fold below
   for (int l = 0; l < cfg->n_sig_layers; ++l) {
     const std::string p = "selfattn.layers." + std::to_string(l) + ".";
     const float* Wp[3];
@@ -341,6 +342,8 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
       b1f[o] = bacc;
     }
     SigLayer& S = H->sig[l];
+    sig_qkv_d.push_back(Wqkv); sig_bqkv_d.push_back(bqkv);
+    sig_w2_d.push_back(to_d(W2, (size_t)2 * D * D)); sig_b2_d.push_back(to_d(b2, D));
     place_w(&S.Wqkv, Wqkv, 3 * D, D, true); place(&S.bqkv, bqkv);
     place_w(&S.W1, W1m, 2 * D, 2 * D); place(&S.b1, b1f);
     place_w(&S.W2, to_d(W2, (size_t)2 * D * D), D, 2 * D); place(&S.b2, to_d(b2, D));
@@ -352,6 +355,33 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
       place_w(&S.W2p, W2perm, D, 2 * D);
     }
 #endif
+  }
+  // x_out = z + W2 hid + b2 (line_transformer.py:180-183) and the next layer's q/k/v projection is linear in x_out (:141-143), so
+  //   [x_out ; qkv_next] = [[I, W2], [Wqkv, Wqkv W2]] [z ; hid] + [b2 ; Wqkv b2 + bqkv]                      (float64, once)
+  // one contraction instead of two dependent ones -- 2.4x the flops, which only pays at single-pair sizes (linetr_net.hip)
+  for (int l = 0; l + 1 < cfg->n_sig_layers; ++l) {
+    const std::vector<double>&W2 = sig_w2_d[l], &b2 = sig_b2_d[l], &Wq = sig_qkv_d[l + 1], &bq = sig_bqkv_d[l + 1];
+    std::vector<double> Wn((size_t)4 * D * 3 * D, 0.0), bn(4 * D);
+    for (int o = 0; o < D; ++o) {
+      Wn[(size_t)o * 3 * D + o] = 1.0;
+      for (int j = 0; j < 2 * D; ++j) Wn[(size_t)o * 3 * D + D + j] = W2[(size_t)o * 2 * D + j];
+      bn[o] = b2[o];
+    }
+    for (int r = 0; r < 3 * D; ++r) {
+      double* row = &Wn[(size_t)(D + r) * 3 * D];
+      const double* wq = &Wq[(size_t)r * D];
+      for (int i = 0; i < D; ++i) row[i] = wq[i];
+      double bacc = bq[r];
+      for (int m2 = 0; m2 < D; ++m2) {          // row[D + j] += wq[m] * W2[m][j]: contiguous in j
+        const double a = wq[m2];
+        const double* w2r = &W2[(size_t)m2 * 2 * D];
+        for (int j = 0; j < 2 * D; ++j) row[D + j] += a * w2r[j];
+        bacc += a * b2[m2];
+      }
+      bn[D + r] = bacc;
+    }
+    place_w(&H->sig[l].Wnext, Wn, 4 * D, 3 * D);
+    place(&H->sig[l].bnext, bn);
   }
   {
     const float* W = tm.get("final_proj.weight", D * D, err);

@@ -416,8 +416,12 @@ extern "C" int linetr_sample_descriptors(LinetrHandle* h, const float* d_points,
 // =============================================================================================
 
 namespace {
+// W2 + residual + next q/k/v projection as one contraction (SigLayer::Wnext) is taken up to this many sub-lines: the sizes at which
+// its N = 1024, K = 768 product still goes to the latency kernel (small_gemm_wins) -- above, 2.4x the flops cost more than a launch
+constexpr int SIG_FOLD_MAX_ROWS = 960;
 struct FwdWs {
   float *a1, *a2, *a3, *a4, *pooled, *att, *fc, *o, *f1, *f2, *l1, *l2, *l3, *l4, *lpos, *zA, *zB, *qkv, *msgp, *msg, *hid;
+  float *zqA, *zqB;                                // [N][4D] = [x_out | q/k/v of the next layer] (single-pair sizes: SigLayer::Wnext)
   unsigned char *zsA, *zsB, *qkvs, *msgs, *hids;   // split-tile images of the signature network's activations (lt_gemm_st.h)
   int* cu;
   char* pn;                                        // activations + arrival counters of the single-pair persistent network (lt_pairnet.h)
@@ -439,6 +443,8 @@ FwdWs fwd_layout(const LinetrHandle* h, int N, int64_t rows, int n_images, char*
   w.zA = take((int64_t)N * D); w.zB = take((int64_t)N * D);
   w.qkv = take((int64_t)N * 3 * D); w.msgp = take((int64_t)N * D); w.msg = take((int64_t)N * D);
   w.hid = take((int64_t)N * 2 * D);
+  const int64_t nq = N <= SIG_FOLD_MAX_ROWS ? (int64_t)N * 4 * D : 0;
+  w.zqA = take(nq); w.zqB = take(nq);
 #ifdef LINETR_EXPERIMENTS
   auto take_st = [&](int cols) { unsigned char* p = (unsigned char*)(base + off); off += align_up(st_bytes(N, cols), 1024); return p; };
   off = align_up(off, 1024);
@@ -743,8 +749,35 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   const bool fused_sig_mlp = h->precision != LINETR_PREC_F32 && N >= 4096 && !LT_XENV("LINETR_NO_FUSED_SIG_MLP") &&
                              LT_XENV("LINETR_FUSED_SIG_MLP") != nullptr;   // opt-in: measured slower
 #endif
+  // single-pair sizes (the 32-query attention below is taken): x_out and the NEXT layer's q/k/v come out of ONE contraction over
+  // [z ; hid] (SigLayer::Wnext) -- one dependent launch less per layer where a launch costs more than its flops
+  const bool small_attn = h->precision != LINETR_PREC_F32 && !LT_XENV("LINETR_ATTN_F32") && !LT_XENV("LINETR_ATTN_4WAVE") &&
+                          !LT_XENV("LINETR_NO_SMALL_ATTN") && (int64_t)n_images * HEADS * cdiv(max_n, 256) < 64;
+  const bool fold_next = !chain && small_attn && N <= SIG_FOLD_MAX_ROWS && !LT_XENV("LINETR_NO_SIG_FOLD");
+  const float* qkv_in = w.qkv;     // where the current layer's q/k/v sit, and their row stride
+  int ldq = 3 * D, ldz = D;        // (z's row stride: D, or 4 D when z is the head of a [x_out | q/k/v] row)
+  float *zq = w.zqA, *zq_next = w.zqB;
+  const float* zc = z;             // the layer's input rows
   for (size_t l = 0; l < h->sig.size(); ++l) {
     const SigLayer& S = h->sig[l];
+    if (fold_next) {
+      if (l == 0) {
+        if ((e = run_gemm(h, st, zc, ldz, nullptr, 0, 0, S.Wqkv, S.bqkv, nullptr, 0, w.qkv, 3 * D, N, 3 * D, D, ACT_NONE))) return e;
+      }
+      {
+        double fl = 0;
+        for (int i = 0; i < n_images; ++i) { double n = h_cu[i + 1] - h_cu[i]; fl += 2.0 * 2.0 * n * n * D; }
+        ProfScope ps(h, st, "sig_attn_bf16x6", fl, (double)N * D * 16);
+        hipLaunchKernelGGL(sig_attn_small_kernel, dim3(n_images, HEADS, cdiv(max_n, 32)), dim3(256), 0, st, qkv_in, cu_dev, w.msgp, ldq);
+        LT_LAUNCH_CHECK();
+      }
+      if ((e = run_gemm(h, st, zc, ldz, w.msgp, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ACT_RELU))) return e;
+      if (l + 1 == h->sig.size()) break;
+      if ((e = run_gemm(h, st, zc, ldz, w.hid, 2 * D, D, S.Wnext, S.bnext, nullptr, 0, zq, 4 * D, N, 4 * D, 3 * D, ACT_NONE))) return e;
+      zc = zq; ldz = 4 * D; qkv_in = zq + D; ldq = 4 * D;
+      std::swap(zq, zq_next);
+      continue;
+    }
     // q/k/v projection + attention of an (image, head) in one launch (lt_attn_fused.h): images of up to 256 sub-lines, and
     // enough (image, head) blocks to fill the chip; q, k, v never reach HBM
     const bool no_fqa = LT_XENV("LINETR_NO_FUSED_QKV_ATTN") != nullptr;     // A/B switch (experiments build; read per call)
@@ -784,7 +817,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
         if (!attn4 && !no_small_attn && (int64_t)n_images * HEADS * cdiv(max_n, 256) < 64)
           // (r04: an eight-wave form -- one key chunk per wave, K fragments straight from global memory -- measured level with this
           // one, 12.6 us per launch for a cfg2 pair either way, and was not kept)
-          hipLaunchKernelGGL(sig_attn_small_kernel, dim3(n_images, HEADS, cdiv(max_n, 32)), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
+          hipLaunchKernelGGL(sig_attn_small_kernel, dim3(n_images, HEADS, cdiv(max_n, 32)), dim3(256), 0, st, w.qkv, cu_dev, w.msgp, 3 * D);
         else if (attn4 || max_n <= 128)
           hipLaunchKernelGGL(sig_attn_split_kernel<4>, dim3(n_images, HEADS, qtiles), dim3(256), 0, st, w.qkv, cu_dev, w.msgp);
         else
@@ -832,7 +865,8 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     if ((e = run_gemm_norm(h, st, z, D, nullptr, 0, 0, h->Wfin, h->bfin, nullptr, zn, d_line_desc, N, D, l2))) return e;
   } else {
     // final_proj(z + W2 hid + b2) = [Wfin | Wfin W2] [z ; hid] + (Wfin b2 + bfin): one K = 768 GEMM instead of two launches
-    if ((e = run_gemm_norm(h, st, z, D, w.hid, 2 * D, D, h->Wfin2, h->bfin2, nullptr, zn, d_line_desc, N, 3 * D, l2))) return e;
+    if (!fold_next) { zc = z; ldz = D; }
+    if ((e = run_gemm_norm(h, st, zc, ldz, w.hid, 2 * D, D, h->Wfin2, h->bfin2, nullptr, zn, d_line_desc, N, 3 * D, l2))) return e;
   }
   return LINETR_OK;
 }

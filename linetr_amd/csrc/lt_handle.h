@@ -16,6 +16,9 @@
 struct SigLayer {
   const float *Wqkv, *bqkv, *W1, *b1, *W2, *b2;  // merge conv folded into W1
   const float* W2p = nullptr;                    // W2 with K permuted inside 16-groups (lt_mlp_fused.h)
+  // [x_out | q/k/v of the NEXT layer] = Wnext [z ; hid] + bnext: W2 + residual and the next projection as ONE contraction
+  // ([4D x 3D]; all layers but the last).  Used for single-pair sizes only, where a dependent launch costs more than its flops.
+  const float *Wnext = nullptr, *bnext = nullptr;
 };
 
 struct ProfClass {

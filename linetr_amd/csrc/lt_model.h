@@ -1012,7 +1012,8 @@ constexpr int ATL_RV = 3 * 64 + 8;     // V^T plane row stride (bytes): [d][3][3
 constexpr int ATL_WAVE_BYTES = 32 * ATL_RK + DH * ATL_RV;   // 12 800 + 12 800
 
 __global__ __launch_bounds__(256) void sig_attn_small_kernel(const float* __restrict__ qkv, const int* __restrict__ cu_sub,
-                                                             float* __restrict__ out /*[N][256] head-major*/) {
+                                                             float* __restrict__ out /*[N][256] head-major*/,
+                                                             int ldq /*row stride of qkv in floats: 768, or 1024 when q/k/v sit behind x_out*/) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * ATL_WAVE_BYTES];
   const int img = blockIdx.x, head = blockIdx.y;
   const int n0 = cu_sub[img], Ni = cu_sub[img + 1] - n0;
@@ -1021,14 +1022,14 @@ __global__ __launch_bounds__(256) void sig_attn_small_kernel(const float* __rest
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h2 = lane >> 5, lq = lane & 31;
   const int q = q0 + lq;
-  const float* base = qkv + (int64_t)n0 * 768;
+  const float* base = qkv + (int64_t)n0 * ldq;
   unsigned char* Ks = lds + wave * ATL_WAVE_BYTES;
   unsigned char* Vt = Ks + 32 * ATL_RK;
 
   bf16x8 qf[4][3];
   {
     const int qr = q < Ni ? q : Ni - 1;
-    const float* qp = base + (int64_t)qr * 768 + head * DH + h2 * 8;
+    const float* qp = base + (int64_t)qr * ldq + head * DH + h2 * 8;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + s * 16);
@@ -1061,7 +1062,7 @@ __global__ __launch_bounds__(256) void sig_attn_small_kernel(const float* __rest
       kreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (kv < Ni) {
-        const float* p = base + (int64_t)kv * 768 + head * DH + sc4;
+        const float* p = base + (int64_t)kv * ldq + head * DH + sc4;
         kreg[i] = *reinterpret_cast<const f32x4*>(p + 256);
         vreg[i] = *reinterpret_cast<const f32x4*>(p + 512);
       }
