@@ -1,5 +1,5 @@
 """GPU: the kernels and switches that were measured and NOT shipped, in the experiments build of the library
-(liblinetr_hip_experiments.so = the same sources with -DLINETR_EXPERIMENTS; `python -m linetr_amd.build --experiments`):
+(experiments/liblinetr_hip_experiments.so = the product sources with -DLINETR_EXPERIMENTS + experiments/csrc; `python -m linetr_amd.build --experiments`):
 the stream-K tail, the fused signature MLP, the separate row-norm path, the split-tile (ST) operand format with its
 LDS-DMA GEMM and attention, and the row-tile-local GEMM chains.  They stay correct (these tests) so that their numbers in
 DESIGN.md can be reproduced; the product library contains none of them."""
@@ -13,8 +13,11 @@ from linetr_amd import _native as nat
 from workloads import synth
 from test_gpu_properties import batch_inputs, describe
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.path.exists(nat.EXPERIMENTS_LIB_PATH), reason="experiments library not built")]
+# NOT part of `pytest tests -m gpu` (which loads the product library only): run on the GPU box with
+#   python -m linetr_amd.build --experiments && python -m pytest experiments -q -m experiments
+pytestmark = [pytest.mark.experiments,
+              pytest.mark.skipif(not os.path.exists(nat.EXPERIMENTS_LIB_PATH), reason="experiments library not built"),
+              pytest.mark.skipif(not torch.cuda.is_available(), reason="no HIP device")]
 torch.set_grad_enabled(False)
 
 

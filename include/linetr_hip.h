@@ -259,6 +259,17 @@ int linetr_pool_distmat(LinetrHandle* h, const float* d_dist, int32_t n0, int32_
                         const int32_t* d_sub2line1, int32_t k1, float* d_dk, void* d_workspace, int64_t workspace_bytes,
                         void* stream);
 
+/* LineTransformer.subline2keyline (models/line_transformer.py:277-282) on the two mat_klines2sublines MATRICES, the way the
+ * reference's call sites pass them (models/matching.py:80: data['mat_klines2sublines0'][0], [K,N] float32 on the device): a matrix
+ * of the form line_tokenizer writes (models/line_process.py:163-167: one non-zero per column, key-lines in order, rows of
+ * float32(1 / num_sublines)) is reduced to its sub-line -> key-line map on the device and pooled like linetr_pool_distmat;
+ * any other matrix is multiplied out as given, Dk = (A0 D) A1^T in fp32.  The decision is made on the device: asynchronous on
+ * `stream`, no host synchronisation.  `h` may be NULL. */
+int64_t linetr_pool_distmat_dense_workspace_bytes(int32_t k0, int32_t n0, int32_t k1, int32_t n1);
+int linetr_pool_distmat_dense(LinetrHandle* h, const float* d_dist, int32_t n0, int32_t n1, const float* d_A0, int32_t k0,
+                              const float* d_A1, int32_t k1, float* d_dk, void* d_workspace, int64_t workspace_bytes,
+                              void* stream);
+
 /* nn_matcher (models/nn_matcher.py:33-42): point-descriptor variant, desc given [256,n] column-major
  * like SuperPoint's `descriptors` -- section 8(f) "next" row, same kernels. */
 int linetr_match_points(LinetrHandle* h, const float* d_desc0_cn, int32_t n0, const float* d_desc1_cn,

@@ -11,8 +11,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblinetr_hip.so")
-# the same sources built with -DLINETR_EXPERIMENTS: tuning switches + the kernels that were measured and lost (tools/, tests)
-EXPERIMENTS_LIB_PATH = os.path.join(_HERE, "csrc", "liblinetr_hip_experiments.so")
+# the product sources + experiments/csrc built with -DLINETR_EXPERIMENTS (`python -m linetr_amd.build --experiments`): tuning
+# switches and the kernels that were measured and lost.  Lives OUTSIDE the package; only tools/ and `pytest -m experiments` load it.
+EXPERIMENTS_LIB_PATH = os.path.join(os.path.dirname(_HERE), "experiments", "liblinetr_hip_experiments.so")
 
 E_ASSERT = -4
 
@@ -115,6 +116,9 @@ def lib(path=None):
     L.linetr_pool_distmat_workspace_bytes.argtypes = [i32, i32]
     L.linetr_pool_distmat_workspace_bytes.restype = i64
     L.linetr_pool_distmat.argtypes = [vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, i64, vp]
+    L.linetr_pool_distmat_dense_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.linetr_pool_distmat_dense_workspace_bytes.restype = i64
+    L.linetr_pool_distmat_dense.argtypes = [vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, i64, vp]
     L.linetr_set_profiling.argtypes = [vp, i32]
     L.linetr_get_profile.argtypes = [vp, C.POINTER(ProfileEntry), i32, C.POINTER(i32)]
     if L.linetr_abi_version() != 3:
@@ -127,7 +131,7 @@ EXPORTS = ["linetr_abi_version", "linetr_last_error", "linetr_create", "linetr_d
            "linetr_prefilter_batch", "linetr_prefilter_tied_images", "linetr_pack_lines", "linetr_tokenize_workspace_bytes", "linetr_tokenize", "linetr_forward_workspace_bytes",
            "linetr_forward", "linetr_describe_workspace_bytes", "linetr_describe", "linetr_match_workspace_bytes", "linetr_match", "linetr_match_gathered", "linetr_match_points",
            "linetr_match_distmat", "linetr_match_distmat_workspace_bytes", "linetr_superpoint_heads", "linetr_set_precision", "linetr_get_precision", "linetr_debug_posenc", "linetr_debug_gemm", "linetr_allgather_desc", "linetr_set_allgather_fn", "linetr_pack_slab", "linetr_sample_descriptors_workspace_bytes",
-           "linetr_sample_descriptors", "linetr_pool_distmat_workspace_bytes", "linetr_pool_distmat", "linetr_set_profiling", "linetr_get_profile"]
+           "linetr_sample_descriptors", "linetr_pool_distmat_workspace_bytes", "linetr_pool_distmat", "linetr_pool_distmat_dense_workspace_bytes", "linetr_pool_distmat_dense", "linetr_set_profiling", "linetr_get_profile"]
 
 
 EXPERIMENT_EXPORTS = ["linetr_st_bytes", "linetr_debug_to_st", "linetr_debug_from_st", "linetr_debug_gemm_st", "linetr_debug_pairnet_stamps"]

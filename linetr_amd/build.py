@@ -1,5 +1,8 @@
 """Build the gfx950 shared library in-tree:  python -m linetr_amd.build [--force] [--experiments | --all]
 
+Default = the product library only.  --experiments additionally builds experiments/liblinetr_hip_experiments.so: the product sources
+with -DLINETR_EXPERIMENTS plus the measured-and-rejected kernels of experiments/csrc/ (never loaded by the package or by `pytest -m gpu`).
+
 hipcc cross-compiles for gfx950 without a GPU present; the resulting linetr_amd/csrc/liblinetr_hip.so travels to the
 GPU box with the repo snapshot.  The library is a handful of translation units (csrc/linetr_*.hip, see lt_handle.h);
 each is compiled to an object under csrc/build/ (in parallel, re-compiled only when one of the files it includes
@@ -17,7 +20,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 OUT = os.path.join(CSRC, "liblinetr_hip.so")
-OUT_X = os.path.join(CSRC, "liblinetr_hip_experiments.so")     # same sources, -DLINETR_EXPERIMENTS (tools/, experiment tests)
+XDIR = os.path.abspath(os.path.join(HERE, "..", "experiments"))
+XSRC = os.path.join(XDIR, "csrc")                               # kernels that were measured and not shipped + their host unit
+OUT_X = os.path.join(XDIR, "liblinetr_hip_experiments.so")      # product sources + XSRC, -DLINETR_EXPERIMENTS (tools/, `pytest -m experiments`)
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-undefined-inline"]
 LFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]
 
@@ -29,12 +34,13 @@ def _hipcc():
     raise RuntimeError("hipcc not found (ROCm toolchain required)")
 
 
-def units():
-    return sorted(glob.glob(os.path.join(CSRC, "linetr_*.hip")))
+def units(experiments: bool = False):
+    return sorted(glob.glob(os.path.join(CSRC, "linetr_*.hip")) + (glob.glob(os.path.join(XSRC, "linetr_*.hip")) if experiments else []))
 
 
-def sources():
-    return sorted(units() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "linetr_hip.h")])
+def sources(experiments: bool = False):
+    return sorted(units(experiments) + glob.glob(os.path.join(CSRC, "*.h")) + (glob.glob(os.path.join(XSRC, "*.h")) if experiments else [])
+                  + [os.path.join(HERE, "..", "include", "linetr_hip.h")])
 
 
 def _deps(dfile):
@@ -65,7 +71,7 @@ def up_to_date(out=OUT) -> bool:
     if not os.path.exists(out):
         return False
     t = os.path.getmtime(out)
-    return all(os.path.getmtime(s) <= t for s in sources())
+    return all(os.path.getmtime(s) <= t for s in sources(out == OUT_X))
 
 
 def build(force: bool = False, verbose: bool = True, experiments: bool = False) -> str:
@@ -77,9 +83,9 @@ def build(force: bool = False, verbose: bool = True, experiments: bool = False) 
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     tag = "x" if experiments else "p"
-    defs = ["-DLINETR_EXPERIMENTS"] if experiments else []
+    defs = ["-DLINETR_EXPERIMENTS", "-I", XSRC, "-I", CSRC] if experiments else []
     jobs, objs = [], []
-    for src in units():
+    for src in units(experiments):
         stem = os.path.splitext(os.path.basename(src))[0]
         obj = os.path.join(OBJ, f"{stem}.{tag}.o")
         dfile = obj[:-2] + ".d"

@@ -277,6 +277,68 @@ extern "C" int linetr_pool_distmat(LinetrHandle* h, const float* d_dist, int32_t
   return LINETR_OK;
 }
 
+// subline2keyline on the two mat_klines2sublines MATRICES, as the reference's call sites hand them over (models/matching.py:80:
+// data['mat_klines2sublines0'][0], a [K,N] float32 tensor).  A tokeniser's matrix is reduced to its sub-line -> key-line map on the
+// device and pooled by the segmented-mean kernel; any other matrix is multiplied out as given.  Asynchronous on `stream`.
+namespace {
+struct DensePoolLayout { int64_t o_map0, o_map1, o_val0, o_val1, o_verdict, o_tmp, o_pool, total; };
+DensePoolLayout dense_pool_layout(int k0, int n0, int k1, int n1) {
+  DensePoolLayout L{};
+  int64_t o = 0;
+  L.o_verdict = o; o += 256;
+  L.o_map0 = o; o += align_up((int64_t)std::max(n0, 1) * 4, 256);
+  L.o_map1 = o; o += align_up((int64_t)std::max(n1, 1) * 4, 256);
+  L.o_val0 = o; o += align_up((int64_t)std::max(n0, 1) * 4, 256);
+  L.o_val1 = o; o += align_up((int64_t)std::max(n1, 1) * 4, 256);
+  L.o_tmp = o; o += align_up((int64_t)std::max(k0, 1) * std::max(n1, 1) * 4, 256);
+  L.o_pool = o; o += linetr_pool_distmat_workspace_bytes(std::min(k0, n0), std::min(k1, n1));
+  L.total = o;
+  return L;
+}
+}  // namespace
+
+extern "C" int64_t linetr_pool_distmat_dense_workspace_bytes(int32_t k0, int32_t n0, int32_t k1, int32_t n1) {
+  return dense_pool_layout(std::max(k0, 0), std::max(n0, 0), std::max(k1, 0), std::max(n1, 0)).total;
+}
+
+extern "C" int linetr_pool_distmat_dense(LinetrHandle* h, const float* d_dist, int32_t n0, int32_t n1, const float* d_A0, int32_t k0,
+                                         const float* d_A1, int32_t k1, float* d_dk, void* d_ws, int64_t ws_bytes, void* stream) {
+  if (n0 < 0 || n1 < 0 || k0 < 0 || k1 < 0) return fail(LINETR_E_ARG, "pool_distmat_dense: bad dims");
+  if (k0 == 0 || k1 == 0) return LINETR_OK;
+  if (!d_dk || !d_ws || ((n0 > 0 && n1 > 0) && (!d_dist || !d_A0 || !d_A1))) return fail(LINETR_E_ARG, "pool_distmat_dense: null pointer");
+  const DensePoolLayout L = dense_pool_layout(k0, n0, k1, n1);
+  if (ws_bytes < L.total) return fail(LINETR_E_WORKSPACE, "pool_distmat_dense: workspace too small (need %lld)", (long long)L.total);
+  hipStream_t st = (hipStream_t)stream;
+  if (h) LT_HIP(hipSetDevice(h->device));
+  char* base = (char*)d_ws;
+  int* verdict = (int*)(base + L.o_verdict);
+  if (n0 == 0 || n1 == 0) {                          // an empty inner dimension: the product is a zero matrix
+    LT_HIP(hipMemsetAsync(d_dk, 0, (size_t)k0 * k1 * 4, st));
+    return LINETR_OK;
+  }
+  // K > N cannot be a tokeniser's matrix (every key-line owns at least one sub-line): the verdict starts non-zero and the
+  // segmented-mean launch is skipped
+  const bool poolable = k0 <= n0 && k1 <= n1;
+  LT_HIP(hipMemsetAsync(verdict, poolable ? 0 : 0x01, 4, st));
+  if (poolable) {
+    int* map0 = (int*)(base + L.o_map0); int* map1 = (int*)(base + L.o_map1);
+    float* val0 = (float*)(base + L.o_val0); float* val1 = (float*)(base + L.o_val1);
+    hipLaunchKernelGGL(mat_to_map_kernel, dim3(cdiv(n0, 256)), dim3(256), 0, st, d_A0, k0, n0, map0, val0, verdict);
+    hipLaunchKernelGGL(mat_to_map_kernel, dim3(cdiv(n1, 256)), dim3(256), 0, st, d_A1, k1, n1, map1, val1, verdict);
+    hipLaunchKernelGGL(mat_check_kernel, dim3(cdiv(n0, 256)), dim3(256), 0, st, (const int*)map0, (const float*)val0, k0, n0, verdict);
+    hipLaunchKernelGGL(mat_check_kernel, dim3(cdiv(n1, 256)), dim3(256), 0, st, (const int*)map1, (const float*)val1, k1, n1, verdict);
+    hipLaunchKernelGGL(map_sanitize_kernel, dim3(cdiv(n0, 256)), dim3(256), 0, st, map0, k0, n0, (const int*)verdict);
+    hipLaunchKernelGGL(map_sanitize_kernel, dim3(cdiv(n1, 256)), dim3(256), 0, st, map1, k1, n1, (const int*)verdict);
+    LT_LAUNCH_CHECK();
+    if (int e = linetr_pool_distmat(h, d_dist, n0, n1, map0, k0, map1, k1, d_dk, base + L.o_pool, ws_bytes - L.o_pool, stream)) return e;
+  }
+  float* tmp = (float*)(base + L.o_tmp);
+  hipLaunchKernelGGL(dense_pool_left_kernel, dim3(cdiv(n1, 256), k0), dim3(256), 0, st, d_A0, d_dist, tmp, n0, n1, (const int*)verdict);
+  hipLaunchKernelGGL(dense_pool_right_kernel, dim3(cdiv(k1, 4), k0), dim3(256), 0, st, (const float*)tmp, d_A1, d_dk, n1, k1, (const int*)verdict);
+  LT_LAUNCH_CHECK();
+  return LINETR_OK;
+}
+
 // One rank's all-gather slab in one launch (layout: lt_match.h pack_slab_kernel, linetr_amd/parallel.py)
 extern "C" int linetr_pack_slab(const float* d_line_desc, int32_t N, const int32_t* d_cu_n, const int32_t* d_cu_k, int32_t n_images,
                                 const int32_t* d_sub2line, int32_t n_images_cap, int32_t rows_cap, int32_t zero_tail, float* d_slab,

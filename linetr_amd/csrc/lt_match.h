@@ -275,6 +275,77 @@ __global__ __launch_bounds__(256) void pair_final_kernel(const PairTable pairs, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// subline2keyline (models/line_transformer.py:277-282) for a mat_klines2sublines given as the MATRIX the reference passes around
+// ([K,N] float32) instead of this library's sub-line -> key-line map: the matrix is reduced to the map when it is one the
+// tokeniser writes (line_process.py:163-167: one non-zero per column, key-lines in order, every entry of a row the float32 of
+// 1 / num_sublines) and pooled by pair_pool_kernel; ANY other matrix is multiplied out as given (two plain fp32 passes).
+// Everything is decided on the device (verdict word in the workspace): the entry point stays asynchronous.
+//   verdict bits: 1 a column without exactly one non-zero, 2 rows not in order / a key-line without sub-lines, 4 an entry that
+//   is not float32(1 / num_sublines)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mat_to_map_kernel(const float* __restrict__ A, int K, int N, int* __restrict__ map,
+                                                         float* __restrict__ vals, int* __restrict__ verdict) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  int cnt = 0, row = 0;
+  float v = 0.f;
+  for (int k = 0; k < K; ++k) {                       // adjacent threads read adjacent columns: coalesced rows
+    const float a = A[(int64_t)k * N + n];
+    if (a != 0.f) { ++cnt; row = k; v = a; }          // (a NaN entry counts as non-zero and fails the value check below)
+  }
+  map[n] = row;
+  vals[n] = v;
+  if (cnt != 1) atomicOr(verdict, 1);
+}
+
+__global__ __launch_bounds__(256) void mat_check_kernel(const int* __restrict__ map, const float* __restrict__ vals, int K, int N,
+                                                        int* __restrict__ verdict) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int prev = n ? map[n - 1] : -1, cur = map[n];
+  int bad = 0;
+  if (cur != prev && cur != prev + 1) bad |= 2;       // key-line ids start at 0 and grow in steps of one
+  if (n == N - 1 && cur != K - 1) bad |= 2;
+  if (cur != prev) {                                  // first sub-line of a key-line: every entry must be float32(1 / count)
+    int len = 1;
+    while (n + len < N && map[n + len] == cur) ++len;
+    const float w = (float)(1.0 / (double)len);       // the tokeniser's value (line_process.py:165: a Python float stored as float32)
+    for (int i = 0; i < len; ++i) if (!(vals[n + i] == w)) bad |= 4;
+  }
+  if (bad) atomicOr(verdict, bad);
+}
+
+// a matrix that is not a tokeniser's: give pair_pool_kernel a well-formed map to run on (its output is overwritten below)
+__global__ __launch_bounds__(256) void map_sanitize_kernel(int* __restrict__ map, int K, int N, const int* __restrict__ verdict) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < N && *verdict) map[n] = n < K - 1 ? n : K - 1;
+}
+
+// tmp[i][m] = sum_n A0[i][n] * D[n][m]   (the reference's left product, as given); grid (cdiv(n1,256), k0)
+__global__ __launch_bounds__(256) void dense_pool_left_kernel(const float* __restrict__ A0, const float* __restrict__ Dm, float* __restrict__ tmp,
+                                                              int n0, int n1, const int* __restrict__ verdict) {
+  if (*verdict == 0) return;
+  const int m = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (m >= n1) return;
+  float acc = 0.f;
+  for (int n = 0; n < n0; ++n) acc += A0[(int64_t)i * n0 + n] * Dm[(int64_t)n * n1 + m];
+  tmp[(int64_t)i * n1 + m] = acc;
+}
+
+// Dk[i][j] = sum_m tmp[i][m] * A1[j][m]; grid (cdiv(k1,4), k0): one wave per (i, j), lanes over m (coalesced), wave reduction
+__global__ __launch_bounds__(256) void dense_pool_right_kernel(const float* __restrict__ tmp, const float* __restrict__ A1, float* __restrict__ Dk,
+                                                               int n1, int k1, const int* __restrict__ verdict) {
+  if (*verdict == 0) return;
+  const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6), i = blockIdx.y;
+  if (j >= k1) return;
+  float acc = 0.f;
+  for (int m = lane; m < n1; m += 64) acc += tmp[(int64_t)i * n1 + m] * A1[(int64_t)j * n1 + m];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) Dk[(int64_t)i * k1 + j] = acc;
+}
+
 // [256][n] (SuperPoint 'descriptors' layout) -> [n][256]
 __global__ void transpose_cn_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int n) {
   __shared__ float tile[32][33];

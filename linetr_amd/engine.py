@@ -223,6 +223,10 @@ class Engine:
             arr = (C.c_void_p * B)()
             for i, vm in enumerate(valid_masks):
                 if vm is not None:
+                    if np.ndim(vm) != 2 or np.shape(vm) != (int(height), int(width)):
+                        # prefilter_core reads vm[y * width + x]: any other shape would be read out of bounds or mis-addressed
+                        raise ValueError(f"valid mask {i} has shape {np.shape(vm)}, the native pre-filter needs ({int(height)}, "
+                                         f"{int(width)}) (other shapes: the NumPy remove_borders of linetr_amd.line_process)")
                     vm = np.ascontiguousarray(vm, dtype=np.float64)
                     keep.append(vm)
                     arr[i] = vm.ctypes.data
@@ -620,6 +624,37 @@ class Engine:
             nat.check(self._L.linetr_pool_distmat(self._h, d.data_ptr(), n0, n1, s0.data_ptr(), k0, s1.data_ptr(), k1,
                                                   dk.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), self._L)
         return dk
+
+    def pool_distmat_dense(self, dist: torch.Tensor, mat0: torch.Tensor, mat1: torch.Tensor):
+        """subline2keyline on the device from the two mat_klines2sublines MATRICES ([K,N] float32): a tokeniser's matrix is
+        reduced to its map and pooled by the segmented-mean kernel, any other is multiplied out as given
+        (linetr_pool_distmat_dense; decided on the device, asynchronous).  Returns Dk [k0,k1]."""
+        d, a0, a1 = self._f32(dist), self._f32(mat0), self._f32(mat1)
+        n0, n1 = int(d.shape[0]), int(d.shape[1])
+        k0, k1 = int(a0.shape[0]), int(a1.shape[0])
+        if tuple(a0.shape) != (k0, n0) or tuple(a1.shape) != (k1, n1):
+            raise ValueError(f"subline2keyline: shapes {tuple(a0.shape)} @ {tuple(d.shape)} @ {tuple(a1.shape)}^T do not chain")
+        dk = torch.empty((k0, k1), dtype=torch.float32, device=self.device)
+        if k0 == 0 or k1 == 0:
+            return dk
+        ws = self._workspace("pool", self._L.linetr_pool_distmat_dense_workspace_bytes(k0, n0, k1, n1))
+        with torch.cuda.device(self.device):
+            nat.check(self._L.linetr_pool_distmat_dense(self._h, d.data_ptr(), n0, n1, a0.data_ptr(), k0, a1.data_ptr(), k1,
+                                                        dk.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), self._L)
+        return dk
+
+    def match_distmat(self, dist: torch.Tensor, thr, mutual=True):
+        """nn_matcher_distmat on a device matrix [n0,n1]: match01 [n0] (device, int32; -1 = no match)."""
+        d = self._f32(dist)
+        n0, n1 = int(d.shape[0]), int(d.shape[1])
+        m01 = torch.full((n0,), -1, dtype=torch.int32, device=self.device)
+        if n0 == 0 or n1 == 0:
+            return m01
+        ws = self._workspace("match_dm", self._L.linetr_match_distmat_workspace_bytes(n0, n1))
+        with torch.cuda.device(self.device):
+            nat.check(self._L.linetr_match_distmat(self._h, d.data_ptr(), n0, n1, float(thr), int(bool(mutual)), m01.data_ptr(),
+                                                   ws.data_ptr(), ws.numel(), self._stream()), self._L)
+        return m01
 
     def sample_descriptors(self, points: torch.Tensor, dense_desc: torch.Tensor, *, align_corners=False, dense_layout="nchw"):
         """sample_descriptors (line_process.py:86-98) for n points [n,2] of one image; dense_desc [256,Hc,Wc] or

@@ -131,6 +131,37 @@ def _token_engine(device):
     return eng
 
 
+def mask_fits_image(mask, height, width) -> bool:
+    """True when an ndarray valid mask has the [height, width] layout the native pre-filter indexes (Engine.prefilter)."""
+    return mask.ndim == 2 and mask.shape[0] == int(height) and mask.shape[1] == int(width)
+
+
+def attach_sub2line(mat: torch.Tensor, sub2line: torch.Tensor) -> torch.Tensor:
+    """The sub-line -> key-line map rides along with the mat_klines2sublines it describes, so that the matcher needs no pass over
+    the matrix (Matching.match_lines).  It is stamped with the matrix's version counter: a matrix edited in place afterwards --
+    through any view -- is read by its CONTENTS again (sub2line_of), as the reference multiplies whatever the matrix holds."""
+    try:
+        stamp = mat._version
+    except RuntimeError:          # an inference tensor keeps no version counter: its map is never trusted
+        stamp = None
+    mat._linetr_sub2line = sub2line
+    mat._linetr_sub2line_stamp = stamp
+    return mat
+
+
+def sub2line_of(mat):
+    """The map attach_sub2line put on `mat`, or None when there is none or the matrix has been written to since."""
+    s = getattr(mat, "_linetr_sub2line", None)
+    if s is None:
+        return None
+    stamp = getattr(mat, "_linetr_sub2line_stamp", None)
+    try:
+        now = mat._version
+    except RuntimeError:
+        return None
+    return s if stamp is not None and stamp == now else None
+
+
 def prefilter_tokenize(klines_cv, height, width, border, min_length, max_sublines, token_distance, max_tokens, pred_superpoint,
                        mask=None):
     """change_cv2_T_np -> remove_borders -> filter_by_length -> line_tokenizer of ONE image (line_process.py:203-231, :59-84, :6-21,
@@ -145,6 +176,11 @@ def prefilter_tokenize(klines_cv, height, width, border, min_length, max_subline
     if dd is None:
         dd = pred_superpoint["dense_descriptor"]
     eng = _token_engine(dd.device)
+    if isinstance(mask, np.ndarray) and not mask_fits_image(mask, height, width):
+        # the native pre-filter addresses the mask as [height, width]; a mask of any other shape goes through the NumPy indexing of
+        # remove_borders, which does with it exactly what the reference does (IndexError, or whatever rows it selects)
+        lines = filter_by_length(remove_borders(change_cv2_T_np(klines_cv), border, height, width, mask), min_length, max_sublines)
+        return lines if len(lines["klines"]) == 0 else tokenize_into(lines, eng, token_distance, max_tokens, pred_superpoint)
     vm = [mask] if isinstance(mask, np.ndarray) else None
     recs, cu_k, cu_n = eng.prefilter([keylines_to_array(klines_cv)], height, width, remove_borders=border, min_length=min_length,
                                      max_keylines=max_sublines, token_distance=token_distance, max_tokens=max_tokens, valid_masks=vm)
@@ -170,10 +206,9 @@ def tokenize_into(klines, eng, token_distance, max_tokens, pred_superpoint, pack
     align = int(torch.__version__[2]) > 2   # the reference's own version switch (line_process.py:93)
     tb = eng.tokenize(recs, np.array([0, K], np.int32), np.array([0, N], np.int32), dd, ds, token_distance=td,
                       max_tokens=T, align_corners=align, dense_layout=layout, want_mat=True)
-    mat = tb.mat[None]
-    # the sub-line -> key-line map rides along with the matrix it describes, so that the matcher needs no argmax pass
-    # (Matching.match_lines, LineTransformer.subline2keyline); a matrix from anywhere else simply lacks the attribute
-    mat._linetr_sub2line = tb.sub2line
+    # the sub-line -> key-line map rides along with the matrix it describes (Matching.match_lines); a matrix from anywhere else -- or
+    # one indexed / edited since -- simply lacks a valid one and is reduced to its map on the device (linetr_pool_distmat_dense)
+    mat = attach_sub2line(tb.mat[None], tb.sub2line)
     # the reference clips the end points through a view, so the exported key-lines carry the clip
     klines["klines"] = tb.klines[None]
     klines["length_klines"] = tb.length[None]
@@ -197,7 +232,10 @@ def line_tokenizer(klines, token_distance, max_tokens, pred_superpoint, image_sh
     ds = pred_superpoint["dense_score"]
     if (int(ds.shape[-2]), int(ds.shape[-1])) != (int(height), int(width)):
         raise ValueError(f"line_tokenizer: image_shape {tuple(image_shape)} does not match dense_score {tuple(ds.shape)}")
-    eng = _token_engine(pred_superpoint["dense_descriptor"].device)
+    dd = pred_superpoint.get("dense_descriptor_nhwc")       # either descriptor key may be the one supplied (tokenize_into)
+    if dd is None:
+        dd = pred_superpoint["dense_descriptor"]
+    eng = _token_engine(dd.device)
     return tokenize_into(klines, eng, token_distance, max_tokens, pred_superpoint)
 
 

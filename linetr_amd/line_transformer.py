@@ -155,20 +155,31 @@ class LineTransformer(nn.Module):
         track = self.__dict__.get("_tracked")
         if track is None:
             owners, names, tensors = [], [], []
+            n_entries, dicts = 0, []
             for mod in self.modules():
+                dicts += [mod._parameters, mod._buffers, mod._modules]
                 for d in (mod._parameters, mod._buffers):
+                    n_entries += len(d)
                     for name, t in d.items():
                         if t is not None:
                             owners.append(d); names.append(name); tensors.append(t)
-            versioned = [t for t in tensors if not t.is_inference()]          # inference tensors keep no version counter
-            track = self.__dict__["_tracked"] = (owners, names, tensors, versioned)
-        owners, names, tensors, versioned = track
-        # three C-level sweeps over the ~190 tensors (a Python loop with the same three reads costs twice as much)
-        if not all(map(operator.is_, map(dict.get, owners, names), tensors)):
+                # the sub-module objects themselves: `lt.final_proj = nn.Conv1d(..)` or a swapped encoder block leaves the OLD
+                # module's parameter dicts untouched, so the identity sweep has to see the parent's _modules entry change
+                n_entries += len(mod._modules)
+                for name, child in mod._modules.items():
+                    if child is not None:
+                        owners.append(mod._modules); names.append(name); tensors.append(child)
+            params = [t for t in tensors if isinstance(t, torch.Tensor)]
+            versioned = [t for t in params if not t.is_inference()]          # inference tensors keep no version counter
+            track = self.__dict__["_tracked"] = (owners, names, tensors, versioned, params, dicts, n_entries)
+        owners, names, tensors, versioned, params, dicts, n_entries = track
+        # C-level sweeps over the ~300 tracked objects (a Python loop with the same reads costs twice as much); the entry count
+        # catches a parameter / buffer / sub-module ADDED to or deleted from a tracked dict
+        if sum(map(len, dicts)) != n_entries or not all(map(operator.is_, map(dict.get, owners, names), tensors)):
             self.__dict__["_tracked"] = None      # a replaced object: walk the tree again (its storage pointer is in the new key)
             return self._weights_version()
         # data_ptr: `p.data = new_tensor` rebinds storage without touching _version
-        return tuple(map(torch.Tensor.data_ptr, tensors)) + tuple(map(_VERSION_OF, versioned))
+        return tuple(map(torch.Tensor.data_ptr, params)) + tuple(map(_VERSION_OF, versioned))
 
     # the native handle is a ctypes pointer: never pickled / deep-copied, rebuilt on first use instead
     def __getstate__(self):
@@ -263,19 +274,20 @@ class LineTransformer(nn.Module):
 
     def subline2keyline(self, distance_sublines, mat_klines2sublines0, mat_klines2sublines1):
         """Mean sub-line distance per key-line pair: (A0 @ D @ A1^T)[None], NumPy in / NumPy out
-        (models/line_transformer.py:277-282).  Matrices that come from this package's tokeniser carry their sub-line ->
-        key-line map and are pooled by the matcher's segmented-mean kernel (linetr_pool_distmat); any other matrix is
-        multiplied out as given."""
-        s0 = getattr(mat_klines2sublines0, "_linetr_sub2line", None)
-        s1 = getattr(mat_klines2sublines1, "_linetr_sub2line", None)
-        dev = mat_klines2sublines0.device if mat_klines2sublines0.is_cuda else None
+        (models/line_transformer.py:277-282).  The call sites hand over plain [K,N] matrices (matching.py:80 indexes [0]), so the
+        matrices are read by their contents, on the device: a tokeniser's matrix (one non-zero per column, rows of
+        1 / num_sublines) is reduced to its sub-line -> key-line map and pooled by the matcher's segmented-mean kernel, any other
+        matrix is multiplied out as given (linetr_pool_distmat_dense).  No torch arithmetic."""
+        a0, a1 = mat_klines2sublines0, mat_klines2sublines1
+        dev = next((t.device for t in (a0, a1) if torch.is_tensor(t) and t.is_cuda), None)
+        eng = _token_engine(dev if dev is not None else self._device())       # the pooling needs no weights
         d = torch.as_tensor(np.asarray(distance_sublines), dtype=torch.float32)
-        if s0 is not None and s1 is not None and d.dim() == 2:
-            eng = self.engine(dev)
-            K0, K1 = int(mat_klines2sublines0.shape[-2]), int(mat_klines2sublines1.shape[-2])
-            return eng.pool_distmat(d.to(eng.device), s0, K0, s1, K1)[None].cpu().numpy()
-        a0, a1 = mat_klines2sublines0.float(), mat_klines2sublines1.float()
-        return (a0 @ d.to(a0.device) @ a1.t())[None].cpu().numpy()
+        if d.dim() != 2:
+            raise ValueError("subline2keyline: distance_sublines must be [N0,N1]")
+        a0, a1 = (torch.as_tensor(a, dtype=torch.float32) for a in (a0, a1))
+        if a0.dim() != 2 or a1.dim() != 2:
+            raise ValueError("subline2keyline: mat_klines2sublines must be [K,N] (the reference's callers index the batch axis away)")
+        return eng.pool_distmat_dense(d, a0, a1)[None].cpu().numpy()
 
     def default_ret(self):
         return {"klines": torch.empty((1, 0, 2, 2)), "sublines": torch.empty((1, 0, 2, 2)),

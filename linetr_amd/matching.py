@@ -57,7 +57,7 @@ class Matching(torch.nn.Module):
         except the descriptors (fp32 round-off: other GEMM tiles for 398 rows; tests/test_gpu_dropin.py).
         Returns the two dicts (preprocess + forward of models/line_transformer.py:225-275), or None when the pair does not
         qualify (an image without lines, maps of different shapes or not on the device)."""
-        from .line_process import get_angles, keylines_to_array
+        from .line_process import attach_sub2line, get_angles, keylines_to_array, mask_fits_image
         lt = self.linetransformer
         imgs = [data["image" + s] for s in sides]
         shape = tuple(imgs[0].shape)
@@ -74,6 +74,8 @@ class Matching(torch.nn.Module):
         # argsort: Engine.prefilter, tie_order); the angles are NumPy's, computed per image as filter_by_length does (:20), because
         # libm's cos / sin may differ from NumPy's in the last ulp
         masks = [data["valid_mask" + s] if isinstance(data["valid_mask" + s], np.ndarray) else None for s in sides]
+        if any(m is not None and not mask_fits_image(m, height, width) for m in masks):
+            return None                                           # oddly shaped masks: NumPy's own indexing, image by image
         eng = lt.engine(dds[0].device)
         recs, cu_k, cu_n = eng.prefilter([keylines_to_array(detected[s]) for s in sides], height, width,
                                          remove_borders=c["remove_borders"], min_length=c["min_length"], max_keylines=c["max_keylines"],
@@ -90,8 +92,7 @@ class Matching(torch.nn.Module):
         for i in range(2):      # one indexing call per entry (a torch view costs ~2 us of host time; there are 24 of them)
             k = slice(int(cu_k[i]), int(cu_k[i + 1]))
             n = slice(int(cu_n[i]), int(cu_n[i + 1]))
-            mat = tb.mat_of(i)[None]
-            mat._linetr_sub2line = tb.sub2line[n]
+            mat = attach_sub2line(tb.mat_of(i)[None], tb.sub2line[n])
             outs.append({"klines": tb.klines[None, k], "length_klines": tb.length[None, k], "angles": tb.angles[None, k],
                          "sublines": tb.sublines[None, n], "pnt_sublines": tb.pnt[None, n],
                          "mask_sublines": tb.mask[None, n, :, None], "resp_sublines": tb.resp[None, n, None],
@@ -124,14 +125,23 @@ class Matching(torch.nn.Module):
             if "valid_mask" + s not in data:
                 data["valid_mask" + s] = torch.ones_like(data["image" + s])   # a tensor: ignored downstream (matching.py:37-40)
         lt = self.linetransformer
-        if sides and self.auto_min_length:                        # matching.py:30-32
-            shape = data["image" + sides[0]].shape
-            lt.config["min_length"] = max(16, max(shape) / 40)
-            lt.config["token_distance"] = max(8, max(shape) / 80)
+
+        def auto_lengths(shape):
+            """min_length / token_distance follow the image about to be tokenised -- per image, matching.py:29-32 and :45-48."""
+            if self.auto_min_length:
+                lt.config["min_length"] = max(16, max(shape) / 40)
+                lt.config["token_distance"] = max(8, max(shape) / 80)
+
         detected = {s: self.lsd.detect_torch(data["image" + s]) for s in sides}
-        outs = self._describe_fused(data, sp, sides, detected) if len(sides) == 2 else None
-        if outs is None:     # one image (anchor cached), an image without lines, host tensors: image by image, described together
-            pres = [lt.preprocess(detected[s], data["image" + s].shape, sp[s], data["valid_mask" + s]) for s in sides]
+        outs = None
+        if len(sides) == 2 and tuple(data["image0"].shape) == tuple(data["image1"].shape):
+            auto_lengths(data["image0"].shape)                    # one shape: both images get the same two values
+            outs = self._describe_fused(data, sp, sides, detected)
+        if outs is None:     # one image (anchor cached), an image without lines, host tensors, two image sizes: tokenised image by
+            pres = []        # image, each with the thresholds of ITS shape (lt.config ends on the last image's, as in the reference)
+            for s in sides:
+                auto_lengths(data["image" + s].shape)
+                pres.append(lt.preprocess(detected[s], data["image" + s].shape, sp[s], data["valid_mask" + s]))
             outs = lt.forward_many(pres)
         for s, out in zip(sides, outs):
             pred.update({k + s: v for k, v in out.items()})
@@ -171,7 +181,7 @@ class Matching(torch.nn.Module):
         linetr_match call.  Returns a list of P dicts with the keys forward() produces, except that the dense
         per-token tensors (pnt/mask/desc/score_sublines) are not materialised.  Key-line order is forward()'s: the native
         pre-filter sorts, and images that hold equal lengths are ordered by NumPy's own argsort (Engine.prefilter, tie_order)."""
-        from .line_process import keylines_to_array
+        from .line_process import attach_sub2line, keylines_to_array
         lt = self.linetransformer
         P = len(pairs)
         if P == 0:
@@ -240,8 +250,7 @@ class Matching(torch.nn.Module):
             for s, img_i in (("0", 2 * p), ("1", 2 * p + 1)):
                 pred.update({key + s: v for key, v in sp_out[img_i].items()})
                 kk, nn = slice(int(cu_k[img_i]), int(cu_k[img_i + 1])), slice(int(cu_n[img_i]), int(cu_n[img_i + 1]))
-                A = A_flat[int(blk[img_i]):int(blk[img_i + 1])].view(int(k[img_i]), int(n[img_i]))[None]
-                A._linetr_sub2line = tb.sub2line[nn]
+                A = attach_sub2line(A_flat[int(blk[img_i]):int(blk[img_i + 1])].view(int(k[img_i]), int(n[img_i]))[None], tb.sub2line[nn])
                 pred.update({"klines" + s: tb.klines[None, kk], "length_klines" + s: tb.length[None, kk],
                              "angles" + s: tb.angles[None, kk], "sublines" + s: tb.sublines[None, nn],
                              "resp_sublines" + s: tb.resp[None, nn, None], "angle_sublines" + s: tb.angle_sub[None, nn],
@@ -268,22 +277,24 @@ class Matching(torch.nn.Module):
         if K0 == 0 or K1 == 0:
             return None
         # the matcher needs no weights: the weight-less engine serves it (no weight-version check on this call)
-        from .line_process import _token_engine
+        from .line_process import _token_engine, sub2line_of
         eng = _token_engine(line_desc0.device if line_desc0.is_cuda else self.linetransformer._device())
         dev = eng.device
-        d0 = line_desc0[0].to(dev).t()      # [N,256] rows: line_desc is a transposed view of exactly that, so no copy
-        d1 = line_desc1[0].to(dev).t()
-        # matrices made by this package's tokeniser carry their sub-line -> key-line map; any other (an anchor reloaded from
-        # an .npz, say) is reduced to it here
-        s0 = getattr(mat0, "_linetr_sub2line", None)
-        s1 = getattr(mat1, "_linetr_sub2line", None)
-        if s0 is None:
-            s0 = mat0[0].to(dev).argmax(dim=0).to(torch.int32)
-        if s1 is None:
-            s1 = mat1[0].to(dev).argmax(dim=0).to(torch.int32)
-        dk, _, m01 = eng.match(d0, np.array([0, N0]), s0, np.array([0, K0]), d1, np.array([0, N1]), s1,
-                               np.array([0, K1]), float(np.float32(thr)), True)
-        return dk, m01, K0, K1
+        # matrices made by this package's tokeniser carry their sub-line -> key-line map (valid while the matrix is unmodified)
+        s0, s1 = sub2line_of(mat0), sub2line_of(mat1)
+        if s0 is not None and s1 is not None:
+            d0 = line_desc0[0].to(dev).t()      # [N,256] rows: line_desc is a transposed view of exactly that, so no copy
+            d1 = line_desc1[0].to(dev).t()
+            dk, _, m01 = eng.match(d0, np.array([0, N0]), s0, np.array([0, K0]), d1, np.array([0, N1]), s1,
+                                   np.array([0, K1]), float(np.float32(thr)), True)
+            return dk, m01, K0, K1
+        # any other matrix (an anchor reloaded from an .npz, an edited one): the reference's three steps one by one, each native --
+        # D from the [256,N] descriptors as they are, the pooling from the matrices' CONTENTS (a tokeniser's matrix is recognised
+        # on the device, anything else is multiplied out as given), then the mutual-NN kernels
+        D, _ = eng.match_points(line_desc0[0].to(dev), line_desc1[0].to(dev), float("inf"), False)
+        dk = eng.pool_distmat_dense(D, mat0[0].to(dev), mat1[0].to(dev))
+        m01 = eng.match_distmat(dk, float(np.float32(thr)), True)
+        return dk.reshape(-1), m01, K0, K1
 
     def match_lines(self, line_desc0, mat0, line_desc1, mat1, thr):
         """(matches [1,K0,K1] float64, Dk [1,K0,K1] float32) as NumPy, like matching.py:77-84."""

@@ -73,6 +73,12 @@ def pack_descriptors(line_desc: torch.Tensor, cu_n, n_images_cap: int, rows_cap:
         from . import _native as nat
         ld = line_desc if (line_desc.dtype == torch.float32 and line_desc.is_contiguous()) else line_desc.float().contiguous()
         s2l = sub2line.to(torch.int32).contiguous() if sub2line is not None else None
+        # the kernel reads both prefix sums as contiguous int32 on `dev`: any other integer tensor is converted, never reinterpreted
+        i32 = lambda t: t if (t.dtype == torch.int32 and t.device == dev and t.is_contiguous()) else t.to(device=dev, dtype=torch.int32).contiguous()
+        d_cu_n = i32(d_cu_n)
+        d_cu_k = i32(d_cu_k) if d_cu_k is not None else None
+        if d_cu_n.numel() < n_img + 1 or (d_cu_k is not None and d_cu_k.numel() < n_img + 1):
+            raise ValueError("pack_descriptors: device prefix sums shorter than n_images + 1")
         with torch.cuda.device(dev):
             nat.check(nat.lib().linetr_pack_slab(ld.data_ptr(), N, d_cu_n.data_ptr(), d_cu_k.data_ptr() if d_cu_k is not None else None,
                                                  n_img, s2l.data_ptr() if s2l is not None else None, n_images_cap, rows_cap, 0,

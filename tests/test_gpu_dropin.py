@@ -100,6 +100,40 @@ def test_module_built_under_inference_mode_and_rebound_weights():
     eng = m2._engine
     m2(pre2)
     assert m2._engine is eng                       # nothing changed: the engine is kept
+    # a whole sub-module replaced after the first forward (its old parameter dicts stay intact): the engine must be rebuilt
+    conv = torch.nn.Conv1d(256, 256, kernel_size=1).to("cuda")
+    with torch.no_grad():
+        conv.weight.copy_(-m2.final_proj.weight)
+        conv.bias.copy_(-m2.final_proj.bias)
+    m2.final_proj = conv
+    out = m2(pre2)["line_desc"].clone()
+    assert m2._engine is not eng and torch.allclose(out, -flipped, atol=1e-6)
+    m2.register_buffer("unrelated", torch.zeros(1, device="cuda"))      # a new entry in a tracked dict: noticed as well
+    eng = m2._engine
+    m2(pre2)
+    assert m2._engine is not eng
+
+
+def test_valid_mask_of_another_shape_goes_through_numpy_indexing():
+    """The native pre-filter addresses an ndarray mask as [height, width]; any other shape must behave like the reference's NumPy
+    indexing (models/line_process.py:76-80): IndexError when an index is out of range, never an out-of-bounds read."""
+    g = load("tiny_validmask")
+    dd, ds, hw = tiny_maps(g)
+    sp = {"dense_descriptor": dd.cuda(), "dense_score": ds.cuda()}
+    m = make_lt()
+    kl = lambda: synth.array_to_keylines(g["lines"])
+    with pytest.raises(IndexError):
+        m.preprocess(kl(), (1, 1, *hw), sp, np.ones((1, 1, *hw)))            # 4-D like the tensor masks
+    with pytest.raises(IndexError):
+        m.preprocess(kl(), (1, 1, *hw), sp, np.ones((hw[0] // 2, hw[1] // 2)))
+    big = np.ones((hw[0] + 7, hw[1] + 9))                                      # larger: NumPy indexes it happily; so must we
+    big[:, :int(g["valid_mask_cols"])] = 0
+    out = m(m.preprocess(kl(), (1, 1, *hw), sp, big))
+    assert np.array_equal(out["klines"].cpu().numpy(), g["klines"])
+    from linetr_amd.engine import Engine
+    with pytest.raises(ValueError):
+        m.engine().prefilter([g["lines"]], *hw, remove_borders=8, min_length=16, max_keylines=-1, token_distance=8, max_tokens=21,
+                             valid_masks=[np.ones((3, 3))])
 
 
 class FakeSuperPoint(torch.nn.Module):
@@ -112,7 +146,7 @@ class FakeSuperPoint(torch.nn.Module):
 
     def forward(self, data):
         seed = self.seeds.pop(0)
-        dd, ds = synth.synth_dense_maps(seed, 480, 640)
+        dd, ds = synth.synth_dense_maps(seed, *data["image"].shape[-2:])
         rs = np.random.RandomState(seed)
         n = 50 + seed % 7
         desc = torch.from_numpy(rs.standard_normal((256, n)).astype(np.float32))
@@ -154,6 +188,31 @@ def test_matching_pipeline_outputs():
     # np.savez payload of match_line_pairs.py:94-104
     out = {k: v[0].cpu().numpy() for k, v in pred.items() if torch.is_tensor(v[0])}
     assert out["klines0"].shape == (199, 2, 2) and out["matches_l"].shape == (199, 199)
+
+
+def test_matching_pair_of_two_image_sizes_like_the_reference():
+    """models/matching.py:29-32 and :45-48: with auto_min_length, min_length / token_distance are recomputed for EACH image from that
+    image's own shape.  A 480 x 640 + 960 x 1280 pair against a golden of the real reference (tests/golden/make_golden_mixed.py):
+    every token tensor of both images bit for bit, descriptors <= 1e-4, matches_l identical, config left on image1's values."""
+    from models.matching import Matching
+    g = load("mixed_size_pair")
+    mt = Matching({"auto_min_length": True, "linetransformer": {**LT_CFG}},
+                  superpoint=FakeSuperPoint([int(g["map_seed0"]), int(g["map_seed1"])]), lsd=FakeLSD([g["lines0"], g["lines1"]]))
+    mt.linetransformer.load_state_dict(synth.to_torch_state_dict(synth.calibrated_state_dict()))
+    mt = mt.eval().to("cuda")
+    imgs = {s: torch.zeros(1, 1, *(int(v) for v in g["hw" + s]), device="cuda") for s in "01"}
+    pred = mt({"image0": imgs["0"], "image1": imgs["1"]})
+    assert float(g["min_length1"]) == 32.0 and float(g["token_distance1"]) == 16.0 and float(g["token_distance0"]) == 8.0
+    assert mt.linetransformer.config["min_length"] == float(g["final_min_length"])
+    assert mt.linetransformer.config["token_distance"] == float(g["final_token_distance"])
+    for s in "01":
+        for k in TOK_KEYS:
+            want, have = g[k + s], pred[k + s].cpu().numpy()
+            assert have.shape == want.shape, (k, s)
+            assert np.abs(have - want).max() <= (1.2e-7 if "angle" in k else 0), (k, s)
+        assert np.abs(pred["line_desc" + s].cpu().numpy() - g["line_desc" + s]).max() < 1e-4
+    assert np.array_equal(pred["matches_l"].numpy(), g["matches_l"]) and g["matches_l"].sum() > 0
+    assert np.abs(pred["matching_scores_l"].numpy() - g["matching_scores_l"]).max() < 1e-4
 
 
 def test_matching_forward_batch_equals_per_pair():

@@ -68,9 +68,11 @@ def test_scalar_helpers_and_sample_descriptors():
 
 
 def test_subline2keyline_pooled_natively_and_as_given():
-    """Matrices from this package's tokeniser are pooled by the matcher's segmented-mean kernel; a foreign matrix is multiplied
-    out as given (models/line_transformer.py:277-282)."""
+    """subline2keyline reads the matrices by their CONTENTS, on the device (linetr_pool_distmat_dense): a tokeniser's matrix is
+    reduced to its map and pooled by the matcher's segmented-mean kernel, anything else is multiplied out as given
+    (models/line_transformer.py:277-282).  No torch matmul behind it."""
     from models.line_transformer import LineTransformer
+    from linetr_amd.line_process import sub2line_of
     m = LineTransformer({"mode": "train", "max_keylines": -1, "min_length": 16, "token_distance": 8, "max_tokens": 3}).eval()
     m.load_state_dict(synth.to_torch_state_dict(synth.calibrated_state_dict()), strict=True)
     m = m.to("cuda")
@@ -79,15 +81,66 @@ def test_subline2keyline_pooled_natively_and_as_given():
         dd, ds = synth.synth_dense_maps(seed, 480, 640)
         pre.append(m.preprocess(synth.array_to_keylines(synth.synth_lines(seed, 60, 480, 640)), (1, 1, 480, 640),
                                 {"dense_descriptor": dd.cuda(), "dense_score": ds.cuda()}))
-    A0, A1 = pre[0]["mat_klines2sublines"][0], pre[1]["mat_klines2sublines"][0]
-    assert hasattr(pre[0]["mat_klines2sublines"], "_linetr_sub2line")
+    A0, A1 = pre[0]["mat_klines2sublines"][0], pre[1]["mat_klines2sublines"][0]      # what matching.py:80 passes
+    assert sub2line_of(pre[0]["mat_klines2sublines"]) is not None and sub2line_of(A0) is None
     assert (A0 > 0).sum(1).max() > 1, "max_tokens=3 must give multi-sub-line key-lines"
-    D = np.random.RandomState(1).rand(A0.shape[1], A1.shape[1]).astype(np.float32)
-    want = (A0.double().cpu().numpy() @ D.astype(np.float64) @ A1.double().cpu().numpy().T)[None]
-    native = m.subline2keyline(D, pre[0]["mat_klines2sublines"], pre[1]["mat_klines2sublines"])      # carries the map
-    plain = m.subline2keyline(D, A0.clone(), A1.clone())                                              # foreign tensors
-    assert native.shape == plain.shape == want.shape and native.dtype == np.float32
-    assert np.abs(native - want).max() < 1e-6 and np.abs(plain - want).max() < 1e-6
+    rs = np.random.RandomState(1)
+    D = rs.rand(A0.shape[1], A1.shape[1]).astype(np.float32)
+    ref = lambda a0, a1: (a0.double().cpu().numpy() @ D.astype(np.float64) @ a1.double().cpu().numpy().T)[None]
+    for a0, a1 in ((A0, A1), (A0.cpu(), A1.cpu())):                                  # device and host tensors alike
+        got = m.subline2keyline(D, a0, a1)
+        assert got.shape == (1, A0.shape[0], A1.shape[0]) and got.dtype == np.float32
+        assert np.abs(got - ref(a0, a1)).max() < 1e-6
+    # the segmented-mean kernel served the call above: its result equals the map-driven entry point's bit for bit
+    eng = m.engine()
+    want = eng.pool_distmat(torch.from_numpy(D).cuda(), sub2line_of(pre[0]["mat_klines2sublines"]), A0.shape[0],
+                            sub2line_of(pre[1]["mat_klines2sublines"]), A1.shape[0])
+    assert np.array_equal(m.subline2keyline(D, A0, A1)[0], want.cpu().numpy())
+    # matrices that are NOT a tokeniser's are multiplied out as given: a wrong weight, two non-zeros in a column, rows out of
+    # order, a key-line without sub-lines, a dense random matrix, more key-lines than sub-lines
+    B = A0.clone(); B[0, int(torch.nonzero(A0[0])[0])] *= 0.5
+    C2 = A0.clone(); C2[1, 0] = 0.25
+    Pm = A0.clone()[torch.randperm(A0.shape[0], generator=torch.Generator().manual_seed(0)).cuda()]
+    Z = A0.clone(); Z[3] = 0
+    R = torch.from_numpy(rs.standard_normal(tuple(A0.shape)).astype(np.float32)).cuda()
+    for a0 in (B, C2, Pm, Z, R):
+        assert np.abs(m.subline2keyline(D, a0, A1) - ref(a0, A1)).max() < 2e-5
+        assert np.abs(m.subline2keyline(D.T.copy(), A1, a0) - np.transpose(ref(a0, A1), (0, 2, 1))).max() < 2e-5
+    tall = torch.from_numpy(rs.standard_normal((A0.shape[1] + 5, A0.shape[1])).astype(np.float32)).cuda()
+    assert np.abs(m.subline2keyline(D, tall, A1) - ref(tall, A1)).max() < 2e-5
+    with pytest.raises(ValueError):
+        m.subline2keyline(D, A0[:, :-1], A1)
+
+
+def test_edited_matrix_is_matched_by_its_contents():
+    """A mat_klines2sublines written to after the tokeniser made it loses its attached map (version stamp): Matching.match_lines then
+    reads the matrix itself, like the reference's `A0 @ D @ A1.T` does (models/matching.py:77-84)."""
+    from models.matching import Matching
+    from linetr_amd.line_process import sub2line_of
+    from models.line_transformer import LineTransformer
+    m = LineTransformer({"mode": "train", "max_keylines": -1, "min_length": 16, "token_distance": 8, "max_tokens": 3,
+                         "nn_threshold": 0.8}).eval()
+    m.load_state_dict(synth.to_torch_state_dict(synth.calibrated_state_dict()), strict=True)
+    m = m.to("cuda")
+    outs = []
+    for seed in (31, 32):
+        dd, ds = synth.synth_dense_maps(seed, 480, 640)
+        outs.append(m(m.preprocess(synth.array_to_keylines(synth.synth_lines(seed, 50, 480, 640)), (1, 1, 480, 640),
+                                   {"dense_descriptor": dd.cuda(), "dense_score": ds.cuda()})))
+    mt = Matching.__new__(Matching)
+    torch.nn.Module.__init__(mt)
+    mt.linetransformer = m
+    args = lambda: (outs[0]["line_desc"], outs[0]["mat_klines2sublines"], outs[1]["line_desc"], outs[1]["mat_klines2sublines"], 0.8)
+    M_fast, Dk_fast = mt.match_lines(*args())
+    # same matrices without their maps (cloned: what an .npz reload gives): the contents path must agree exactly
+    a, b, c, d, thr = args()
+    M_slow, Dk_slow = mt.match_lines(a, b.clone(), c, d.clone(), thr)
+    assert np.array_equal(M_fast, M_slow) and np.array_equal(Dk_fast, Dk_slow)
+    # edit in place: key-line 0 of image 0 now ignores its sub-lines (row zeroed) -> Dk row 0 becomes 0, as A0 @ D @ A1^T says
+    outs[0]["mat_klines2sublines"][0, 0].zero_()
+    assert sub2line_of(outs[0]["mat_klines2sublines"]) is None
+    M_ed, Dk_ed = mt.match_lines(*args())
+    assert np.all(Dk_ed[0, 0] == 0) and np.abs(Dk_ed[0, 1:] - Dk_fast[0, 1:]).max() < 1e-6
 
 
 def test_pack_slab_kernel_equals_the_host_packing():
@@ -104,6 +157,11 @@ def test_pack_slab_kernel_equals_the_host_packing():
     got = parallel.pack_descriptors(ld.cuda(), cu_n, cap_img, cap_rows, out=out, cu_k=cu_k, sub2line=s2l.cuda(),
                                     d_cu_n=torch.from_numpy(cu_n).cuda(), d_cu_k=torch.from_numpy(cu_k).cuda())
     assert got.data_ptr() == out.data_ptr()
+    # prefix sums of another integer dtype / on the host / non-contiguous are converted, never reinterpreted
+    got64 = parallel.pack_descriptors(ld.cuda(), cu_n, cap_img, cap_rows, cu_k=cu_k, sub2line=s2l.cuda(),
+                                      d_cu_n=torch.from_numpy(cu_n.astype(np.int64)).cuda(),
+                                      d_cu_k=torch.from_numpy(np.repeat(cu_k, 2)).cuda()[::2])
+    assert torch.equal(got64, got)
     hr, mr = parallel.header_rows(cap_img), parallel.map_rows(cap_rows)
     g, w = got.cpu(), want
     assert torch.equal(g[:hr].view(torch.int32).view(-1)[:1 + 2 * cap_img], w[:hr].view(torch.int32).view(-1)[:1 + 2 * cap_img])

@@ -37,6 +37,27 @@ def test_cfg2_pair_tokenizer_forward_match():
     assert np.abs(Dk - g["pair_Dk"]).max() < 1e-5
 
 
+def test_mixed_size_pair_per_image_thresholds():
+    """A 480 x 640 + 960 x 1280 pair through the reference's Matching.forward line branch with auto_min_length (matching.py:29-32,
+    :45-48: thresholds per image; normalisation keeps the constructor's 480 x 640) -- tests/golden/make_golden_mixed.py."""
+    g = load("mixed_size_pair")
+    sd = synth.to_torch_state_dict(synth.calibrated_state_dict())
+    outs = []
+    for s in "01":
+        hw = tuple(int(v) for v in g["hw" + s])
+        dd, ds = synth.synth_dense_maps(int(g["map_seed" + s]), *hw)
+        cfg = dict(BASE_CFG, min_length=max(16, max(hw) / 40), token_distance=max(8, max(hw) / 80))
+        assert cfg["min_length"] == float(g["min_length" + s]) and cfg["token_distance"] == float(g["token_distance" + s])
+        out = oracle_image(sd, g["lines" + s], dd, ds, hw, cfg, image_shape=(480, 640))
+        for k in TOK_KEYS:
+            assert np.array_equal(out[k].numpy(), g[k + s]), (k, s)
+        assert np.abs(out["line_desc"].numpy() - g["line_desc" + s]).max() < DESC_TOL
+        outs.append(out)
+    M, Dk = O.match_lines(outs[0]["line_desc"], outs[1]["line_desc"], outs[0]["mat_klines2sublines"][0],
+                          outs[1]["mat_klines2sublines"][0], 0.8)
+    assert np.array_equal(M, g["matches_l"]) and np.abs(Dk - g["matching_scores_l"]).max() < 1e-5
+
+
 def test_jitter_pair_recovers_permutation():
     g = load("cfg2_jitter_pair")
     sd = synth.to_torch_state_dict(synth.calibrated_state_dict())

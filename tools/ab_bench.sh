@@ -2,7 +2,7 @@
 # Same-box A/B of bench.py under different environment settings:  tools/ab_bench.sh "NAME=ENV=1 ..." ...
 # each argument is "label:VAR=val,VAR2=val2" (label alone = default environment); prints value, ms/step and the kernel table.
 # Switches other than LINETR_PRECISION / LINETR_HOST_THREADS only exist in the experiments build: add
-# LINETR_LIB=linetr_amd/csrc/liblinetr_hip_experiments.so to the spec (and to the baseline, for a like-for-like A/B).
+# LINETR_LIB=experiments/liblinetr_hip_experiments.so to the spec (and to the baseline, for a like-for-like A/B).
 mkdir -p gpurun_out
 for spec in "$@"; do
   label="${spec%%:*}"; envs=""

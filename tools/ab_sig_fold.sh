@@ -2,7 +2,7 @@
 # Same-box A/B of the single-pair signature fold (SigLayer::Wnext: W2 + residual + the next q/k/v projection as one contraction):
 #   gpurun -- 'bash tools/ab_sig_fold.sh'      (experiments build: LINETR_NO_SIG_FOLD=1 switches it off)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-export LINETR_LIB=$PWD/linetr_amd/csrc/liblinetr_hip_experiments.so
+export LINETR_LIB=$PWD/experiments/liblinetr_hip_experiments.so
 for rep in 1 2 3; do for mode in fold nofold; do
   if [ $mode = nofold ]; then export LINETR_NO_SIG_FOLD=1; else unset LINETR_NO_SIG_FOLD; fi
   python bench.py --workload cfg2 --steps 200 --warmup 20 --settle-s 1 --no-cpu-baseline --no-sub-workloads 2>/dev/null | tail -1 > gpurun_out/ab_fold_$mode.json

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-LINETR_LIB=$PWD/linetr_amd/csrc/liblinetr_hip_experiments.so LINETR_PROFILE_SHAPES=1 timeout 300 python bench.py --workload cfg5 --pairs 8 --dense-layout nhwc --steps 10 --no-cpu-baseline --no-sub-workloads > gpurun_out/r04x_cfg5_shapes.json 2> gpurun_out/r04x_cfg5_shapes.log
+LINETR_LIB=$PWD/experiments/liblinetr_hip_experiments.so LINETR_PROFILE_SHAPES=1 timeout 300 python bench.py --workload cfg5 --pairs 8 --dense-layout nhwc --steps 10 --no-cpu-baseline --no-sub-workloads > gpurun_out/r04x_cfg5_shapes.json 2> gpurun_out/r04x_cfg5_shapes.log
 python - gpurun_out/r04x_cfg5_shapes.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -2,7 +2,7 @@
 import torch, time, sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 # tuning switches and the non-shipped kernels live in the experiments build of the library
-os.environ.setdefault("LINETR_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "linetr_amd", "csrc", "liblinetr_hip_experiments.so"))
+os.environ.setdefault("LINETR_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "experiments", "liblinetr_hip_experiments.so"))
 from workloads import synth
 from linetr_amd.engine import Engine
 eng = Engine(synth.make_state_dict(0), 'cuda:0'); eng.set_precision(sys.argv[1] if len(sys.argv) > 1 else 'bf16x6')

@@ -9,11 +9,14 @@ has() { [[ " $stages " == *" $1 "* ]]; }
 if has tests; then
   timeout 900 python -m pytest tests -m gpu -q --maxfail=12 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -4 ${O}_pytest.log
 fi
+if has xtests; then   # the measured-and-rejected kernels (experiments/): their own marker, their own library
+  timeout 600 python -m pytest experiments -m experiments -q > ${O}_pytest_experiments.log 2>&1; echo "experiments rc=$?"; tail -3 ${O}_pytest_experiments.log
+fi
 if has bench; then
   timeout 600 python bench.py --steps 20 --warmup 5 > ${O}_bench.json 2> ${O}_bench.log; echo "bench rc=$?"; cut -c1-900 ${O}_bench.json
 fi
 if has shapes; then   # per-GEMM-shape HIP-event profile of the cfg3 step
-  LINETR_LIB=$PWD/linetr_amd/csrc/liblinetr_hip_experiments.so LINETR_PROFILE_SHAPES=1 timeout 300 python bench.py --steps 10 --no-cpu-baseline --no-sub-workloads > ${O}_bench_shapes.json 2> ${O}_bench_shapes.log
+  LINETR_LIB=$PWD/experiments/liblinetr_hip_experiments.so LINETR_PROFILE_SHAPES=1 timeout 300 python bench.py --steps 10 --no-cpu-baseline --no-sub-workloads > ${O}_bench_shapes.json 2> ${O}_bench_shapes.log
   python - ${O}_bench_shapes.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))

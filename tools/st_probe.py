@@ -7,7 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 # tuning switches and the non-shipped kernels live in the experiments build of the library
-os.environ.setdefault("LINETR_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "linetr_amd", "csrc", "liblinetr_hip_experiments.so"))
+os.environ.setdefault("LINETR_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "experiments", "liblinetr_hip_experiments.so"))
 from workloads import synth
 from linetr_amd.engine import Engine
 
