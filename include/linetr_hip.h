@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LINETR_ABI_VERSION 3
+#define LINETR_ABI_VERSION 4
 
 enum {
   LINETR_OK = 0,
@@ -49,6 +49,9 @@ typedef struct {
   int32_t enc_channels[4];  /* keyline_encoder = {32,64,128,256}                            */
   int32_t norm_height;      /* constructor-time image_shape used by normalize_keylines      */
   int32_t norm_width;       /* (models/line_transformer.py:206,:238)                        */
+  int32_t bn_batch_stats;   /* 0: BatchNorm(eval) folded into the convolutions (inference).  1: a TRAINING-mode handle      */
+                            /* (train.py:127 -> model.train()): the convolutions stay unfolded and only                      */
+                            /* linetr_forward_train may run on it                                                            */
 } LinetrModelConfig;
 
 /* One key-line after pre-filtering (float64 geometry exactly as the reference keeps it in NumPy). */
@@ -160,12 +163,14 @@ int64_t linetr_tokenize_workspace_bytes(int32_t n_images, int32_t height, int32_
  * the clipped end points are what `out.klines` holds (reference quirk: it mutates through a view).
  * d_sub2line [N] int32 (key-line index of every sub-line INSIDE ITS IMAGE, non-decreasing per image)
  * is written for linetr_match.  `out.desc` may be NULL to skip descriptor sampling.  `h` may be NULL (no weights are
- * involved; the current HIP device is used). */
+ * involved; the current HIP device is used).  clip_height / clip_width: the `image_shape` ARGUMENT of line_tokenizer
+ * (models/line_process.py:101), which only sets the end-point clip (:115-116) and need not be the maps' shape -- the dataset
+ * builder passes (640, 480) for 480 x 640 images (dataloaders/utils/util_lines.py:682,703); <= 0 = height / width. */
 int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N,
                     double token_distance, int32_t max_tokens, const float* d_dense_desc,
                     const float* d_dense_score, int32_t n_images, int32_t height, int32_t width,
-                    int32_t align_corners, int32_t dense_is_nhwc, LinetrTokens out, int32_t* d_sub2line,
-                    void* d_workspace, int64_t workspace_bytes, void* stream);
+                    int32_t clip_height, int32_t clip_width, int32_t align_corners, int32_t dense_is_nhwc,
+                    LinetrTokens out, int32_t* d_sub2line, void* d_workspace, int64_t workspace_bytes, void* stream);
 
 /* sample_descriptors (models/line_process.py:86-98) on its own, for the module-level function of the shim: n points
  * d_points [n,2] (x,y in pixels) of ONE image sampled bilinearly (zero padding) from its dense descriptor map
@@ -190,6 +195,22 @@ int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const int32_t* h_cu
                    int64_t workspace_bytes, void* stream);
 
 /* ---- device: fused tokenise + describe (batched fast path) ---------------------------------------- */
+
+/* Training-time forward (train.py:127,163-164: model.train(); pred = model(data) on a batch of B fixed-size samples): the same
+ * network as linetr_forward with every BatchNorm1d of the three MLP stacks (models/line_transformer.py:9-20: 4 in
+ * WordPositionalEncoder, 4 in LinePositionalEncoder, 1 per AttentionalPropagation) in TRAINING mode -- normalised with the mean and
+ * biased variance of this batch (over all B*N*T token positions / B*N sub-lines), running statistics moved by `momentum` towards
+ * the batch mean / UNBIASED variance.  Dropout (models/line_attention.py:11,39,84) is taken at probability 0: the caller has to
+ * make sure of that (the Python surface refuses otherwise); no gradients are produced.
+ * `h` must have been created with bn_batch_stats = 1.  The images of the batch are the n_images entries of h_cu_sub, as in
+ * linetr_forward.  d_bn_running (in/out) and d_bn_batch (out, may be NULL) are packed per BatchNorm layer, in state_dict order --
+ * word encoder 1,4,7,10 | line encoder 1,4,7,10 | selfattn.layers.l.mlp.1 --, each layer as mean[C] | var[C]; d_bn_batch
+ * receives the batch mean | biased variance.  linetr_bn_stats_floats() = the length of both arrays. */
+int64_t linetr_bn_stats_floats(const LinetrHandle* h);
+int64_t linetr_forward_train_workspace_bytes(const LinetrHandle* h, int32_t N, int32_t max_tokens);
+int linetr_forward_train(LinetrHandle* h, const LinetrTokens* tok, const int32_t* h_cu_sub, const int32_t* d_cu_sub,
+                         int32_t n_images, int32_t max_tokens, float momentum, float* d_bn_running, float* d_bn_batch,
+                         float* d_line_desc, void* d_workspace, int64_t workspace_bytes, void* stream);
 
 int64_t linetr_describe_workspace_bytes(const LinetrHandle* h, int32_t n_images, int32_t height, int32_t width,
                                         int32_t N, int64_t n_real_tokens);

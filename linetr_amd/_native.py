@@ -21,7 +21,7 @@ E_ASSERT = -4
 class ModelConfig(C.Structure):
     _fields_ = [("d_model", C.c_int32), ("n_heads", C.c_int32), ("d_inner", C.c_int32),
                 ("n_sig_layers", C.c_int32), ("n_desc_layers", C.c_int32), ("enc_channels", C.c_int32 * 4),
-                ("norm_height", C.c_int32), ("norm_width", C.c_int32)]
+                ("norm_height", C.c_int32), ("norm_width", C.c_int32), ("bn_batch_stats", C.c_int32)]
 
 
 class LineRec(C.Structure):
@@ -83,10 +83,15 @@ def lib(path=None):
                                   vp, i64, vp]
     L.linetr_tokenize_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.linetr_tokenize_workspace_bytes.restype = i64
-    L.linetr_tokenize.argtypes = [vp, vp, i32, i32, f64, i32, vp, vp, i32, i32, i32, i32, i32, Tokens, vp, vp, i64, vp]
+    L.linetr_tokenize.argtypes = [vp, vp, i32, i32, f64, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, Tokens, vp, vp, i64, vp]
     L.linetr_forward_workspace_bytes.argtypes = [vp, i32, i32]
     L.linetr_forward_workspace_bytes.restype = i64
     L.linetr_forward.argtypes = [vp, C.POINTER(Tokens), vp, vp, i32, i32, vp, vp, i64, vp]
+    L.linetr_bn_stats_floats.argtypes = [vp]
+    L.linetr_bn_stats_floats.restype = i64
+    L.linetr_forward_train_workspace_bytes.argtypes = [vp, i32, i32]
+    L.linetr_forward_train_workspace_bytes.restype = i64
+    L.linetr_forward_train.argtypes = [vp, C.POINTER(Tokens), vp, vp, i32, i32, f32, vp, vp, vp, vp, i64, vp]
     L.linetr_match_workspace_bytes.argtypes = [i32, i64, i64, i64]
     L.linetr_match_workspace_bytes.restype = i64
     L.linetr_match.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, i64, vp]
@@ -121,7 +126,7 @@ def lib(path=None):
     L.linetr_pool_distmat_dense.argtypes = [vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, i64, vp]
     L.linetr_set_profiling.argtypes = [vp, i32]
     L.linetr_get_profile.argtypes = [vp, C.POINTER(ProfileEntry), i32, C.POINTER(i32)]
-    if L.linetr_abi_version() != 3:
+    if L.linetr_abi_version() != 4:
         raise RuntimeError("liblinetr_hip.so ABI version mismatch")
     _libs[path] = L
     return L
@@ -129,7 +134,7 @@ def lib(path=None):
 
 EXPORTS = ["linetr_abi_version", "linetr_last_error", "linetr_create", "linetr_destroy", "linetr_prefilter",
            "linetr_prefilter_batch", "linetr_prefilter_tied_images", "linetr_pack_lines", "linetr_tokenize_workspace_bytes", "linetr_tokenize", "linetr_forward_workspace_bytes",
-           "linetr_forward", "linetr_describe_workspace_bytes", "linetr_describe", "linetr_match_workspace_bytes", "linetr_match", "linetr_match_gathered", "linetr_match_points",
+           "linetr_forward", "linetr_bn_stats_floats", "linetr_forward_train_workspace_bytes", "linetr_forward_train", "linetr_describe_workspace_bytes", "linetr_describe", "linetr_match_workspace_bytes", "linetr_match", "linetr_match_gathered", "linetr_match_points",
            "linetr_match_distmat", "linetr_match_distmat_workspace_bytes", "linetr_superpoint_heads", "linetr_set_precision", "linetr_get_precision", "linetr_debug_posenc", "linetr_debug_gemm", "linetr_allgather_desc", "linetr_set_allgather_fn", "linetr_pack_slab", "linetr_sample_descriptors_workspace_bytes",
            "linetr_sample_descriptors", "linetr_pool_distmat_workspace_bytes", "linetr_pool_distmat", "linetr_pool_distmat_dense_workspace_bytes", "linetr_pool_distmat_dense", "linetr_set_profiling", "linetr_get_profile"]
 

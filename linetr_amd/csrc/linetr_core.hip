@@ -173,6 +173,12 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
     gemm_w.push_back({dst, rows, K, st});
   };
 
+  // training-mode handle: gamma / beta of the 8 + n_sig_layers BatchNorm layers (the vectors are sized up front: place() keeps
+  // pointers to their elements until the arena is uploaded)
+  int bn_slot = 0;
+  if (cfg->bn_batch_stats) {
+    H->bn_g.reserve(8 + cfg->n_sig_layers); H->bn_b.reserve(8 + cfg->n_sig_layers); H->bn_c.reserve(8 + cfg->n_sig_layers);
+  }
   // ---- positional encoders: 4 x (conv + BN + ReLU) + linear ------------------------------------
   const int ch_w[6] = {3, e0, e1, e2, e3, D}, ch_l[6] = {5, e0, e1, e2, e3, D};
   std::vector<double> W5w, b5w;  // last (linear) layer of the word encoder, consumed algebraically
@@ -193,6 +199,12 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
       const float* va = tm.get(bn + ".running_var", ch[i + 1], err);
       if (err) return err;
       std::vector<double> Wf, bf;
+      if (cfg->bn_batch_stats) {     // training-mode handle: the convolution as it is, BatchNorm applied by lt_bntrain.h
+        Wf = to_d(W, (size_t)ch[i + 1] * ch[i]); bf = to_d(b, ch[i + 1]);
+        H->bn_g.push_back(nullptr); H->bn_b.push_back(nullptr); H->bn_c.push_back(ch[i + 1]);
+        place(&H->bn_g[bn_slot], to_d(g, ch[i + 1])); place(&H->bn_b[bn_slot], to_d(be, ch[i + 1]));
+        ++bn_slot;
+      } else
       fold_bn(W, b, g, be, mu, va, ch[i + 1], ch[i], Wf, bf);
       // layers 2-4 also get split-tile images: the one-kernel MLP of lt_tokmlp.h keeps layers 2 / 3 in LDS and layer 4 in registers as
       // such, and the weight-stationary GEMM of lt_gemm_ws.h reads layer 4's planes from one
@@ -325,6 +337,12 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
       for (int h = 0; h < HEADS; ++h)
         for (int d = 0; d < DH; ++d) Wm2[(size_t)o * D + h * DH + d] = Wm[o * D + d * HEADS + h];
     std::vector<double> W1f, b1f;
+    if (cfg->bn_batch_stats) {
+      W1f = to_d(W1, (size_t)4 * D * D); b1f = to_d(b1, 2 * D);
+      H->bn_g.push_back(nullptr); H->bn_b.push_back(nullptr); H->bn_c.push_back(2 * D);
+      place(&H->bn_g[bn_slot], to_d(g, 2 * D)); place(&H->bn_b[bn_slot], to_d(be, 2 * D));
+      ++bn_slot;
+    } else
     fold_bn(W1, b1, g, be, mu, va, 2 * D, 2 * D, W1f, b1f);
     // fold the attention's merge conv into the MLP's first layer (both linear, nothing in between):
     //   W1 [x ; Wm a + bm] + b1 = W1a x + (W1b Wm) a + (W1b bm + b1)            (line_transformer.py:154,:166)

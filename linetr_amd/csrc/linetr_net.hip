@@ -24,6 +24,7 @@
 #include "lt_attn_st.h"
 #endif
 #include "lt_token.h"
+#include "lt_bntrain.h"
 
 using namespace lt;
 
@@ -333,9 +334,13 @@ extern "C" int64_t linetr_tokenize_workspace_bytes(int32_t n_images, int32_t hei
 
 extern "C" int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N, double td,
                                int32_t T, const float* d_dense_desc, const float* d_dense_score, int32_t n_images,
-                               int32_t height, int32_t width, int32_t align_corners, int32_t dense_is_nhwc,
-                               LinetrTokens out, int32_t* d_sub2line, void* d_ws, int64_t ws_bytes, void* stream) {
+                               int32_t height, int32_t width, int32_t clip_height, int32_t clip_width, int32_t align_corners,
+                               int32_t dense_is_nhwc, LinetrTokens out, int32_t* d_sub2line, void* d_ws, int64_t ws_bytes,
+                               void* stream) {
   if (K <= 0 || N <= 0) return LINETR_OK;
+  if (clip_height <= 0) clip_height = height;
+  if (clip_width <= 0) clip_width = width;
+  const double clip_x = (double)clip_width - 0.6, clip_y = (double)clip_height - 0.6;
   if (!d_recs || !d_dense_score || !out.sublines || !out.pnt || !out.mask || !out.resp || !out.angle_sub ||
       !out.score || (out.desc && !d_dense_desc))
     return fail(LINETR_E_ARG, "tokenize: null pointer");
@@ -352,15 +357,15 @@ extern "C" int linetr_tokenize(LinetrHandle* h, const LinetrLineRec* d_recs, int
   int* s2l_g = (int*)((char*)d_ws + align_up((int64_t)n_images * P * D * 4, 256));
   {
     ProfScope ps(h, st, "line_fill", 0, (double)K * 80 + (double)N * 8);
-    hipLaunchKernelGGL(line_fill_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, d_recs, K, (double)width - 0.6,
-                       (double)height - 0.6, out.klines, out.length, out.angles, s2l_g, d_sub2line);
+    hipLaunchKernelGGL(line_fill_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, d_recs, K, clip_x, clip_y, out.klines, out.length,
+                       out.angles, s2l_g, d_sub2line);
     LT_LAUNCH_CHECK();
   }
   {
     ProfScope ps(h, st, "tokenize", 0, (double)N * T * 16);
     // (with out.mat: K more blocks write the rows of mat_klines2sublines in the same launch)
     hipLaunchKernelGGL(tokenize_kernel, dim3(N + (out.mat ? K : 0)), dim3(64), 0, st, d_recs, s2l_g, N, td, T, height, width,
-                       d_dense_score, out.sublines, out.pnt, out.mask, out.resp, out.angle_sub, out.score, (float*)nullptr,
+                       clip_x, clip_y, d_dense_score, out.sublines, out.pnt, out.mask, out.resp, out.angle_sub, out.score, (float*)nullptr,
                        (float*)nullptr, 0, (int64_t)0, out.mat, k2s);
     LT_LAUNCH_CHECK();
   }
@@ -480,6 +485,7 @@ struct TokenStage {            // how the token stage (word MLP + CLS pooling) i
   int64_t first_pad = 0;
   int Hc = 0, Wc = 0, align_corners = 0;
   bool use_side = false;       // h->side carries the NHWC transpose (ev_nhwc) and may take the line-position MLP
+  const BnTrain* bn = nullptr; // training-time forward (linetr_forward_train): BatchNorm on batch statistics, convolutions unfolded
 };
 
 bool fused_mlp_enabled(const LinetrModelConfig& c) {
@@ -596,6 +602,39 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     aml.W4st = st_of(h->lW4); aml.b4 = h->lb4; aml.Y = w.l4; aml.ldy = e3;
   }
   bool line_done = false;
+  if (ts.bn) {
+    // training mode (train.py:127): conv -> BatchNorm(batch statistics) -> ReLU, layer by layer, on the unfolded convolutions of a
+    // bn_batch_stats handle.  Statistics run over ALL rows of the batch: B*N*T token positions (padding tokens included, as the
+    // reference's [B*N, 3, T] input has them) for the word encoder, B*N sub-lines for the line encoder.
+    const BnTrain& bt = *ts.bn;
+    int64_t off = 0;
+    auto bn = [&](int layer, float* zbuf, int64_t r, int C) {
+      const int64_t o = off; off += 2 * C;
+      return bn_train_layer(st, bt, zbuf, r, C, C, h->bn_g[layer], h->bn_b[layer], o);
+    };
+    hipLaunchKernelGGL(word_mlp1_kernel<false>, dim3((unsigned)cdiv((int)(rows * 8), 256)), dim3(256), 0, st, ts.pnt, ts.score, rows,
+                       cx, cy, scale, h->wW1, h->wb1, w.a1);
+    LT_LAUNCH_CHECK();
+    bn(0, w.a1, rows, e0);
+    if ((e = run_gemm(h, st, w.a1, e0, nullptr, 0, 0, h->wW2, h->wb2, nullptr, 0, w.a2, e1, (int)rows, e1, e0, ACT_NONE))) return e;
+    bn(1, w.a2, rows, e1);
+    if ((e = run_gemm(h, st, w.a2, e1, nullptr, 0, 0, h->wW3, h->wb3, nullptr, 0, w.a3, e2, (int)rows, e2, e1, ACT_NONE))) return e;
+    bn(2, w.a3, rows, e2);
+    if ((e = run_gemm(h, st, w.a3, e2, nullptr, 0, 0, h->wW4, h->wb4, nullptr, 0, w.a4, e3, (int)rows, e3, e2, ACT_NONE))) return e;
+    bn(3, w.a4, rows, e3);
+    hipLaunchKernelGGL(line_mlp1_kernel<false>, dim3(cdiv(N * 8, 256)), dim3(256), 0, st, sublines, resp, angle_sub, N, cx, cy, scale,
+                       h->lW1, h->lb1, w.l1);
+    LT_LAUNCH_CHECK();
+    bn(4, w.l1, N, e0);
+    if ((e = run_gemm(h, st, w.l1, e0, nullptr, 0, 0, h->lW2, h->lb2, nullptr, 0, w.l2, e1, N, e1, e0, ACT_NONE))) return e;
+    bn(5, w.l2, N, e1);
+    if ((e = run_gemm(h, st, w.l2, e1, nullptr, 0, 0, h->lW3, h->lb3, nullptr, 0, w.l3, e2, N, e2, e1, ACT_NONE))) return e;
+    bn(6, w.l3, N, e2);
+    if ((e = run_gemm(h, st, w.l3, e2, nullptr, 0, 0, h->lW4, h->lb4, nullptr, 0, w.l4, e3, N, e3, e2, ACT_NONE))) return e;
+    bn(7, w.l4, N, e3);
+    LT_LAUNCH_CHECK();
+    line_done = true;
+  } else
   // both encoders in ONE launch: side by side for a small batch, one after the other inside every persistent block for a large one
   if (tok_mlp && line_mlp && !ts.use_side && rows > 0 && N > 0 && !LT_XENV("LINETR_NO_DUAL_MLP")) {
     ProfScope ps(h, st, "pos_mlp_dual_bf16x6", 2.0 * rows * (3 * e0 + e0 * e1 + e1 * e2 + e2 * e3) + 2.0 * N * (5 * e0 + e0 * e1 + e1 * e2 + e2 * e3),
@@ -618,7 +657,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   } else {
     {
       ProfScope ps(h, st, "mlp_first", 2.0 * rows * 3 * e0, (double)rows * (12 + 4 * e0));
-      hipLaunchKernelGGL(word_mlp1_kernel, dim3((unsigned)cdiv((int)(rows * 8), 256)), dim3(256), 0, st,
+      hipLaunchKernelGGL(word_mlp1_kernel<true>, dim3((unsigned)cdiv((int)(rows * 8), 256)), dim3(256), 0, st,
                          ts.cpnt ? ts.cpnt : ts.pnt, ts.cpnt ? ts.cscore : ts.score, rows, cx, cy, scale, h->wW1, h->wb1, w.a1);
       LT_LAUNCH_CHECK();
     }
@@ -643,7 +682,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   } else {
     {
       ProfScope ps(h, ls, "mlp_first", 2.0 * N * 5 * e0, (double)N * (28 + 4 * e0));
-      hipLaunchKernelGGL(line_mlp1_kernel, dim3(cdiv(N * 8, 256)), dim3(256), 0, ls, sublines, resp, angle_sub, N, cx, cy,
+      hipLaunchKernelGGL(line_mlp1_kernel<true>, dim3(cdiv(N * 8, 256)), dim3(256), 0, ls, sublines, resp, angle_sub, N, cx, cy,
                          scale, h->lW1, h->lb1, w.l1);
       LT_LAUNCH_CHECK();
     }
@@ -744,6 +783,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     return sig_network_st(h, st, w, h_cu, cu_dev, n_images, N, max_n, d_line_desc);
 #endif
   const int qtiles = cdiv(max_n, ATT_QT);
+  const int64_t sig_bn_off = 4 * (int64_t)(e0 + e1 + e2 + e3);   // the signature layers' slots behind the two encoders' in the packed statistics
   // layers but the last: W1 -> ReLU -> W2 + residual in one kernel, hidden activations in registers (lt_mlp_fused.h)
 #ifdef LINETR_EXPERIMENTS
   const bool fused_sig_mlp = h->precision != LINETR_PREC_F32 && N >= 4096 && !LT_XENV("LINETR_NO_FUSED_SIG_MLP") &&
@@ -771,7 +811,8 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
         hipLaunchKernelGGL(sig_attn_small_kernel, dim3(n_images, HEADS, cdiv(max_n, 32)), dim3(256), 0, st, qkv_in, cu_dev, w.msgp, ldq);
         LT_LAUNCH_CHECK();
       }
-      if ((e = run_gemm(h, st, zc, ldz, w.msgp, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ACT_RELU))) return e;
+      if ((e = run_gemm(h, st, zc, ldz, w.msgp, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ts.bn ? ACT_NONE : ACT_RELU))) return e;
+      if (ts.bn) bn_train_layer(st, *ts.bn, w.hid, N, 2 * D, 2 * D, h->bn_g[8 + l], h->bn_b[8 + l], sig_bn_off + (int64_t)l * 4 * D);
       if (l + 1 == h->sig.size()) break;
       if ((e = run_gemm(h, st, zc, ldz, w.hid, 2 * D, D, S.Wnext, S.bnext, nullptr, 0, zq, 4 * D, N, 4 * D, 3 * D, ACT_NONE))) return e;
       zc = zq; ldz = 4 * D; qkv_in = zq + D; ldq = 4 * D;
@@ -855,7 +896,8 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
       continue;
     }
 #endif
-    if ((e = run_gemm(h, st, z, D, w.msgp, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ACT_RELU))) return e;
+    if ((e = run_gemm(h, st, z, D, w.msgp, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ts.bn ? ACT_NONE : ACT_RELU))) return e;
+    if (ts.bn) bn_train_layer(st, *ts.bn, w.hid, N, 2 * D, 2 * D, h->bn_g[8 + l], h->bn_b[8 + l], sig_bn_off + (int64_t)l * 4 * D);
     if (l + 1 == h->sig.size()) break;   // the last layer's second MLP GEMM is folded into the final projection below
     if ((e = run_gemm(h, st, w.hid, 2 * D, nullptr, 0, 0, S.W2, S.b2, z, D, zn, D, N, D, 2 * D, ACT_NONE))) return e;
     std::swap(z, zn);
@@ -891,6 +933,7 @@ extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const in
                               int32_t n_images, int32_t T, float* d_line_desc, void* d_ws, int64_t ws_bytes,
                               void* stream) {
   if (!h || !tok) return fail(LINETR_E_ARG, "forward: null argument");
+  if (h->cfg.bn_batch_stats) return fail(LINETR_E_ARG, "forward: a training-mode handle (bn_batch_stats = 1) runs linetr_forward_train only");
   if (int e = check_cu(h_cu, n_images)) return e;
   const int N = h_cu[n_images];
   if (N <= 0) return LINETR_OK;
@@ -916,6 +959,51 @@ extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const in
   const int e = forward_core(h, st, ts, tok->sublines, tok->resp, tok->angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);
   if (e && ts.use_side) join_side_after_error(h, st);
   return e;
+}
+
+// Training-time forward (train.py:127,163-164): linetr_forward's dense token path with BatchNorm on batch
+// statistics (lt_bntrain.h).  The workspace is linetr_forward's plus the statistics scratch.
+extern "C" int64_t linetr_bn_stats_floats(const LinetrHandle* h) {
+  if (!h) return -1;
+  const LinetrModelConfig& c = h->cfg;
+  return 4 * (int64_t)(c.enc_channels[0] + c.enc_channels[1] + c.enc_channels[2] + c.enc_channels[3]) + (int64_t)c.n_sig_layers * 4 * D;
+}
+
+extern "C" int64_t linetr_forward_train_workspace_bytes(const LinetrHandle* h, int32_t N, int32_t T) {
+  if (!h) return -1;
+  return linetr_forward_workspace_bytes(h, N, T) + (int64_t)BN_MAX_BLOCKS * 2 * 512 * 8 + 2 * 512 * 4 + 512;
+}
+
+extern "C" int linetr_forward_train(LinetrHandle* h, const LinetrTokens* tok, const int32_t* h_cu, const int32_t* d_cu, int32_t n_images,
+                                    int32_t T, float momentum, float* d_bn_running, float* d_bn_batch, float* d_line_desc, void* d_ws,
+                                    int64_t ws_bytes, void* stream) {
+  if (!h || !tok) return fail(LINETR_E_ARG, "forward_train: null argument");
+  if (!h->cfg.bn_batch_stats) return fail(LINETR_E_ARG, "forward_train: the handle was created for inference (bn_batch_stats = 0)");
+  if (!d_bn_running) return fail(LINETR_E_ARG, "forward_train: null running statistics");
+  if (!(momentum >= 0.f && momentum <= 1.f)) return fail(LINETR_E_ARG, "forward_train: momentum out of [0, 1]");
+  if (int e = check_cu(h_cu, n_images)) return e;
+  const int N = h_cu[n_images];
+  if (N <= 0) return LINETR_OK;
+  if (!tok->sublines || !tok->pnt || !tok->resp || !tok->angle_sub || !tok->desc || !tok->score || !d_line_desc)
+    return fail(LINETR_E_ARG, "forward_train: null tensor");
+  if (ws_bytes < linetr_forward_train_workspace_bytes(h, N, T)) return fail(LINETR_E_WORKSPACE, "forward_train: workspace too small");
+  if ((int64_t)N * T > INT32_MAX / 8) return fail(LINETR_E_ARG, "forward_train: batch too large");
+  hipStream_t st = (hipStream_t)stream;
+  LT_HIP(hipSetDevice(h->device));
+  FwdWs w = fwd_layout(h, N, (int64_t)N * T, std::max(N, 1), (char*)d_ws);
+  BnTrain bt;
+  bt.running = d_bn_running; bt.batch = d_bn_batch; bt.momentum = momentum;
+  bt.partial = (double*)((char*)d_ws + align_up(w.total, 256));
+  bt.affine = (float*)((char*)bt.partial + (int64_t)BN_MAX_BLOCKS * 2 * 512 * 8);
+  const int* cu_dev = d_cu;
+  if (!cu_dev) {
+    LT_HIP(hipMemcpyAsync(w.cu, h_cu, (n_images + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    cu_dev = w.cu;
+  }
+  TokenStage ts;
+  ts.pnt = tok->pnt; ts.score = tok->score; ts.desc = tok->desc; ts.rows = (int64_t)N * T;
+  ts.bn = &bt;
+  return forward_core(h, st, ts, tok->sublines, tok->resp, tok->angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);
 }
 
 // =============================================================================================
@@ -956,6 +1044,7 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
                                int32_t align_corners, int32_t dense_is_nhwc, LinetrTokens out, int32_t* d_sub2line,
                                float* d_line_desc, void* d_ws, int64_t ws_bytes, void* stream) {
   if (!h) return fail(LINETR_E_ARG, "describe: null handle");
+  if (h->cfg.bn_batch_stats) return fail(LINETR_E_ARG, "describe: a training-mode handle (bn_batch_stats = 1) runs linetr_forward_train only");
   if (int e = check_cu(h_cu, n_images)) return e;
   if (h_cu[n_images] != N) return fail(LINETR_E_ARG, "describe: cu_sub does not end at N");
   if (K <= 0 || N <= 0) return LINETR_OK;
@@ -1005,7 +1094,8 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
     ProfScope ps(h, st, "tokenize", 0, (double)n_real * 16);
     // (the last cdiv(n_images, 64) blocks write the per-image padding rows of the compact token list)
     hipLaunchKernelGGL(tokenize_kernel, dim3(N + cdiv(n_images, 64) + (out.mat ? K : 0)), dim3(64), 0, st, d_recs, dw.s2l_g, N, td, T,
-                       height, width, d_dense_score, sublines, out.pnt, out.mask, resp, angle_sub, out.score, dw.cpnt, dw.cscore,
+                       height, width, (double)width - 0.6, (double)height - 0.6, d_dense_score, sublines, out.pnt, out.mask, resp,
+                       angle_sub, out.score, dw.cpnt, dw.cscore,
                        n_images, (int64_t)n_real, out.mat, k2s);
     LT_LAUNCH_CHECK();
   }

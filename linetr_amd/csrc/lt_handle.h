@@ -39,6 +39,10 @@ struct LinetrHandle {
   lt::ClsPoolConst pool;
   const float *Watt, *batt, *Wfc, *bfc, *ln1g, *ln1b, *Wf1, *bf1, *Wf2, *bf2, *ln2g, *ln2b;
   std::vector<SigLayer> sig;
+  // training-mode handle (cfg.bn_batch_stats): gamma / beta / channel count of every BatchNorm layer, in the order of the packed
+  // statistics arrays of linetr_forward_train (word encoder x4, line encoder x4, one per signature layer)
+  std::vector<const float*> bn_g, bn_b;
+  std::vector<int> bn_c;
   const float *Wfin, *bfin;
   const float *Wfin2 = nullptr, *bfin2 = nullptr;   // final projection with the last signature layer's second MLP GEMM folded in
   // split-bf16 copies of every GEMM weight (2 and 3 planes), keyed by the fp32 pointer

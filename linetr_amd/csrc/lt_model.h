@@ -11,6 +11,7 @@ namespace lt {
 // fused with normalize_keylines (models/line_transformer.py:22-38, :40-73).
 // 8 threads per row, 4 output channels each.
 // ---------------------------------------------------------------------------------------------
+template <bool RELU = true>      // RELU = false: the pre-activations, for BatchNorm in training mode (lt_bntrain.h)
 __global__ void word_mlp1_kernel(const float* __restrict__ pnt, const float* __restrict__ score, int64_t rows,
                                  float cx, float cy, float scale, const float* __restrict__ W /*[32][3]*/,
                                  const float* __restrict__ b, float* __restrict__ out /*[rows][32]*/) {
@@ -27,11 +28,12 @@ __global__ void word_mlp1_kernel(const float* __restrict__ pnt, const float* __r
   for (int c = 0; c < 4; ++c) {
     const float* w = W + (c0 + c) * 3;
     float v = b[c0 + c] + w[0] * x + w[1] * y + w[2] * s;
-    o[c] = fmaxf(v, 0.f);
+    o[c] = RELU ? fmaxf(v, 0.f) : v;
   }
   *reinterpret_cast<f32x4*>(out + row * 32 + c0) = o;
 }
 
+template <bool RELU = true>
 __global__ void line_mlp1_kernel(const float* __restrict__ sublines /*[N][2][2]*/, const float* __restrict__ resp,
                                  const float* __restrict__ angle, int N, float cx, float cy, float scale,
                                  const float* __restrict__ W /*[32][5]*/, const float* __restrict__ b,
@@ -52,7 +54,7 @@ __global__ void line_mlp1_kernel(const float* __restrict__ sublines /*[N][2][2]*
     float v = b[c0 + c];
 #pragma unroll
     for (int i = 0; i < 5; ++i) v += w[i] * in[i];
-    o[c] = fmaxf(v, 0.f);
+    o[c] = RELU ? fmaxf(v, 0.f) : v;
   }
   *reinterpret_cast<f32x4*>(out + (int64_t)row * 32 + c0) = o;
 }

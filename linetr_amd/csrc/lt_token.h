@@ -108,7 +108,7 @@ __device__ __forceinline__ void walk_along(const double sp[2], const double ep[2
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void tokenize_kernel(
     const LinetrLineRec* __restrict__ recs, const int* __restrict__ sub2line_g, int N, double td, int T,
-    int height, int width, const float* __restrict__ dense_score, float* __restrict__ sublines,
+    int height, int width, double clip_x, double clip_y, const float* __restrict__ dense_score, float* __restrict__ sublines,
     float* __restrict__ pnt, float* __restrict__ mask, float* __restrict__ resp,
     float* __restrict__ angle_sub, float* __restrict__ score, float* __restrict__ cpnt,
     float* __restrict__ cscore, int n_pad_images, int64_t first_pad, float* __restrict__ mat_k2s, const K2sTable k2s) {
@@ -141,7 +141,9 @@ __global__ __launch_bounds__(64) void tokenize_kernel(
   }
   const LinetrLineRec r = recs[sub2line_g[n]];
   const int j = n - r.first_sub;  // sub-line index inside its key-line
-  const double epc[2] = {fmin(r.ep[0], (double)width - 0.6), fmin(r.ep[1], (double)height - 0.6)};
+  // end-point clip of line_process.py:115-116: the limits come from the `image_shape` ARGUMENT of line_tokenizer (width - 0.6,
+  // height - 0.6), which need not be the score map's shape (the dataset builder passes (640, 480) for a 480 x 640 image)
+  const double epc[2] = {fmin(r.ep[0], clip_x), fmin(r.ep[1], clip_y)};
   for (int t = threadIdx.x; t < T; t += 64) {
     const int ti = j * T + t;
     double x = 0.0, y = 0.0;

@@ -16,7 +16,7 @@ from . import _native as nat
 D = 256
 
 DEFAULT_MODEL = dict(descriptor_dim=256, keyline_encoder=[32, 64, 128, 256], n_heads=4,
-                     n_line_descriptive_layers=1, d_inner=1024, n_sig_layers=7, image_shape=[480, 640])
+                     n_line_descriptive_layers=1, d_inner=1024, n_sig_layers=7, image_shape=[480, 640], bn_batch_stats=False)
 
 
 def _as_numpy_f32(v):
@@ -114,6 +114,7 @@ class Engine:
             mc.enc_channels[i] = c
         shape = cfg["image_shape"]
         mc.norm_height, mc.norm_width = int(shape[-2]), int(shape[-1])
+        mc.bn_batch_stats = int(bool(cfg["bn_batch_stats"]))     # a training-mode handle: forward_train_tensors only
         names, arrs = [], []
         for k, v in state_dict.items():
             if k.endswith("num_batches_tracked"):
@@ -297,9 +298,10 @@ class Engine:
 
     # ------------------------------------------------------------------ device stages
     def tokenize(self, recs, cu_k, cu_n, dense_desc, dense_score, *, token_distance, max_tokens, align_corners=False,
-                 sample_desc=True, dense_layout="nchw", want_mat=False) -> TokenBatch:
+                 sample_desc=True, dense_layout="nchw", want_mat=False, clip_shape=None) -> TokenBatch:
         """line_tokenizer on the device.  dense_desc [B,256,H/8,W/8] (dense_layout='nchw') or [B,H/8,W/8,256]
-        ('nhwc', the producer's layout: no transposition pass), dense_score [B,H,W]."""
+        ('nhwc', the producer's layout: no transposition pass), dense_score [B,H,W].  clip_shape: the (height, width) the
+        reference's `image_shape` argument carries when it is not the maps' shape (it only sets the end-point clip)."""
         B = len(cu_k) - 1
         K, N, T = int(cu_k[-1]), int(cu_n[-1]), int(max_tokens)
         dense_desc = self._f32(dense_desc)
@@ -356,7 +358,9 @@ class Engine:
             ct.desc = None
         with torch.cuda.device(self.device):     # a weight-less engine has no handle: the current device is used
             nat.check(self._L.linetr_tokenize(self._h, d_recs.data_ptr(), K, N, float(token_distance), T,
-                                              dense_desc.data_ptr(), dense_score.data_ptr(), B, H, W, int(bool(align_corners)),
+                                              dense_desc.data_ptr(), dense_score.data_ptr(), B, H, W,
+                                              int(clip_shape[0]) if clip_shape is not None else 0,
+                                              int(clip_shape[1]) if clip_shape is not None else 0, int(bool(align_corners)),
                                               int(nhwc), ct, tb.sub2line.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), self._L)
         tb.extra["d_recs"] = d_recs  # keep alive until the stream has consumed it
         return tb
@@ -528,6 +532,35 @@ class Engine:
         nat.check(self._L.linetr_forward(self._h, C.byref(t), nat.np_ptr(cu), d_cu_n.data_ptr() if d_cu_n is not None else None,
                                          len(cu) - 1, T, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), self._L)
         return out
+
+    def bn_stats_floats(self) -> int:
+        return int(self._L.linetr_bn_stats_floats(self._h))
+
+    def forward_train_tensors(self, sublines, pnt, resp, angle_sub, desc, score, cu_n, bn_running, momentum=0.1, want_batch_stats=False):
+        """The training-time forward (train.py:127,163-164) on flat tensors, on an Engine made with bn_batch_stats=True: BatchNorm on
+        the statistics of THIS batch; `bn_running` (float32 device tensor of bn_stats_floats() entries: per BatchNorm layer
+        mean[C] | var[C], state_dict order) is updated in place.  Returns line_desc [N,256], and with want_batch_stats the batch mean
+        | biased variance packed the same way."""
+        N, T = int(pnt.shape[0]), int(pnt.shape[1])
+        t = nat.Tokens()
+        keep = [self._f32(x) for x in (sublines, pnt, resp, angle_sub, desc, score)]
+        t.sublines, t.pnt, t.resp, t.angle_sub, t.desc, t.score = [x.data_ptr() for x in keep]
+        cu = np.ascontiguousarray(cu_n, dtype=np.int32)
+        if int(cu[-1]) != N:
+            raise ValueError("cu_n does not match the number of sub-lines")
+        n_stats = self.bn_stats_floats()
+        if (bn_running.dtype != torch.float32 or bn_running.device != self.device or not bn_running.is_contiguous()
+                or bn_running.numel() != n_stats):
+            raise ValueError(f"bn_running must be a contiguous float32 tensor of {n_stats} entries on {self.device}")
+        out = torch.empty((N, D), dtype=torch.float32, device=self.device)
+        batch = torch.empty((n_stats,), dtype=torch.float32, device=self.device) if want_batch_stats else None
+        if N == 0:
+            return (out, batch) if want_batch_stats else out
+        ws = self._workspace("fwd", self._L.linetr_forward_train_workspace_bytes(self._h, N, T))
+        nat.check(self._L.linetr_forward_train(self._h, C.byref(t), nat.np_ptr(cu), None, len(cu) - 1, T, float(momentum),
+                                               bn_running.data_ptr(), batch.data_ptr() if batch is not None else None,
+                                               out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), self._L)
+        return (out, batch) if want_batch_stats else out
 
     def forward(self, tb: TokenBatch, out=None) -> torch.Tensor:
         return self.forward_tensors(tb.sublines, tb.pnt, tb.resp, tb.angle_sub, tb.desc, tb.score, tb.cu_n, out,

@@ -190,7 +190,7 @@ def prefilter_tokenize(klines_cv, height, width, border, min_length, max_subline
     return tokenize_into({}, eng, token_distance, max_tokens, pred_superpoint, packed=(recs, int(cu_n[1])))
 
 
-def tokenize_into(klines, eng, token_distance, max_tokens, pred_superpoint, packed=None):
+def tokenize_into(klines, eng, token_distance, max_tokens, pred_superpoint, packed=None, clip_shape=None):
     """line_tokenizer body shared by the module-level function and LineTransformer.preprocess: fills the reference's dict
     (line_process.py:182-196; 11 tensor entries with a leading batch axis of 1) from ONE native tokeniser call.
     `packed`: (records, number of sub-lines) when the lines are already packed (prefilter_tokenize); `klines` is then the empty
@@ -205,7 +205,7 @@ def tokenize_into(klines, eng, token_distance, max_tokens, pred_superpoint, pack
     K = len(recs)
     align = int(torch.__version__[2]) > 2   # the reference's own version switch (line_process.py:93)
     tb = eng.tokenize(recs, np.array([0, K], np.int32), np.array([0, N], np.int32), dd, ds, token_distance=td,
-                      max_tokens=T, align_corners=align, dense_layout=layout, want_mat=True)
+                      max_tokens=T, align_corners=align, dense_layout=layout, want_mat=True, clip_shape=clip_shape)
     # the sub-line -> key-line map rides along with the matrix it describes (Matching.match_lines); a matrix from anywhere else -- or
     # one indexed / edited since -- simply lacks a valid one and is reduced to its map on the device (linetr_pool_distmat_dense)
     mat = attach_sub2line(tb.mat[None], tb.sub2line)
@@ -226,17 +226,15 @@ def tokenize_into(klines, eng, token_distance, max_tokens, pred_superpoint, pack
 
 def line_tokenizer(klines, token_distance, max_tokens, pred_superpoint, image_shape):
     """line_process.py:100-196.  `klines`: {'klines' [K,2,2], 'length_klines' [K], 'angles' [K,2]} float64 NumPy;
-    `image_shape` = (height, width) -- it must be the shape of pred_superpoint['dense_score'] (the native tokeniser takes the
-    clip limits and the score map from the same tensor)."""
+    `image_shape` = (height, width): as in the reference it only sets the end-point clip (width - 0.6, height - 0.6, :115-116) and
+    need not be the maps' shape -- conv_fixed_size hands over conf['data']['resize'] = (640, 480) for 480 x 640 images
+    (dataloaders/utils/util_lines.py:682,703).  Scores and descriptors are gathered within the maps' own bounds (:174-179)."""
     height, width = image_shape
-    ds = pred_superpoint["dense_score"]
-    if (int(ds.shape[-2]), int(ds.shape[-1])) != (int(height), int(width)):
-        raise ValueError(f"line_tokenizer: image_shape {tuple(image_shape)} does not match dense_score {tuple(ds.shape)}")
     dd = pred_superpoint.get("dense_descriptor_nhwc")       # either descriptor key may be the one supplied (tokenize_into)
     if dd is None:
         dd = pred_superpoint["dense_descriptor"]
     eng = _token_engine(dd.device)
-    return tokenize_into(klines, eng, token_distance, max_tokens, pred_superpoint)
+    return tokenize_into(klines, eng, token_distance, max_tokens, pred_superpoint, clip_shape=(int(height), int(width)))
 
 
 def preprocess(klines_cv, image_shape, pred_superpoint, mask=None, conf={}):

@@ -97,6 +97,11 @@ class LineTransformer(nn.Module):
         "d_inner": 1024,
     }
     N_SIGNATURE_LAYERS = 7
+    # The reference hard-codes dropout 0.1 in its attention blocks (models/line_transformer.py:77,96; models/line_attention.py:8,25,79):
+    # active whenever the module is in train mode.  The training-time forward of this build is deterministic -- BatchNorm on batch
+    # statistics, dropout probability 0, no autograd -- so it only runs once the caller has said so by setting
+    # `model.dropout = 0.0`, the counterpart of zeroing `p` on the reference's nn.Dropout instances.
+    dropout = 0.1
 
     def __init__(self, config):
         super().__init__()
@@ -136,13 +141,21 @@ class LineTransformer(nn.Module):
 
     def load_state_dict(self, *a, **k):
         self._engine = None
+        self.__dict__["_engine_train"] = None
         self.__dict__["_tracked"] = None
         return super().load_state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):
         self._engine = None
+        self.__dict__["_engine_train"] = None
         self.__dict__["_tracked"] = None
         return super()._apply(fn, *a, **k)
+
+    def _params_version(self):
+        """_weights_version without the buffers: the training-mode engine keeps the convolutions unfolded and never reads the
+        BatchNorm running statistics, which every training-time forward rewrites."""
+        ps = [p for p in self.parameters()]
+        return tuple(id(p) for p in ps) + tuple(map(torch.Tensor.data_ptr, ps)) + tuple(p._version for p in ps if not p.is_inference())
 
     def _weights_version(self):
         """Changes whenever a parameter / buffer is modified in place through the tensor itself (optimizer step, `with
@@ -186,6 +199,8 @@ class LineTransformer(nn.Module):
         state = self.__dict__.copy()
         state["_engine"] = None
         state["_engine_key"] = None
+        state["_engine_train"] = None
+        state["_engine_train_key"] = None
         state["_tracked"] = None
         return state
 
@@ -195,17 +210,76 @@ class LineTransformer(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = None if k in ("_engine", "_engine_key", "_tracked") else copy.deepcopy(v, memo)
+            new.__dict__[k] = None if k in ("_engine", "_engine_key", "_engine_train", "_engine_train_key", "_tracked") else copy.deepcopy(v, memo)
         return new
+
+    def _bn_layers(self):
+        """The 15 BatchNorm1d modules in the order of the native packed statistics (word encoder, line encoder, signature MLPs)."""
+        mods = [m for enc in (self.klenc.word_position_enc.encoder, self.klenc.line_position_enc.encoder)
+                for m in enc if isinstance(m, nn.BatchNorm1d)]
+        return mods + [layer.mlp[1] for layer in self.selfattn.layers]
+
+    def _forward_train(self, data):
+        """train.py:127,163-164: the module in train mode, called on a batch of fixed-size samples.  Every BatchNorm1d normalises with
+        the statistics of THIS call's batch and moves its running_mean / running_var / num_batches_tracked exactly as
+        torch.nn.BatchNorm1d does (linetr_forward_train, csrc/lt_bntrain.h).  Forward only: the returned line_desc carries no
+        autograd graph, and dropout must have been switched off (`model.dropout = 0.0`)."""
+        if self.dropout != 0:
+            raise RuntimeError(
+                "linetr_amd.LineTransformer in train mode: the training-time forward of this build has no dropout (the reference "
+                "applies nn.Dropout(0.1) in its attention blocks, models/line_attention.py:11,39,84) and no autograd.  Set "
+                "`model.dropout = 0.0` to run the deterministic train-mode forward (BatchNorm batch statistics, running statistics "
+                "updated), or call .eval() for inference (match_line_pairs.py:75, demo_LineTR.py:154, train.py:133)")
+        bns = self._bn_layers()
+        for bn in bns:
+            if bn.momentum is None or bn.eps != 1e-5 or not bn.track_running_stats or not bn.affine:
+                raise RuntimeError("linetr_amd train-mode forward: BatchNorm1d must keep the reference's settings "
+                                   "(momentum given, eps 1e-5, affine, track_running_stats)")
+        momentum = float(bns[0].momentum)
+        if any(float(bn.momentum) != momentum for bn in bns):
+            raise RuntimeError("linetr_amd train-mode forward: one momentum for all BatchNorm layers")
+        sub = data["sublines"]
+        dev = sub.device if sub.is_cuda else self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("LineTransformer (linetr_amd) runs on a HIP device only: move the module with .to('cuda'); there is no CPU fallback")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        key = (dev, tuple(self.image_shape[-2:]), self._params_version())
+        if self.__dict__.get("_engine_train") is None or self.__dict__.get("_engine_train_key") != key:
+            c = self.config
+            self.__dict__["_engine_train"] = Engine(self.state_dict(), dev, descriptor_dim=c["descriptor_dim"],
+                                                    keyline_encoder=list(c["keyline_encoder"]), n_heads=c["n_heads"],
+                                                    n_line_descriptive_layers=c["n_line_descriptive_layers"], d_inner=c["d_inner"],
+                                                    n_sig_layers=self.N_SIGNATURE_LAYERS, image_shape=list(self.image_shape[-2:]),
+                                                    bn_batch_stats=True)
+            self.__dict__["_engine_train_key"] = key
+        eng = self.__dict__["_engine_train"]
+        B, N = int(sub.shape[0]), int(sub.shape[1])
+        T = int(data["pnt_sublines"].shape[2])
+        flat = lambda t, *tail: t.reshape(B * N, *tail)
+        with torch.no_grad():
+            running = torch.cat([t.detach().to(device=dev, dtype=torch.float32).reshape(-1) for bn in bns
+                                 for t in (bn.running_mean, bn.running_var)])
+            out = eng.forward_train_tensors(flat(sub, 2, 2), flat(data["pnt_sublines"], T, 2), flat(data["resp_sublines"]),
+                                            flat(data["angle_sublines"], 2), flat(data["desc_sublines"], T, 256),
+                                            flat(data["score_sublines"], T), np.arange(B + 1, dtype=np.int32) * N, running,
+                                            momentum=momentum)
+            off = 0
+            for bn in bns:     # the updated statistics go back through copy_ (version counters move: an eval engine is rebuilt)
+                C_ = bn.num_features
+                bn.running_mean.copy_(running[off:off + C_]); bn.running_var.copy_(running[off + C_:off + 2 * C_])
+                bn.num_batches_tracked.add_(1)
+                off += 2 * C_
+        data.update({"line_desc": out.view(B, N, 256).transpose(1, 2)})
+        return data
 
     def engine(self, device=None) -> Engine:
         if self.training:
-            # train.py:127 puts the reference in train mode: BatchNorm batch statistics, dropout, autograd (out
-            # of scope).  The native network folds BatchNorm(eval) into the convolutions -- running it for a module in train mode
-            # would silently return validation-mode descriptors without gradients.
-            raise RuntimeError("linetr_amd.LineTransformer is in train mode: this build provides the inference forward only "
-                               "(BatchNorm running statistics, no dropout, no autograd).  Call .eval() -- the reference's scripts "
-                               "and its validation loop do (match_line_pairs.py:75, demo_LineTR.py:154, train.py:133)")
+            # the inference engine folds BatchNorm(eval) into the convolutions: a module in train mode goes through _forward_train
+            # (BatchNorm on batch statistics); anything that asks for THIS engine would silently get validation-mode descriptors
+            raise RuntimeError("linetr_amd.LineTransformer is in train mode: the inference engine (BatchNorm running statistics) "
+                               "is not served; forward() runs the training-time path, everything else needs .eval() "
+                               "(match_line_pairs.py:75, demo_LineTR.py:154, train.py:133)")
         dev = torch.device(device) if device is not None else self._device()
         if dev.type != "cuda":
             raise RuntimeError("LineTransformer (linetr_amd) runs on a HIP device only: move the module with "
@@ -235,6 +309,8 @@ class LineTransformer(nn.Module):
     def forward(self, data):
         if len(data["klines"]) == 0:
             return self.default_ret()
+        if self.training:
+            return self._forward_train(data)
         sub = data["sublines"]
         B, N = int(sub.shape[0]), int(sub.shape[1])
         T = int(data["pnt_sublines"].shape[2])
@@ -253,7 +329,10 @@ class LineTransformer(nn.Module):
         without lines get default_ret(), like forward()."""
         live = [d for d in datas if len(d["klines"]) != 0]
         outs = {id(d): self.default_ret() for d in datas if len(d["klines"]) == 0}
-        if len(live) == 1:
+        if self.training:                        # batch statistics are per call: one call per dict, as separate forward()s would be
+            for d in live:
+                outs[id(d)] = self.forward(d)
+        elif len(live) == 1:
             outs[id(live[0])] = self.forward(live[0])
         elif live:
             T = int(live[0]["pnt_sublines"].shape[2])

@@ -319,6 +319,80 @@ def forward_batch(sd: dict, data: dict, image_shape=(480, 640), n_heads: int = 4
     return data
 
 
+def _mlp_train(sd: dict, prefix: str, x: torch.Tensor, momentum: float) -> torch.Tensor:
+    """_mlp with BatchNorm1d in TRAINING mode (train.py:127 -> model.train()): batch statistics over all rows, and the running
+    statistics / num_batches_tracked entries of ``sd`` updated IN PLACE the way torch.nn.BatchNorm1d does."""
+    idx = 0
+    while f"{prefix}.{idx}.weight" in sd:
+        x = F.linear(x, sd[f"{prefix}.{idx}.weight"][:, :, 0], sd[f"{prefix}.{idx}.bias"])
+        idx += 1
+        if f"{prefix}.{idx}.running_mean" in sd:
+            x = F.batch_norm(x, sd[f"{prefix}.{idx}.running_mean"], sd[f"{prefix}.{idx}.running_var"],
+                             sd[f"{prefix}.{idx}.weight"], sd[f"{prefix}.{idx}.bias"], True, momentum, 1e-5)
+            if f"{prefix}.{idx}.num_batches_tracked" in sd:
+                sd[f"{prefix}.{idx}.num_batches_tracked"] += 1
+            x = F.relu(x)
+            idx += 2
+    return x
+
+
+def forward_train(sd: dict, data: dict, image_shape=(480, 640), n_heads: int = 4, momentum: float = 0.1) -> dict:
+    """The TRAIN-MODE forward (8(f) row 4): models/line_transformer.py:225-249 with the module in .train() (train.py:127), called
+    on a batch [B,N,...] of fixed-size samples (train.py:163-164).  Every BatchNorm1d of the three MLP stacks normalises with the
+    statistics of the whole batch -- B*N*T token positions in the word encoder ([B*N,3,T] input, :63-68), B*N sub-lines in the line
+    encoder and the signature MLPs -- and ``sd``'s running statistics are updated in place.  Dropout is taken at probability 0
+    (models/line_attention.py:11,39,84; a fixture cannot hold an RNG stream).  line_desc comes back as [B,256,N]."""
+    sub, pnt, desc = data["sublines"], data["pnt_sublines"], data["desc_sublines"]
+    B, N, T, d = desc.shape
+    score, mask = data["score_sublines"], data["mask_sublines"]
+    resp, ang = data["resp_sublines"], data["angle_sublines"]
+    height, width = image_shape[-2:]
+    ctr = torch.tensor([width / 2.0, height / 2.0])
+    scale = torch.tensor(float(max(width, height))) * 0.7
+    sub_n = ((sub - ctr) / scale).reshape(B * N, 2, 2)
+    pnt_n = ((pnt - ctr) / scale).reshape(B * N, T, 2)
+    mid = (sub_n[:, 0] + sub_n[:, 1]) / 2.0
+    line_pos = _mlp_train(sd, "klenc.line_position_enc.encoder",
+                          torch.cat([mid, resp.reshape(B * N, 1), ang.reshape(B * N, 2)], dim=1), momentum)
+    word_pos = _mlp_train(sd, "klenc.word_position_enc.encoder",
+                          torch.cat([pnt_n, score.reshape(B * N, T, 1)], dim=-1).reshape(B * N * T, 3), momentum).reshape(B * N, T, d)
+    x = desc.reshape(B * N, T, d) + word_pos
+    M = B * N
+    x = torch.cat([sd["klenc.cls_token"].reshape(1, 1, d).expand(M, 1, d), x], dim=1)
+    n_layers = 0
+    while f"klenc.desc_layers.{n_layers}.slf_attn.fc.weight" in sd:
+        n_layers += 1
+    p = f"klenc.desc_layers.{n_layers - 1}"
+    S, dh = T + 1, d // n_heads
+    q = F.linear(x, sd[f"{p}.slf_attn.w_qs.weight"], sd[f"{p}.slf_attn.w_qs.bias"]).view(M, S, n_heads, dh).transpose(1, 2)
+    k = F.linear(x, sd[f"{p}.slf_attn.w_ks.weight"], sd[f"{p}.slf_attn.w_ks.bias"]).view(M, S, n_heads, dh).transpose(1, 2)
+    v = F.linear(x, sd[f"{p}.slf_attn.w_vs.weight"], sd[f"{p}.slf_attn.w_vs.bias"]).view(M, S, n_heads, dh).transpose(1, 2)
+    att = torch.matmul(q / (dh ** 0.5), k.transpose(2, 3))
+    att = att.masked_fill(mask.reshape(M, 1, S, 1) == 0, -1e9)
+    att = F.softmax(att, dim=-1)
+    o = torch.matmul(att, v).transpose(1, 2).reshape(M, S, d)
+    o = F.linear(o, sd[f"{p}.slf_attn.fc.weight"], sd[f"{p}.slf_attn.fc.bias"]) + x
+    o = F.layer_norm(o, (d,), sd[f"{p}.slf_attn.layer_norm.weight"], sd[f"{p}.slf_attn.layer_norm.bias"], 1e-6)
+    f = F.linear(F.gelu(F.linear(o, sd[f"{p}.pos_ffn.w_1.weight"], sd[f"{p}.pos_ffn.w_1.bias"])),
+                 sd[f"{p}.pos_ffn.w_2.weight"], sd[f"{p}.pos_ffn.w_2.bias"]) + o
+    f = F.layer_norm(f, (d,), sd[f"{p}.pos_ffn.layer_norm.weight"], sd[f"{p}.pos_ffn.layer_norm.bias"], 1e-6)
+    z = line_pos + f[:, 0, :]                                                      # [B*N,256]
+    l = 0
+    while f"selfattn.layers.{l}.attn.merge.weight" in sd:
+        a = f"selfattn.layers.{l}.attn"
+        qkv = [F.linear(z, sd[f"{a}.proj.{j}.weight"][:, :, 0], sd[f"{a}.proj.{j}.bias"]).view(B, N, dh, n_heads) for j in range(3)]
+        sc = torch.einsum("bndh,bmdh->bhnm", qkv[0], qkv[1]) / dh ** 0.5           # per image (:132-136)
+        pr = F.softmax(sc, dim=-1)
+        msg = torch.einsum("bhnm,bmdh->bndh", pr, qkv[2]).reshape(M, d)
+        msg = F.linear(msg, sd[f"{a}.merge.weight"][:, :, 0], sd[f"{a}.merge.bias"])
+        z = z + _mlp_train(sd, f"selfattn.layers.{l}.mlp", torch.cat([z, msg], dim=1), momentum)
+        l += 1
+    z = F.linear(z, sd["final_proj.weight"][:, :, 0], sd["final_proj.bias"])
+    z = F.normalize(z, p=2, dim=1)
+    data["line_desc"] = z.reshape(B, N, d).transpose(1, 2).contiguous()
+    return data
+
+
 # --------------------------------------------------------------------------------------------
 # a19-a21: matcher (NumPy, like the reference)
 # --------------------------------------------------------------------------------------------

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import BASE_CFG, TOK_KEYS, load, tiny_maps
+from helpers import BASE_CFG, TOK_KEYS, load, tiny_maps, train_mode_batches
 from workloads import synth
 
 pytestmark = pytest.mark.gpu
@@ -481,6 +481,71 @@ def test_training_time_batched_forward_golden():
     # batch element b equals the same image pushed through alone (the signature attention is per image)
     alone = m({k: v[1:2].clone() for k, v in batch.items() if k != "line_desc"})
     assert (alone["line_desc"][0] - res["line_desc"][1]).abs().max().item() < 2e-6
+
+
+def _shim_train_batches(g, m):
+    hw = tuple(int(v) for v in g["hw"])
+    from models.line_process import line_tokenizer
+    pre = lambda rows, pred: m.preprocess(synth.array_to_keylines(rows), (1, 1, *hw), pred)
+    tok = lambda lines, pred: line_tokenizer(lines, 8, 21, pred, (640, 480))      # conv_fixed_size's image_shape (util_lines.py:682,703)
+    return train_mode_batches(g, pre, tok, to_dev=lambda t: t.cuda())
+
+
+def test_line_tokenizer_with_the_dataset_builders_swapped_image_shape():
+    """line_tokenizer's `image_shape` only sets the end-point clip (models/line_process.py:101,115-116); conv_fixed_size passes
+    (640, 480) for 480 x 640 maps (dataloaders/utils/util_lines.py:682,703), which bends 29 of the fixture's 111 pseudo lines at
+    x = 479.4.  Every tensor against the real reference's output for the same call."""
+    from models.line_process import line_tokenizer
+    g = load("train_mode")
+    dd, ds = synth.synth_dense_maps_np(int(g["map_seed_0_0"]), 480, 640)
+    pred = {"dense_descriptor": torch.from_numpy(dd).cuda(), "dense_score": torch.from_numpy(ds).cuda()}
+    lines = {k: g[f"pseudo_{k}_0_0"].copy() for k in ("klines", "length_klines", "angles")}
+    out = line_tokenizer(lines, 8, 21, pred, (640, 480))
+    for k in TOK_KEYS:
+        assert np.array_equal(out[k].cpu().numpy(), g[f"pseudo_tok_{k}"]), k
+    assert out["klines"][0, :, 1, 0].max().item() <= 479.4 + 1e-4
+
+
+def test_train_mode_forward_golden():
+    """8(f) row 4, train mode (train.py:127,163-164): the module in .train() called twice on batches of 3 x 250 sub-lines padded /
+    truncated by the reference's conv_fixed_size, against a fixture of the real reference in .train() with dropout probability 0
+    (tests/golden/make_golden_train_mode.py): BatchNorm on batch statistics, line_desc <= 1e-4, running_mean / running_var /
+    num_batches_tracked of all 15 BatchNorm1d layers after each call.  Forward only."""
+    from models.line_transformer import LineTransformer
+    g = load("train_mode")
+    nl = int(g["n_desc_layers"])
+    m = LineTransformer({**LT_CFG, "n_line_descriptive_layers": nl})
+    m.load_state_dict(synth.to_torch_state_dict(synth.calibrated_state_dict(nl)), strict=True)
+    m = m.to("cuda").eval()
+    batches = _shim_train_batches(g, m)
+    eval_before = m({k: v.clone() for k, v in batches[0].items()})["line_desc"].clone()
+    m.train()
+    assert m.training and m.dropout == 0.1
+    with pytest.raises(RuntimeError, match="dropout"):          # the reference's train mode has dropout 0.1: not silently dropped
+        m(dict(batches[0]))
+    m.dropout = 0.0
+    for c, batch in enumerate(batches):
+        res = m(batch)
+        assert res is batch and res["line_desc"].shape == (3, 256, 250) and not res["line_desc"].requires_grad
+        got = res["line_desc"].cpu().numpy()
+        want = g[f"line_desc_{c}"]
+        assert np.abs((got if c == 0 else got[:, :, ::5]) - want).max() < 1e-4
+        sd = m.state_dict()
+        for k, v in sd.items():
+            if "running_" in k:
+                ref = g[f"bn{c}.{k}"]
+                assert np.abs(v.cpu().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (c, k)
+            elif k.endswith("num_batches_tracked"):
+                assert int(v) == int(g[f"bn{c}.{k}"]), (c, k)
+    # back in eval mode the folded engine is rebuilt on the MOVED running statistics: the reference's eval forward with the fixture's
+    # statistics after the second call (the oracle restates it; pinned by tests/test_oracle_golden.py)
+    m.eval()
+    eval_after = m({k: v.clone() for k, v in batches[0].items() if k != "line_desc"})["line_desc"]
+    assert (eval_after - eval_before).abs().max().item() > 1e-4
+    from oracle import linetr_oracle as O
+    sd_t = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    want = O.forward_batch(sd_t, {k: v.cpu() for k, v in batches[0].items() if k != "line_desc"}, (480, 640))["line_desc"]
+    assert (eval_after.cpu() - want).abs().max().item() < 1e-4
 
 
 def test_matching_forward_fused_pair_equals_the_per_image_path(monkeypatch):

@@ -8,7 +8,7 @@ import torch
 
 from workloads import synth
 from oracle import linetr_oracle as O
-from helpers import BASE_CFG, TOK_KEYS, golden_cfg, load, oracle_image, tiny_maps, weights_for
+from helpers import BASE_CFG, TOK_KEYS, golden_cfg, load, oracle_image, tiny_maps, train_mode_batches, weights_for
 
 torch.set_grad_enabled(False)
 DESC_TOL = 2e-5
@@ -164,3 +164,46 @@ def test_training_time_batched_forward():
     got = O.forward_batch(sd, batch, hw)["line_desc"].numpy()
     assert got.shape == g["line_desc"].shape == (3, 256, n_fix)
     assert np.abs(got - g["line_desc"]).max() < 2e-6
+
+
+def _oracle_train_batches(g):
+    hw = tuple(int(v) for v in g["hw"])
+    pre = lambda rows, pred: O.preprocess(synth.array_to_keylines(rows), (1, 1, *hw), pred["dense_descriptor"], pred["dense_score"],
+                                          dict(BASE_CFG))
+    tok = lambda lines, pred: O.tokenize(lines, 8, 21, pred["dense_descriptor"], pred["dense_score"], (640, 480))
+    return train_mode_batches(g, pre, tok)
+
+
+def test_pseudo_lines_tokenised_with_the_dataset_builders_swapped_image_shape():
+    """conv_fixed_size hands conf['data']['resize'] = (640, 480) = (width, height) to line_tokenizer as `image_shape`
+    (dataloaders/utils/util_lines.py:682,703), which reads it as (height, width) and clips end points at x <= 479.4
+    (models/line_process.py:101,115-116): 29 of the 111 pseudo lines of the fixture are bent by it."""
+    g = load("train_mode")
+    dd, ds = synth.synth_dense_maps_np(int(g["map_seed_0_0"]), 480, 640)
+    lines = {k: g[f"pseudo_{k}_0_0"].copy() for k in ("klines", "length_klines", "angles")}
+    assert (lines["klines"][:, 1, 0] > 479.4).sum() == 29
+    out = O.tokenize(lines, 8, 21, torch.from_numpy(dd), torch.from_numpy(ds), (640, 480))
+    for k in TOK_KEYS:
+        assert np.array_equal(out[k].numpy(), g[f"pseudo_tok_{k}"]), k
+
+
+def test_train_mode_forward_and_running_statistics():
+    """8(f) row 4, train mode: the reference in .train() with dropout probability 0, called twice on batches of 3 x 250 sub-lines
+    padded / truncated by its own conv_fixed_size (make_golden_train_mode.py): BatchNorm on batch statistics, running statistics and
+    num_batches_tracked after each call."""
+    g = load("train_mode")
+    hw = tuple(int(v) for v in g["hw"])
+    nl = int(g["n_desc_layers"])
+    sd = synth.to_torch_state_dict(synth.calibrated_state_dict(nl))
+    sd = {k: v.clone() for k, v in sd.items()}
+    bn_keys = [k for k in sd if k.endswith("running_mean")]
+    assert len(bn_keys) == 15
+    for c, batch in enumerate(_oracle_train_batches(g)):
+        got = O.forward_train(sd, batch, hw)["line_desc"].numpy()
+        want = g[f"line_desc_{c}"]
+        assert np.abs((got if c == 0 else got[:, :, ::5]) - want).max() < 5e-6
+        for k in bn_keys:
+            for kk in (k, k.replace("running_mean", "running_var")):
+                assert np.abs(sd[kk].numpy() - g[f"bn{c}.{kk}"]).max() <= 1e-6 * max(1.0, np.abs(g[f"bn{c}.{kk}"]).max()), (c, kk)
+            nbt = k.replace("running_mean", "num_batches_tracked")
+            assert int(sd[nbt]) == int(g[f"bn{c}.{nbt}"])
