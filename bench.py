@@ -475,6 +475,7 @@ def sub_workload(eng, name, device, settle_s, repeat=1, brief=False):
             out["oracle_check"] = oracle_check(lines, lambda i: nhwc[i].permute(2, 0, 1)[None].contiguous().cpu(), ds, hw,
                                                tuple(eng.cfg["image_shape"][-2:]), T, ld, tb,
                                                m01, dk, off_dk, off_k0, pairs)
+            out["argmin"] = argmin_margins(dk, off_dk, margs[2], out["oracle_check"]["max_abs_dk_err_vs_oracle"])
     if pairs == 1:      # single pair: strict latency (submit, wait, repeat) of describe and of describe + match
         margs = pipe.match_args(tb, ld)
         lat, lat_m = [], []
@@ -518,11 +519,18 @@ def sub_workload(eng, name, device, settle_s, repeat=1, brief=False):
     return out
 
 
-def argmin_margins(dk, off_dk, dims):
+ARGMIN_CONTRACT = ("an argmin whose best-vs-second-best margin exceeds 4 x max|Dk - oracle| is identical to the oracle's by arithmetic; "
+                   "below that, the reference's own fp32 result depends on summation order (two BLAS builds can flip it) and EITHER index "
+                   "is a correct answer -- margins_at_risk counts those rows and columns (tests/test_gpu_properties.py::"
+                   "test_near_tie_contract builds such a tie on purpose)")
+
+
+def argmin_margins(dk, off_dk, dims, dk_err=None):
     """Best-vs-second-best gap of every row and every column of each pair's key-line distance matrix Dk (SURVEY.md section 7,
-    "hard parts": an argmin is only as stable as its margin).  Returns the smallest gap over the batch and how many gaps are
-    below 1e-5 (the descriptors agree with the reference to ~4e-7, i.e. distances to ~1e-6)."""
-    mins, small, n = [], 0, 0
+    "hard parts": an argmin is only as stable as its margin).  Returns the smallest gap over the batch, how many gaps are
+    below 1e-5 (the descriptors agree with the reference to ~4e-7, i.e. distances to ~1e-6) and -- given the measured
+    max|Dk - oracle| of the same run -- how many are below that error and below four times it (ARGMIN_CONTRACT)."""
+    gaps = []
     for p in range(len(dims)):
         k0, k1 = int(dims[p][1]), int(dims[p][3])
         if k0 < 1 or k1 < 1:
@@ -532,12 +540,17 @@ def argmin_margins(dk, off_dk, dims):
             if m.shape[1] < 2:
                 continue
             two = torch.topk(m, 2, dim=1, largest=False).values
-            gap = two[:, 1] - two[:, 0]
-            mins.append(gap.min())
-            small += int((gap < 1e-5).sum().item())
-            n += gap.numel()
-    return {"min_argmin_margin": float(torch.stack(mins).min().item()) if mins else None, "margins_below_1e-5": small,
-            "argmins_checked": n}
+            gaps.append(two[:, 1] - two[:, 0])
+    if not gaps:
+        return {"min_argmin_margin": None, "margins_below_1e-5": 0, "argmins_checked": 0}
+    g = torch.cat(gaps)
+    out = {"min_argmin_margin": float(g.min().item()), "margins_below_1e-5": int((g < 1e-5).sum().item()), "argmins_checked": int(g.numel())}
+    if dk_err is not None:
+        out["margins_below_dk_err"] = int((g < dk_err).sum().item())
+        out["margins_at_risk"] = int((g < 4 * dk_err).sum().item())
+        out["dk_err_used"] = dk_err
+        out["contract"] = ARGMIN_CONTRACT
+    return out
 
 
 def oracle_check(lines, dense_nchw_of, ds, hw, norm_hw, T, ld, tb, m01, dk, off_dk, off_k0, pairs):
@@ -842,6 +855,40 @@ def run_cfg4(args, eng, device, rank, world, dist):
 
 # =====================================================================================================================
 
+def fail_line(msg, world, rank, code=3):
+    """A multi-GPU run that cannot be trusted must not look like a slow one: ONE JSON line with "error" and a null value from rank 0,
+    then a non-zero exit code on every rank."""
+    if rank == 0:
+        print(json.dumps({"metric": "line_descriptors_per_sec", "value": None, "unit": "line-descriptors/s", "n_gpus": world,
+                          "error": msg}), flush=True)
+    sys.stdout.flush()
+    os._exit(code)
+
+
+def preflight(dist, world, rank, device, backend):
+    """Before anything is timed on N > 1 ranks: the process group really has N ranks that see each other (an all-reduce of ones and an
+    all-gather of the rank ids through the SAME backend the benchmark uses), and -- unless the one-device test hook is on -- every rank
+    sits on its own GPU.  Returns what was seen; raises SystemExit through fail_line otherwise."""
+    ones = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    ids = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int64, device=device))
+    torch.cuda.synchronize()
+    seen = sorted(int(v) for v in ids.cpu())
+    if int(ones.item()) != world or seen != list(range(world)):
+        fail_line(f"pre-flight: the collective saw {int(ones.item())} ranks {seen}, expected {world}", world, rank)
+    props = torch.cuda.get_device_properties(device)
+    tag = str(getattr(props, "uuid", "")) or f"{props.name}#{device.index}"
+    box = [None] * world
+    dist.all_gather_object(box, (rank, device.index, tag))
+    distinct = len({t for _r, _i, t in box})
+    if distinct != world and not os.environ.get("LINETR_BENCH_ONE_DEVICE"):
+        fail_line(f"pre-flight: {world} ranks on {distinct} distinct GPUs ({box})", world, rank)
+    ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" and hasattr(torch.cuda, "nccl") else None
+    return {"ranks_seen": world, "distinct_gpus": distinct, "backend": backend, "rccl_version": ver,
+            "devices": [f"rank {r}: cuda:{i}" for r, i, _t in sorted(box)]}
+
+
 def self_launch(n):
     """Re-run this command under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1, a free port)."""
     import socket
@@ -913,6 +960,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    pre = preflight(dist, world, rank, device, os.environ.get("LINETR_BENCH_BACKEND", "nccl")) if world > 1 else None
 
     H, W, n_lines, lo, hi, T, def_pairs = WORKLOADS[args.workload]
     pairs = args.pairs or def_pairs
@@ -921,6 +969,7 @@ def main():
 
     if args.workload == "cfg4":
         out = run_cfg4(args, eng, device, rank, world, dist)
+        out["preflight"] = pre
         if rank == 0:
             print(json.dumps(out), flush=True)
         if world > 1:
@@ -965,7 +1014,7 @@ def main():
         pipe.prefilter_only()
     host_prefilter_ms = (time.perf_counter() - t0) / 10 * 1e3
 
-    gathered_ok, global_match, gather_ms = None, None, None
+    gathered_ok, global_match, gather_ms, gather_ms_per_rank, native_collective = None, None, None, None, None
     if world > 1 and _g is not None:
         # the collective alone (not part of `value`'s clock, which overlaps it with the next step's compute)
         slab = pipe.pack(tb, ld)
@@ -977,6 +1026,26 @@ def main():
             parallel.allgather_descriptors(slab, async_op=False)
         torch.cuda.synchronize()
         gather_ms = round((time.perf_counter() - t0) / 5 * 1e3, 4)
+        box = [None] * world
+        dist.all_gather_object(box, gather_ms)
+        gather_ms_per_rank = [float(v) for v in box]
+        if os.environ.get("LINETR_BENCH_COLLECTIVE") == "native":
+            # the C ABI's own collective (linetr_allgather_desc over an RCCL communicator of the same ranks) beside torch's: same
+            # bytes out, timed the same way
+            nag = parallel.NativeAllGather(device)
+            ref = parallel.allgather_descriptors(slab, async_op=False)
+            got = nag(slab)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(got, ref))
+            t0 = time.perf_counter()
+            for _ in range(5):
+                nag(slab)
+            torch.cuda.synchronize()
+            native_collective = {"entry_point": "linetr_allgather_desc", "equal_to_torch_all_gather": same,
+                                 "gather_ms": round((time.perf_counter() - t0) / 5 * 1e3, 4)}
+            nag.close()
+            if not same:
+                fail_line("linetr_allgather_desc returned other bytes than torch.distributed.all_gather_into_tensor", world, rank)
         # every rank's slab of the last all-gather carries that rank's descriptors; then GLOBAL matching on the gathered set:
         # this rank's side-0 images against the side-1 images of the NEXT rank's pairs (descriptors this rank never computed)
         gs = parallel.GatheredSet(_g, pipe.n_img_cap, pipe.rows_cap)
@@ -999,6 +1068,14 @@ def main():
         torch.cuda.synchronize()
         global_match = {"ms_per_batch": round((time.perf_counter() - t0) / 5 * 1e3, 4), "pair_matches": pairs,
                         "against": f"side-1 images of rank {nxt} (gathered)", "matches": int((m01g >= 0).sum().item())}
+        if os.environ.get("LINETR_BENCH_INJECT") == "bad_gather" and rank == world - 1:
+            gathered_ok = False          # test hook (tests/test_gpu_bench_launch.py): the failure path below must be loud
+        # every rank must have seen every rank's rows intact: one rank's failure fails the run
+        ok_all = torch.tensor([int(gathered_ok)], dtype=torch.int64, device=device)
+        dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+        gathered_ok = bool(ok_all.item())
+        if not gathered_ok:
+            fail_line("gathered_rows_checked is false: a rank received descriptor rows that differ from what their owner packed", world, rank)
 
     # ---- pair-match ms (a19-a21) on the descriptors just produced --------------------------------------------
     margs = pipe.match_args(tb, ld)
@@ -1018,6 +1095,7 @@ def main():
     oracle_chk = None
     if world == 1 and not args.no_cpu_baseline:
         oracle_chk = oracle_check(lines, lambda i: dd_nchw[i:i + 1].cpu(), ds, hw, (H, W), T, ld, tb, m01, dk, off_dk, _ok0, pairs)
+        argmin = argmin_margins(dk, off_dk, margs[2], oracle_chk["max_abs_dk_err_vs_oracle"])
     # ... and for ONE pair at a time (latency of get_dist_matrix + subline2keyline + nn_matcher_distmat)
     one_args = (margs[0], margs[1], margs[2][:1], margs[3][:1], margs[4][:1], margs[5][:1], margs[6][:1])
     for _ in range(3):
@@ -1072,6 +1150,7 @@ def main():
         "settle": {"seconds_min": args.settle_s, "windows": len(settle_hist), "first_ms": round(settle_hist[0], 4),
                    "last3_ms": [round(v, 4) for v in settle_hist[-3:]]},
         "gathered_rows_checked": gathered_ok, "global_match": global_match, "gather_ms": gather_ms,
+        "gather_ms_per_rank": gather_ms_per_rank, "preflight": pre, "native_collective": native_collective,
         "collective_backend": (None if world == 1 else os.environ.get("LINETR_BENCH_BACKEND", "nccl")),
         "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and hasattr(torch.cuda, "nccl") else None),
         "pair_match_ms": round(pair_match_ms, 4), "pair_match_latency_ms": round(pair_match_latency_ms, 4),

@@ -56,6 +56,32 @@ PinnedRing& staging_ring() {   // one ring per device (its events belong to the 
   return *r;
 }
 
+// Scratch of the one-launch single-pair matcher (pair_match_fused_kernel): column keys, row results, arrival counter.  One slot per
+// (device, stream): launches on a stream are ordered and the kernel leaves its slot clean, so a slot is never shared by two
+// launches in flight.  Allocated and initialised once (column keys all-ones, counter 0); leaked at exit like the staging ring.
+PairSlot* pair_slot(hipStream_t st) {
+  static std::mutex m;
+  static std::map<std::pair<int, hipStream_t>, PairSlot> slots;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(m);
+  auto it = slots.find({dev, st});
+  if (it != slots.end()) return &it->second;
+  char* mem = nullptr;
+  const size_t bytes = (size_t)PF_MAX_K * 16 + 256;
+  if (hipMalloc((void**)&mem, bytes) != hipSuccess) return nullptr;
+  if (hipMemset(mem, 0xff, (size_t)PF_MAX_K * 8) != hipSuccess || hipMemset(mem + (size_t)PF_MAX_K * 8, 0, (size_t)PF_MAX_K * 8 + 256) != hipSuccess ||
+      hipDeviceSynchronize() != hipSuccess) {
+    (void)hipFree(mem);
+    return nullptr;
+  }
+  PairSlot ps;
+  ps.col_best = (unsigned long long*)mem;
+  ps.row_res = (unsigned long long*)(mem + (size_t)PF_MAX_K * 8);
+  ps.counter = (unsigned*)(mem + (size_t)PF_MAX_K * 16);
+  return &(slots[{dev, st}] = ps);
+}
+
 // ints of argmin scratch one pair needs (layout in lt_match.h)
 int64_t pair_scratch_ints(int k0, int k1) { return 2 * (int64_t)k0 + 2 * (int64_t)k1 + 1 + 2 * (int64_t)cdiv(std::max(k0, 1), PM_ROWS) * k1 + 8; }
 }  // namespace
@@ -133,9 +159,29 @@ extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* 
   }
   if (max_n0 > 0 && max_n1 > 0) {
     if (!d_desc0 || !d_desc1 || !d_s2l0 || !d_s2l1 || !d_dk) return fail(LINETR_E_ARG, "match: null tensor");
-    // (r03: one fused launch for a single pair -- every block computing its own strip of D, pooling it, the last
-    // arriver finishing -- was built and measured at 0.10 ms submit-to-done against 0.08 ms for these three launches: 13
-    // blocks walking 4 column tiles x 8 K steps of exposed load latency each lose to 16 + 13 + 1 blocks in parallel.)
+    // A single pair of ordinary size: ONE launch (pair_match_fused_kernel, lt_match.h).  (r03 built a one-launch form that staged
+    // 8 K steps through LDS with a load round trip exposed at each and lost to the three launches, 0.10 vs 0.08 ms; this one keeps
+    // whole operand rows in registers -- two exposed round trips in all -- and combines the column argmin with one 64-bit atomicMin.)
+    const bool no_fused = getenv("LINETR_MATCH_THREE_LAUNCHES") != nullptr;    // A/B switch, read per call (tests, tools)
+    if (P == 1 && !no_fused && pd[0].k0 > 0 && pd[0].k1 > 0 && pd[0].n1 <= PF_MAX_N1 && pd[0].k0 <= PF_MAX_K && pd[0].k1 <= PF_MAX_K) {
+      PairSlot* ps_ = pair_slot(st);
+      if (!ps_) return fail(LINETR_E_HIP, "match: scratch allocation for the single-pair matcher failed");
+      const PairDesc& d = pd[0];
+      const size_t lds = pair_fused_lds(d.n1, d.k1);
+      static unsigned long long attr_done = 0;
+      const unsigned long long dev_bit = current_device_bit();
+      if (!(attr_done & dev_bit)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_match_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)pair_fused_lds(PF_MAX_N1, PF_MAX_N1));
+        attr_done |= dev_bit;
+      }
+      ProfScope ps(h, st, "pair_match_fused", flops, 4.0 * ((double)(d.n0 + d.n1) * D + (double)d.k0 * d.k1));
+      hipLaunchKernelGGL(pair_match_fused_kernel, dim3(cdiv(d.k0, PM_ROWS)), dim3(512), lds, st, d_desc0 + d.off_n0 * D,
+                         d_desc1 + d.off_n1 * D, d_s2l0 + d.off_s0, d_s2l1 + d.off_s1, d.n0, d.k0, d.n1, d.k1, thr, mutual,
+                         d_dk + d.off_dk, d_match01 + d.off_k0, *ps_);
+      LT_LAUNCH_CHECK();
+      return LINETR_OK;
+    }
     ProfScope ps(h, st, "pair_dist", flops, 0);
     hipLaunchKernelGGL(pair_dist_kernel, dim3(cdiv(max_n1, 64), cdiv(max_n0, 64), P), dim3(256), 0, st, tab, d_desc0,
                        d_desc1, d_dist);

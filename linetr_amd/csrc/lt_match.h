@@ -346,6 +346,204 @@ __global__ __launch_bounds__(256) void dense_pool_right_kernel(const float* __re
   if (lane == 0) Dk[(int64_t)i * k1 + j] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ONE pair in ONE launch (the latency path of Matching.forward / LineTransformer's matching tail: get_dist_matrix +
+// subline2keyline + nn_matcher_distmat, models/line_process.py:198-201, models/line_transformer.py:277-282,
+// models/nn_matcher.py:3-31).  grid = cdiv(k0, PM_ROWS) blocks of 8 waves; a block owns PM_ROWS key-lines of image 0:
+//   1. segment tables of both images from the sub-line -> key-line maps (one coalesced pass each);
+//   2. the distance rows of its sub-lines against ALL sub-lines of image 1, 16 rows at a time, by exact-fp32 MFMA
+//      (v_mfma_f32_16x16x4_f32) with NO staging: a lane fetches the 64 consecutive channels of its own row that the K order
+//      {64 (lane / 16) + s} assigns to it -- 16 independent dwordx4 loads, all in flight at once, operands straight in
+//      registers -- and two column tiles are multiplied interleaved (the MFMA's 40-cycle dependent latency hides behind the
+//      other accumulator).  Two exposed memory round trips in the whole kernel (the r03 attempt paid one per K step);
+//   3. t[r][b] = sum_a w0 D[a][b] as the rows arrive, then Dk[r][j] = sum_b t[r][b] w1 -- the summation order of pair_pool_kernel;
+//   4. row argmin per key-line; the column argmin across blocks through ONE 64-bit atomicMin per column on the packed
+//      (distance bits, row) key: distances are >= +0, so the unsigned order of the key is (distance, first row) -- np.argmin's rule;
+//   5. the last block to arrive (agent-scope counter) applies the threshold and the mutual check and leaves the slot clean
+//      (column keys all-ones, counter 0) for the next call.  Cross-block traffic is 8-byte agent-scope atomics on both sides
+//      (MI355X_MICROARCH.md, "Valid forms"): no fences.
+// Deterministic: min is order-independent, every sum has a fixed order.
+// ---------------------------------------------------------------------------------------------
+struct PairSlot {                 // library-owned scratch of the one-launch matcher, one per (device, stream); self-cleaning
+  unsigned long long* col_best;   // [PF_MAX_K] packed (distance bits << 32 | row), all-ones when idle
+  unsigned long long* row_res;    // [PF_MAX_K] packed (row minimum bits << 32 | column)
+  unsigned* counter;              // arrivals, 0 when idle
+};
+constexpr int PF_MAX_K = 4096;    // key-lines per image the slot holds
+constexpr int PF_MAX_N1 = 1024;   // sub-lines of image 1: t [PM_ROWS][n1] + a 16-row distance tile must fit the LDS
+inline size_t pair_fused_lds(int n1, int k1) {
+  const int n1p = (n1 + 15) / 16 * 16;
+  return (size_t)((k1 + 1) + (PM_ROWS + 2) + 2 * PM_ROWS * n1p) * sizeof(float) + 64;
+}
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512) void pair_match_fused_kernel(const float* __restrict__ desc0, const float* __restrict__ desc1,
+                                                               const int* __restrict__ m0, const int* __restrict__ m1, int n0, int k0,
+                                                               int n1, int k1, float thr, int mutual, float* __restrict__ dk_out,
+                                                               int* __restrict__ match01, PairSlot slot) {
+  extern __shared__ int pf_lds[];
+  const int n1p = (n1 + 15) / 16 * 16;
+  int* seg1 = pf_lds;                                            // [k1 + 1]
+  int* seg0 = seg1 + k1 + 1;                                     // [PM_ROWS + 1] (+1 pad)
+  float* tbuf = reinterpret_cast<float*>(seg0 + PM_ROWS + 2);    // [PM_ROWS][n1p]
+  float* dt = tbuf + PM_ROWS * n1p;                              // [16][n1p]; later the pooled rows [PM_ROWS][k1]
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = blockIdx.x * PM_ROWS, rows = min(PM_ROWS, k0 - i0);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int n_ct = n1p / 16;                                     // column tiles of 16 sub-lines
+  // ---- column operands of this wave's first two tiles: independent of everything else, requested first ------------------
+  f32x4v b0[16], b1[16];
+  const int ct0 = wave, ct1 = wave + 8;
+  {
+    const int c0 = min(ct0 * 16 + lr, n1 - 1), c1 = min(ct1 * 16 + lr, n1 - 1);
+    const f32x4v* p0 = reinterpret_cast<const f32x4v*>(desc1 + (int64_t)c0 * D + 64 * lg);
+    const f32x4v* p1 = reinterpret_cast<const f32x4v*>(desc1 + (int64_t)c1 * D + 64 * lg);
+    if (ct0 < n_ct) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) b0[q] = p0[q];
+    }
+    if (ct1 < n_ct) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) b1[q] = p1[q];
+    }
+  }
+  // ---- 1. segment starts (sub-lines of a key-line are contiguous, ids non-decreasing: a start is where the id changes) -------
+  for (int n = tid; n < n1; n += 512)
+    if (n == 0 || m1[n] != m1[n - 1]) seg1[m1[n]] = n;
+  for (int n = tid; n < n0; n += 512)
+    if (n == 0 || m0[n] != m0[n - 1]) {
+      const int k = m0[n] - i0;
+      if (k >= 0 && k <= rows) seg0[k] = n;
+    }
+  if (tid == 0) {
+    seg1[k1] = n1;
+    if (i0 + rows == k0) seg0[rows] = n0;
+  }
+  for (int e = tid; e < PM_ROWS * n1p; e += 512) tbuf[e] = 0.f;
+  __syncthreads();
+  const int a_lo = seg0[0], a_hi = seg0[rows];
+  // ---- 2. + 3a. distance rows, 16 sub-lines of image 0 at a time ---------------------------------------------------------
+  for (int a0 = a_lo; a0 < a_hi; a0 += 16) {
+    f32x4v av[16];
+    {
+      const int ar = min(a0 + lr, n0 - 1);
+      const f32x4v* pa = reinterpret_cast<const f32x4v*>(desc0 + (int64_t)ar * D + 64 * lg);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) av[q] = pa[q];
+    }
+    for (int ct = wave; ct < n_ct; ct += 16) {
+      const int ctb = ct + 8;
+      const bool two = ctb < n_ct;                               // wave-uniform
+      if (ct != ct0 || a0 != a_lo) {                             // beyond the prefetched pair (or a later row tile): fetch now
+        const int c0 = min(ct * 16 + lr, n1 - 1), c1 = min(ctb * 16 + lr, n1 - 1);
+        const f32x4v* p0 = reinterpret_cast<const f32x4v*>(desc1 + (int64_t)c0 * D + 64 * lg);
+        const f32x4v* p1 = reinterpret_cast<const f32x4v*>(desc1 + (int64_t)c1 * D + 64 * lg);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) b0[q] = p0[q];
+        if (two) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) b1[q] = p1[q];
+        }
+      }
+      f32x4v c0v = {0.f, 0.f, 0.f, 0.f}, c1v = {0.f, 0.f, 0.f, 0.f};
+      if (two) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            c0v = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][e], b0[q][e], c0v, 0, 0, 0);
+            c1v = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][e], b1[q][e], c1v, 0, 0, 0);
+          }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) c0v = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][e], b0[q][e], c0v, 0, 0, 0);
+      }
+      // C/D layout of the 16 x 16 tile: lane = column lr, registers = rows 4 lg + i
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dt[(4 * lg + i) * n1p + ct * 16 + lr] = fmaxf(2.f - 2.f * c0v[i], 0.f);
+        if (two) dt[(4 * lg + i) * n1p + ctb * 16 + lr] = fmaxf(2.f - 2.f * c1v[i], 0.f);
+      }
+    }
+    __syncthreads();
+    // t[r][b] += w0 D[a][b], a ascending inside its key-line (pair_pool_kernel's order)
+    const int a_end = min(a0 + 16, a_hi);
+    for (int b = tid; b < n1; b += 512) {
+      int r = 0;
+      for (int a = a0; a < a_end; ++a) {
+        while (a >= seg0[r + 1]) ++r;
+        const float w0 = 1.f / (float)(seg0[r + 1] - seg0[r]);
+        tbuf[r * n1p + b] += w0 * dt[(a - a0) * n1p + b];
+      }
+    }
+    __syncthreads();
+  }
+  // ---- 3b. Dk rows of this block (global + LDS) ------------------------------------------------------------------------
+  float* dks = dt;
+  const int total = rows * k1;
+  for (int e = tid; e < total; e += 512) {
+    const int r = e / k1, j = e - r * k1;
+    const int bb0 = seg1[j], bb1 = seg1[j + 1];
+    const float w1 = 1.f / (float)(bb1 - bb0);
+    float acc = 0.f;
+    for (int b = bb0; b < bb1; ++b) acc += tbuf[r * n1p + b] * w1;
+    dk_out[(int64_t)(i0 + r) * k1 + j] = acc;
+    dks[e] = acc;
+  }
+  __syncthreads();
+  // ---- 4. argmins ---------------------------------------------------------------------------------------------------------
+  for (int r = wave; r < rows; r += 8) {
+    float best = INFINITY; int arg = 0x7fffffff;
+    for (int j = lane; j < k1; j += 64) {
+      const float v = fmaxf(dks[r * k1 + j], 0.f);
+      if (v < best) { best = v; arg = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oa = __shfl_xor(arg, o, 64);
+      if (ov < best || (ov == best && oa < arg)) { best = ov; arg = oa; }
+    }
+    if (lane == 0) {
+      const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(arg == 0x7fffffff ? 0 : arg);
+      __hip_atomic_store(slot.row_res + i0 + r, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  for (int j = tid; j < k1; j += 512) {
+    float best = INFINITY; int arg = 0;
+    for (int r = 0; r < rows; ++r) {
+      const float v = fmaxf(dks[r * k1 + j], 0.f) + 0.f;           // (+0: a -0 would order after every positive as a key)
+      if (v < best) { best = v; arg = i0 + r; }
+    }
+    const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)arg;
+    __hip_atomic_fetch_min(slot.col_best + j, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- 5. arrival; the last block finishes -----------------------------------------------------------------------------------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) s_last = __hip_atomic_fetch_add(slot.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  for (int i = tid; i < k0; i += 512) {
+    const unsigned long long rr = __hip_atomic_load(slot.row_res + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int a = (int)(unsigned)(rr & 0xffffffffull);
+    bool keep = __uint_as_float((unsigned)(rr >> 32)) < thr;
+    if (mutual) {
+      // read through a no-op atomic: the value every other block's atomicMin left, wherever it was executed
+      const unsigned long long cb = __hip_atomic_fetch_min(slot.col_best + a, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      keep = keep && ((int)(unsigned)(cb & 0xffffffffull) == i);
+    }
+    match01[i] = keep ? a : -1;
+  }
+  __syncthreads();
+  for (int j = tid; j < k1; j += 512) __hip_atomic_store(slot.col_best + j, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_store(slot.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // [256][n] (SuperPoint 'descriptors' layout) -> [n][256]
 __global__ void transpose_cn_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int n) {
   __shared__ float tile[32][33];

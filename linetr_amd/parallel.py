@@ -141,6 +141,60 @@ def allgather_descriptors(packed: torch.Tensor, group=None, async_op: bool = Fal
     return (work, out) if async_op else out
 
 
+class NativeAllGather:
+    """The descriptor all-gather through the library's own C entry point: linetr_allgather_desc (ncclAllGather of the packed slabs,
+    include/linetr_hip.h) over an RCCL communicator that spans the ranks of the initialised torch.distributed group and is created
+    directly on the librccl PyTorch has loaded (ncclGetUniqueId on rank 0, the 128-byte id handed round with
+    dist.broadcast_object_list, ncclCommInitRank on every rank).  Same result as allgather_descriptors; exists so that the C ABI's
+    collective is exercised by the same command as the torch one (bench.py, LINETR_BENCH_COLLECTIVE=native).  One rank per DEVICE:
+    RCCL refuses two ranks on one GPU, so the single-device gloo harness cannot use it."""
+
+    def __init__(self, device, group=None):
+        import ctypes as C
+        import os
+
+        from . import _native as nat
+        self._nat, self._C = nat, C
+        self.device = torch.device(device)
+        inited = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if inited else 0
+        self.world = dist.get_world_size(group) if inited else 1
+        self._rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=C.RTLD_GLOBAL)
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        self._rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+        self._rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        self._rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        uid = UniqueId()
+        if self.rank == 0 and self._rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        box = [bytes(C.string_at(C.addressof(uid), 128))]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+            C.memmove(C.addressof(uid), box[0], 128)
+        self._comm = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self._rccl.ncclCommInitRank(C.byref(self._comm), self.world, uid, self.rank)
+        if rc != 0:
+            raise RuntimeError(f"ncclCommInitRank failed on rank {self.rank} (code {rc})")
+
+    def __call__(self, packed: torch.Tensor) -> torch.Tensor:
+        """[rows,256] slab of this rank -> [world, rows, 256]; enqueued on the current stream of the device."""
+        packed = packed.contiguous()
+        out = torch.empty((self.world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+        with torch.cuda.device(self.device):
+            st = self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            self._nat.check(self._nat.lib().linetr_allgather_desc(self._comm, packed.data_ptr(), out.data_ptr(),
+                                                                   packed.numel() * packed.element_size(), st))
+        return out
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self._rccl.ncclCommDestroy(self._comm)
+            self._comm = None
+
+
 class GatheredSet:
     """The global descriptor set after the all-gather: per-rank views + host tables, images addressed globally.
 

@@ -12,13 +12,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _run(extra):
-    env = dict(os.environ, LINETR_BENCH_ONE_DEVICE="1", LINETR_BENCH_BACKEND="gloo")
+def _run(extra, expect_failure=False, **more_env):
+    env = dict(os.environ, LINETR_BENCH_ONE_DEVICE="1", LINETR_BENCH_BACKEND="gloo", **more_env)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--settle-s", "0.2", *extra], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-2000:]
+    assert (p.returncode != 0) if expect_failure else (p.returncode == 0), p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     return json.loads(lines[0])
@@ -30,6 +30,15 @@ def test_default_workload_self_launch():
     assert d["config"]["descriptors_per_step"] > 2 * 4 * 2 * 150      # both ranks' descriptors are counted
     assert d["gathered_rows_checked"] is True and d["gather_ms"] > 0 and d["collective_backend"] == "gloo"
     assert d["global_match"]["matches"] > 0
+    # pre-flight: both ranks saw each other through the benchmark's own backend; one gather time per rank
+    assert d["preflight"]["ranks_seen"] == 2 and d["preflight"]["backend"] == "gloo" and len(d["gather_ms_per_rank"]) == 2
+
+
+def test_a_bad_gather_fails_loudly():
+    """A rank that received rows differing from what their owner packed must end the run with a non-zero exit code and ONE JSON line
+    that carries "error" and a null value -- never a normal-looking line (the failure is injected on the last rank)."""
+    d = _run(["--pairs", "4"], expect_failure=True, LINETR_BENCH_INJECT="bad_gather")
+    assert d["value"] is None and "gathered_rows_checked" in d["error"] and d["n_gpus"] == 2
 
 
 def test_cfg4_self_launch():

@@ -208,3 +208,16 @@ def test_native_allgather_entry_point_single_rank():
         assert torch.equal(out, slab)
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+def test_native_allgather_wrapper_single_rank():
+    """parallel.NativeAllGather (what bench.py runs with LINETR_BENCH_COLLECTIVE=native): the RCCL communicator is created on the
+    RCCL PyTorch loaded, the slab goes through linetr_allgather_desc, the result has torch's all-gather layout [world, rows, 256]."""
+    nag = parallel.NativeAllGather(torch.device("cuda:0"))
+    try:
+        slab = torch.randn(777, 256, device="cuda")
+        out = nag(slab)
+        torch.cuda.synchronize()
+        assert nag.world == 1 and out.shape == (1, 777, 256) and torch.equal(out[0], slab)
+    finally:
+        nag.close()

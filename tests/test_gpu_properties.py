@@ -267,3 +267,41 @@ def test_async_host_tickets_deliver_their_own_data_and_refuse_stale_ones():
         eng.collect(old)
     (h,) = eng.to_host(ts[3])
     assert (h == 3).all()
+
+
+def test_near_tie_contract(eng):
+    """"Line matches bit-exact by index" and its limit (bench.py ARGMIN_CONTRACT): the matcher's argmin equals the float64 answer
+    wherever the best-vs-second-best margin exceeds 4 x the measured distance error; a tie built ON PURPOSE below that error (two
+    candidate lines whose descriptors differ by ~1e-7) may come out as either index -- both are correct fp32 results, the
+    reference's own BLAS could flip it as well -- and never as anything else."""
+    rs = np.random.RandomState(11)
+    n0, n1 = 150, 151
+    d0 = rs.standard_normal((n0, 256)); d0 /= np.linalg.norm(d0, axis=1, keepdims=True)
+    d1 = d0[rs.permutation(n0)] + 0.15 * rs.standard_normal((n0, 256))
+    d1 = np.concatenate([d1, d1[:1]])                       # candidate 150 = candidate 0 ...
+    d1[150] += 2e-7 * rs.standard_normal(256)               # ... moved by less than an fp32 ulp of a unit vector's entries
+    d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
+    d0f, d1f = d0.astype(np.float32), d1.astype(np.float32)
+    iota0 = torch.arange(n0, dtype=torch.int32, device="cuda")
+    iota1 = torch.arange(n1, dtype=torch.int32, device="cuda")
+    dk, _, m01 = eng.match(torch.from_numpy(d0f).cuda(), np.array([0, n0]), iota0, np.array([0, n0]), torch.from_numpy(d1f).cuda(),
+                           np.array([0, n1]), iota1, np.array([0, n1]), 10.0, False)      # one-way, no threshold: the raw row argmin
+    got = m01.cpu().numpy()
+    exact = np.clip(2.0 - 2.0 * d0f.astype(np.float64) @ d1f.astype(np.float64).T, 0, None)
+    err = float(np.abs(dk.cpu().numpy().reshape(n0, n1) - exact).max())
+    assert err < 2e-6
+    srt = np.sort(exact, axis=1)
+    margin = srt[:, 1] - srt[:, 0]
+    best = exact.argmin(1)
+    safe = margin > 4 * err
+    assert safe.sum() >= n0 - 2 and np.array_equal(got[safe], best[safe])          # by arithmetic
+    tied = np.nonzero(~safe)[0]
+    assert len(tied) >= 1                                                           # the constructed tie is in there
+    for i in tied:                                                                  # either index of the tie, nothing else
+        assert exact[i, got[i]] - exact[i, best[i]] <= 4 * err, (i, got[i], best[i])
+    i_tie = int(np.nonzero(best == 0)[0][0]) if (best == 0).any() else int(np.nonzero(best == 150)[0][0])
+    assert got[i_tie] in (0, 150)
+    # deterministic: the same call gives the same index every time
+    for _ in range(5):
+        assert np.array_equal(eng.match(torch.from_numpy(d0f).cuda(), np.array([0, n0]), iota0, np.array([0, n0]),
+                                        torch.from_numpy(d1f).cuda(), np.array([0, n1]), iota1, np.array([0, n1]), 10.0, False)[2].cpu().numpy(), got)
