@@ -272,6 +272,13 @@ int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_t n0, int32
                          int32_t mutual, int32_t* d_match01, void* d_workspace, int64_t workspace_bytes,
                          void* stream);
 
+/* nn_matcher_distmat (models/nn_matcher.py:3-31) on a float64 device matrix d_dist [n0,n1], compared in float64 the way NumPy
+ * compares a float64 matrix (the reference's own caller passes float32: linetr_match_distmat).  nn_thresh is a double.  `h` may
+ * be NULL; asynchronous on `stream`. */
+int64_t linetr_match_distmat_f64_workspace_bytes(int32_t n0, int32_t n1);
+int linetr_match_distmat_f64(LinetrHandle* h, const double* d_dist, int32_t n0, int32_t n1, double nn_thresh, int32_t mutual,
+                             int32_t* d_match01, void* d_workspace, int64_t workspace_bytes, void* stream);
+
 /* LineTransformer.subline2keyline (models/line_transformer.py:277-282) alone: Dk [k0,k1] = A0 D A1^T for a sub-line distance
  * matrix d_dist [n0,n1] that already lives on the device, the two mat_klines2sublines given as the sub-line -> key-line maps
  * linetr_tokenize writes (non-decreasing; rows of A are 1/num_sublines).  `h` may be NULL.  Asynchronous on `stream`. */

@@ -58,7 +58,7 @@ PinnedRing& staging_ring() {   // one ring per device (its events belong to the 
 
 // Scratch of the one-launch single-pair matcher (pair_match_fused_kernel): column keys, row results, arrival counter.  One slot per
 // (device, stream): launches on a stream are ordered and the kernel leaves its slot clean, so a slot is never shared by two
-// launches in flight.  Allocated and initialised once (column keys all-ones, counter 0); leaked at exit like the staging ring.
+// launches in flight.  Allocated and initialised once (column and row keys all-ones, counter 0); leaked at exit like the staging ring.
 PairSlot* pair_slot(hipStream_t st) {
   static std::mutex m;
   static std::map<std::pair<int, hipStream_t>, PairSlot> slots;
@@ -70,7 +70,7 @@ PairSlot* pair_slot(hipStream_t st) {
   char* mem = nullptr;
   const size_t bytes = (size_t)PF_MAX_K * 16 + 256;
   if (hipMalloc((void**)&mem, bytes) != hipSuccess) return nullptr;
-  if (hipMemset(mem, 0xff, (size_t)PF_MAX_K * 8) != hipSuccess || hipMemset(mem + (size_t)PF_MAX_K * 8, 0, (size_t)PF_MAX_K * 8 + 256) != hipSuccess ||
+  if (hipMemset(mem, 0xff, (size_t)PF_MAX_K * 16) != hipSuccess || hipMemset(mem + (size_t)PF_MAX_K * 16, 0, 256) != hipSuccess ||
       hipDeviceSynchronize() != hipSuccess) {
     (void)hipFree(mem);
     return nullptr;
@@ -171,14 +171,26 @@ extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* 
       static unsigned long long attr_done = 0;
       const unsigned long long dev_bit = current_device_bit();
       if (!(attr_done & dev_bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_match_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_match_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)pair_fused_lds(PF_MAX_N1, PF_MAX_N1));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_match_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)pair_fused_lds(PF_MAX_N1, PF_MAX_N1));
         attr_done |= dev_bit;
       }
       ProfScope ps(h, st, "pair_match_fused", flops, 4.0 * ((double)(d.n0 + d.n1) * D + (double)d.k0 * d.k1));
-      hipLaunchKernelGGL(pair_match_fused_kernel, dim3(cdiv(d.k0, PM_ROWS)), dim3(512), lds, st, d_desc0 + d.off_n0 * D,
-                         d_desc1 + d.off_n1 * D, d_s2l0 + d.off_s0, d_s2l1 + d.off_s1, d.n0, d.k0, d.n1, d.k1, thr, mutual,
-                         d_dk + d.off_dk, d_match01 + d.off_k0, *ps_);
+      // one sub-line per key-line on both sides (known from the counts alone: the maps are onto): Dk = D, columns split over two
+      // blocks when a wave would otherwise multiply two tiles
+      const bool ident = d.n0 == d.k0 && d.n1 == d.k1;
+      const float* a0 = d_desc0 + d.off_n0 * D; const float* a1 = d_desc1 + d.off_n1 * D;
+      if (ident) {
+        const int n_ct = cdiv(d.n1, 16);
+        hipLaunchKernelGGL(pair_match_fused_kernel<true>, dim3(cdiv(d.k0, PM_ROWS), cdiv(n_ct, 8)), dim3(512), lds, st, a0, a1,
+                           d_s2l0 + d.off_s0, d_s2l1 + d.off_s1, d.n0, d.k0, d.n1, d.k1, thr, mutual, d_dk + d.off_dk,
+                           d_match01 + d.off_k0, *ps_);
+      } else {
+        hipLaunchKernelGGL(pair_match_fused_kernel<false>, dim3(cdiv(d.k0, PM_ROWS)), dim3(512), lds, st, a0, a1, d_s2l0 + d.off_s0,
+                           d_s2l1 + d.off_s1, d.n0, d.k0, d.n1, d.k1, thr, mutual, d_dk + d.off_dk, d_match01 + d.off_k0, *ps_);
+      }
       LT_LAUNCH_CHECK();
       return LINETR_OK;
     }
@@ -287,6 +299,32 @@ extern "C" int linetr_match_distmat(LinetrHandle* h, const float* d_dist, int32_
     LT_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(pair_final_kernel, dim3(1), dim3(256), 0, st, tab, thr, mutual, d_match01, (int*)(base + o_scr));
+  LT_LAUNCH_CHECK();
+  return LINETR_OK;
+}
+
+extern "C" int64_t linetr_match_distmat_f64_workspace_bytes(int32_t n0, int32_t n1) {
+  n0 = std::max(n0, 0); n1 = std::max(n1, 0);
+  return align_up((int64_t)n0 * 8, 256) + align_up((int64_t)n0 * 4, 256) + align_up((int64_t)std::max(n1, 1) * 4, 256) + 256;
+}
+
+extern "C" int linetr_match_distmat_f64(LinetrHandle* h, const double* d_dist, int32_t n0, int32_t n1, double thr, int32_t mutual,
+                                        int32_t* d_match01, void* d_ws, int64_t ws_bytes, void* stream) {
+  if (n0 < 0 || n1 < 0) return fail(LINETR_E_ARG, "match_distmat_f64: bad argument");
+  if (n0 == 0) return LINETR_OK;
+  if (!d_match01 || !d_ws || (n1 > 0 && !d_dist)) return fail(LINETR_E_ARG, "match_distmat_f64: null pointer");
+  if (ws_bytes < linetr_match_distmat_f64_workspace_bytes(n0, n1)) return fail(LINETR_E_WORKSPACE, "match_distmat_f64: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (h) LT_HIP(hipSetDevice(h->device));
+  if (n1 == 0) { LT_HIP(hipMemsetAsync(d_match01, 0xff, (size_t)n0 * 4, st)); return LINETR_OK; }
+  char* base = (char*)d_ws;
+  double* row_min = (double*)base;
+  int* row_arg = (int*)(base + align_up((int64_t)n0 * 8, 256));
+  int* col_arg = (int*)((char*)row_arg + align_up((int64_t)n0 * 4, 256));
+  hipLaunchKernelGGL(argmin_rows_f64_kernel, dim3(cdiv(n0, 4)), dim3(256), 0, st, d_dist, n0, n1, row_arg, row_min);
+  hipLaunchKernelGGL(argmin_cols_f64_kernel, dim3(cdiv(n1, 256)), dim3(256), 0, st, d_dist, n0, n1, col_arg);
+  hipLaunchKernelGGL(match_final_f64_kernel, dim3(cdiv(n0, 256)), dim3(256), 0, st, (const int*)row_arg, (const double*)row_min,
+                     (const int*)col_arg, n0, thr, mutual, d_match01);
   LT_LAUNCH_CHECK();
   return LINETR_OK;
 }

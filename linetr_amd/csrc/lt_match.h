@@ -378,6 +378,11 @@ inline size_t pair_fused_lds(int n1, int k1) {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// IDENT: every key-line of both images has exactly one sub-line (n == k on both sides: the point matcher always, line pairs whose
+// lines are all shorter than token_distance x max_tokens): Dk IS D, so the segment tables, the t stage and the pooling stage
+// disappear, the row operands are requested at the first instruction, and the columns are split over gridDim.y blocks (the row
+// argmin is then combined across blocks like the column argmin, by atomicMin on the packed key).
+template <bool IDENT>
 __global__ __launch_bounds__(512) void pair_match_fused_kernel(const float* __restrict__ desc0, const float* __restrict__ desc1,
                                                                const int* __restrict__ m0, const int* __restrict__ m1, int n0, int k0,
                                                                int n1, int k1, float thr, int mutual, float* __restrict__ dk_out,
@@ -393,37 +398,43 @@ __global__ __launch_bounds__(512) void pair_match_fused_kernel(const float* __re
   const int i0 = blockIdx.x * PM_ROWS, rows = min(PM_ROWS, k0 - i0);
   const int lr = lane & 15, lg = lane >> 4;
   const int n_ct = n1p / 16;                                     // column tiles of 16 sub-lines
+  // column tiles of this block (IDENT: split over gridDim.y) and of this wave
+  const int ct_lo = IDENT ? (int)blockIdx.y * ((n_ct + (int)gridDim.y - 1) / (int)gridDim.y) : 0;
+  const int ct_hi = IDENT ? min(n_ct, ct_lo + (n_ct + (int)gridDim.y - 1) / (int)gridDim.y) : n_ct;
   // ---- column operands of this wave's first two tiles: independent of everything else, requested first ------------------
   f32x4v b0[16], b1[16];
-  const int ct0 = wave, ct1 = wave + 8;
+  const int ct0 = ct_lo + wave, ct1 = ct0 + 8;
   {
     const int c0 = min(ct0 * 16 + lr, n1 - 1), c1 = min(ct1 * 16 + lr, n1 - 1);
     const f32x4v* p0 = reinterpret_cast<const f32x4v*>(desc1 + (int64_t)c0 * D + 64 * lg);
     const f32x4v* p1 = reinterpret_cast<const f32x4v*>(desc1 + (int64_t)c1 * D + 64 * lg);
-    if (ct0 < n_ct) {
+    if (ct0 < ct_hi) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) b0[q] = p0[q];
     }
-    if (ct1 < n_ct) {
+    if (ct1 < ct_hi) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) b1[q] = p1[q];
     }
   }
-  // ---- 1. segment starts (sub-lines of a key-line are contiguous, ids non-decreasing: a start is where the id changes) -------
-  for (int n = tid; n < n1; n += 512)
-    if (n == 0 || m1[n] != m1[n - 1]) seg1[m1[n]] = n;
-  for (int n = tid; n < n0; n += 512)
-    if (n == 0 || m0[n] != m0[n - 1]) {
-      const int k = m0[n] - i0;
-      if (k >= 0 && k <= rows) seg0[k] = n;
+  int a_lo = i0, a_hi = i0 + rows;
+  if constexpr (!IDENT) {
+    // ---- 1. segment starts (sub-lines of a key-line are contiguous, ids non-decreasing: a start is where the id changes) -----
+    for (int n = tid; n < n1; n += 512)
+      if (n == 0 || m1[n] != m1[n - 1]) seg1[m1[n]] = n;
+    for (int n = tid; n < n0; n += 512)
+      if (n == 0 || m0[n] != m0[n - 1]) {
+        const int k = m0[n] - i0;
+        if (k >= 0 && k <= rows) seg0[k] = n;
+      }
+    if (tid == 0) {
+      seg1[k1] = n1;
+      if (i0 + rows == k0) seg0[rows] = n0;
     }
-  if (tid == 0) {
-    seg1[k1] = n1;
-    if (i0 + rows == k0) seg0[rows] = n0;
+    for (int e = tid; e < PM_ROWS * n1p; e += 512) tbuf[e] = 0.f;
+    __syncthreads();
+    a_lo = seg0[0]; a_hi = seg0[rows];
   }
-  for (int e = tid; e < PM_ROWS * n1p; e += 512) tbuf[e] = 0.f;
-  __syncthreads();
-  const int a_lo = seg0[0], a_hi = seg0[rows];
   // ---- 2. + 3a. distance rows, 16 sub-lines of image 0 at a time ---------------------------------------------------------
   for (int a0 = a_lo; a0 < a_hi; a0 += 16) {
     f32x4v av[16];
@@ -433,9 +444,9 @@ __global__ __launch_bounds__(512) void pair_match_fused_kernel(const float* __re
 #pragma unroll
       for (int q = 0; q < 16; ++q) av[q] = pa[q];
     }
-    for (int ct = wave; ct < n_ct; ct += 16) {
+    for (int ct = ct0; ct < ct_hi; ct += 16) {
       const int ctb = ct + 8;
-      const bool two = ctb < n_ct;                               // wave-uniform
+      const bool two = ctb < ct_hi;                              // wave-uniform
       if (ct != ct0 || a0 != a_lo) {                             // beyond the prefetched pair (or a later row tile): fetch now
         const int c0 = min(ct * 16 + lr, n1 - 1), c1 = min(ctb * 16 + lr, n1 - 1);
         const f32x4v* p0 = reinterpret_cast<const f32x4v*>(desc1 + (int64_t)c0 * D + 64 * lg);
@@ -457,10 +468,17 @@ __global__ __launch_bounds__(512) void pair_match_fused_kernel(const float* __re
             c1v = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][e], b1[q][e], c1v, 0, 0, 0);
           }
       } else {
+        // one tile: two accumulators over alternating K steps (a single chain waits the MFMA's 40-cycle dependent latency on every
+        // step), added at the end in a fixed order
 #pragma unroll
         for (int q = 0; q < 16; ++q)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) c0v = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][e], b0[q][e], c0v, 0, 0, 0);
+          for (int e = 0; e < 4; e += 2) {
+            c0v = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][e], b0[q][e], c0v, 0, 0, 0);
+            c1v = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][e + 1], b0[q][e + 1], c1v, 0, 0, 0);
+          }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c0v[i] += c1v[i];
       }
       // C/D layout of the 16 x 16 tile: lane = column lr, registers = rows 4 lg + i
 #pragma unroll
@@ -470,36 +488,50 @@ __global__ __launch_bounds__(512) void pair_match_fused_kernel(const float* __re
       }
     }
     __syncthreads();
-    // t[r][b] += w0 D[a][b], a ascending inside its key-line (pair_pool_kernel's order)
-    const int a_end = min(a0 + 16, a_hi);
-    for (int b = tid; b < n1; b += 512) {
-      int r = 0;
-      for (int a = a0; a < a_end; ++a) {
-        while (a >= seg0[r + 1]) ++r;
-        const float w0 = 1.f / (float)(seg0[r + 1] - seg0[r]);
-        tbuf[r * n1p + b] += w0 * dt[(a - a0) * n1p + b];
+    if constexpr (!IDENT) {
+      // t[r][b] += w0 D[a][b], a ascending inside its key-line (pair_pool_kernel's order)
+      const int a_end = min(a0 + 16, a_hi);
+      for (int b = tid; b < n1; b += 512) {
+        int r = 0;
+        for (int a = a0; a < a_end; ++a) {
+          while (a >= seg0[r + 1]) ++r;
+          const float w0 = 1.f / (float)(seg0[r + 1] - seg0[r]);
+          tbuf[r * n1p + b] += w0 * dt[(a - a0) * n1p + b];
+        }
       }
+      __syncthreads();
+    }
+  }
+  // ---- 3b. Dk rows of this block (global + LDS: `dks`, row stride `ldk`, columns j_lo .. j_hi) --------------------------------
+  const float* dks = dt;
+  int ldk = n1p, j_lo = 0, j_hi = k1;
+  if constexpr (IDENT) {
+    j_lo = ct_lo * 16; j_hi = min(k1, ct_hi * 16);
+    const int w = j_hi - j_lo;
+    for (int e = tid; e < rows * w; e += 512) {
+      const int r = e / w, j = j_lo + e - r * w;
+      dk_out[(int64_t)(i0 + r) * k1 + j] = dt[r * n1p + j];
+    }
+  } else {
+    float* dkw = dt;
+    ldk = k1;
+    const int total = rows * k1;
+    for (int e = tid; e < total; e += 512) {
+      const int r = e / k1, j = e - r * k1;
+      const int bb0 = seg1[j], bb1 = seg1[j + 1];
+      const float w1 = 1.f / (float)(bb1 - bb0);
+      float acc = 0.f;
+      for (int b = bb0; b < bb1; ++b) acc += tbuf[r * n1p + b] * w1;
+      dk_out[(int64_t)(i0 + r) * k1 + j] = acc;
+      dkw[e] = acc;              // (e = r k1 + j: element e of a row tile is never read as D again -- the t stage is complete)
     }
     __syncthreads();
   }
-  // ---- 3b. Dk rows of this block (global + LDS) ------------------------------------------------------------------------
-  float* dks = dt;
-  const int total = rows * k1;
-  for (int e = tid; e < total; e += 512) {
-    const int r = e / k1, j = e - r * k1;
-    const int bb0 = seg1[j], bb1 = seg1[j + 1];
-    const float w1 = 1.f / (float)(bb1 - bb0);
-    float acc = 0.f;
-    for (int b = bb0; b < bb1; ++b) acc += tbuf[r * n1p + b] * w1;
-    dk_out[(int64_t)(i0 + r) * k1 + j] = acc;
-    dks[e] = acc;
-  }
-  __syncthreads();
-  // ---- 4. argmins ---------------------------------------------------------------------------------------------------------
+  // ---- 4. argmins: both combined across blocks by a 64-bit atomicMin on (distance bits, index) ----------------------------------
   for (int r = wave; r < rows; r += 8) {
     float best = INFINITY; int arg = 0x7fffffff;
-    for (int j = lane; j < k1; j += 64) {
-      const float v = fmaxf(dks[r * k1 + j], 0.f);
+    for (int j = j_lo + lane; j < j_hi; j += 64) {
+      const float v = fmaxf(dks[r * ldk + j], 0.f) + 0.f;          // (+0: a -0 would order after every positive as a key)
       if (v < best) { best = v; arg = j; }
     }
 #pragma unroll
@@ -508,15 +540,15 @@ __global__ __launch_bounds__(512) void pair_match_fused_kernel(const float* __re
       const int oa = __shfl_xor(arg, o, 64);
       if (ov < best || (ov == best && oa < arg)) { best = ov; arg = oa; }
     }
-    if (lane == 0) {
-      const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(arg == 0x7fffffff ? 0 : arg);
-      __hip_atomic_store(slot.row_res + i0 + r, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0 && arg != 0x7fffffff) {                          // (an all-inf row leaves the all-ones key: column 0xffffffff, rejected below)
+      const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)arg;
+      __hip_atomic_fetch_min(slot.row_res + i0 + r, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  for (int j = tid; j < k1; j += 512) {
+  for (int j = j_lo + tid; j < j_hi; j += 512) {
     float best = INFINITY; int arg = 0;
     for (int r = 0; r < rows; ++r) {
-      const float v = fmaxf(dks[r * k1 + j], 0.f) + 0.f;           // (+0: a -0 would order after every positive as a key)
+      const float v = fmaxf(dks[r * ldk + j], 0.f) + 0.f;
       if (v < best) { best = v; arg = i0 + r; }
     }
     const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)arg;
@@ -525,23 +557,71 @@ __global__ __launch_bounds__(512) void pair_match_fused_kernel(const float* __re
   // ---- 5. arrival; the last block finishes -----------------------------------------------------------------------------------
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) s_last = __hip_atomic_fetch_add(slot.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  if (tid == 0)
+    s_last = __hip_atomic_fetch_add(slot.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1;
   __syncthreads();
   if (!s_last) return;
   for (int i = tid; i < k0; i += 512) {
-    const unsigned long long rr = __hip_atomic_load(slot.row_res + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int a = (int)(unsigned)(rr & 0xffffffffull);
-    bool keep = __uint_as_float((unsigned)(rr >> 32)) < thr;
+    // read AND reset through one atomic exchange: the value every block's atomicMin left, wherever it was executed
+    const unsigned long long rr = __hip_atomic_exchange(slot.row_res + i, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned a = (unsigned)(rr & 0xffffffffull);
+    bool keep = a < (unsigned)k1 && __uint_as_float((unsigned)(rr >> 32)) < thr;
+    const int aa = a < (unsigned)k1 ? (int)a : 0;
     if (mutual) {
-      // read through a no-op atomic: the value every other block's atomicMin left, wherever it was executed
-      const unsigned long long cb = __hip_atomic_fetch_min(slot.col_best + a, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long cb = __hip_atomic_load(slot.col_best + aa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       keep = keep && ((int)(unsigned)(cb & 0xffffffffull) == i);
     }
-    match01[i] = keep ? a : -1;
+    match01[i] = keep ? aa : -1;
   }
   __syncthreads();
   for (int j = tid; j < k1; j += 512) __hip_atomic_store(slot.col_best + j, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid == 0) __hip_atomic_store(slot.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// nn_matcher_distmat (models/nn_matcher.py:3-31) on a float64 matrix, compared IN float64 like NumPy does with one: clip(min = 0),
+// first-index argmin of rows and columns, strict `<` against the threshold, optional mutual check.  (The reference's Matching
+// passes float32, which the kernels above serve; this is the form a caller with a float64 matrix gets, instead of a rounding to
+// float32 that could merge two distinct distances.)  Cold path: plain kernels.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void argmin_rows_f64_kernel(const double* __restrict__ d, int n0, int n1, int* __restrict__ row_arg,
+                                                              double* __restrict__ row_min) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n0) return;
+  double best = INFINITY; int arg = 0x7fffffff;
+  for (int j = lane; j < n1; j += 64) {
+    const double v = fmax(d[(int64_t)r * n1 + j], 0.0);
+    if (v < best) { best = v; arg = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(best, o, 64);
+    const int oa = __shfl_xor(arg, o, 64);
+    if (ov < best || (ov == best && oa < arg)) { best = ov; arg = oa; }
+  }
+  if (lane == 0) { row_arg[r] = arg == 0x7fffffff ? 0 : arg; row_min[r] = best; }
+}
+
+__global__ __launch_bounds__(256) void argmin_cols_f64_kernel(const double* __restrict__ d, int n0, int n1, int* __restrict__ col_arg) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n1) return;
+  double best = INFINITY; int arg = 0;
+  for (int r = 0; r < n0; ++r) {                       // ascending rows, strict <: the first minimum
+    const double v = fmax(d[(int64_t)r * n1 + j], 0.0);
+    if (v < best) { best = v; arg = r; }
+  }
+  col_arg[j] = arg;
+}
+
+__global__ __launch_bounds__(256) void match_final_f64_kernel(const int* __restrict__ row_arg, const double* __restrict__ row_min,
+                                                              const int* __restrict__ col_arg, int n0, double thr, int mutual,
+                                                              int* __restrict__ match01) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n0) return;
+  const int a = row_arg[i];
+  bool keep = row_min[i] < thr;
+  if (mutual) keep = keep && col_arg[a] == i;
+  match01[i] = keep ? a : -1;
 }
 
 // [256][n] (SuperPoint 'descriptors' layout) -> [n][256]

@@ -43,10 +43,10 @@ def match01_to_matrix(m01: np.ndarray, n1: int) -> np.ndarray:
 def nn_matcher_distmat(dist_mat, nn_thresh, is_mutual_NN=True):
     """Nearest-neighbour matching on a [1,n0,n1] distance matrix (reference: nn_matcher.py:3-31).
 
-    Contract of the device matcher: the argmin / threshold run in float32 (the dtype `Matching` passes; a float64
-    matrix is rounded to float32 first, so values within one float32 ulp of each other or of `nn_thresh` may match
-    differently from the reference's float64 comparison) and the matrix must be NaN-free: np.argmin returns the first
-    NaN, the kernel would skip it, so a NaN raises ValueError here instead of silently diverging."""
+    The comparison runs in the matrix's own precision, as NumPy's does: a float32 matrix (what `Matching` passes) is compared in
+    float32 against the float32 of `nn_thresh`, a float64 matrix in float64 against the Python float (linetr_match_distmat /
+    linetr_match_distmat_f64); other dtypes are taken to float64.  The matrix must be NaN-free: np.argmin returns the first NaN, the
+    kernels would skip it, so a NaN raises ValueError here instead of silently diverging."""
     dist_mat = np.asarray(dist_mat)
     n0, n1 = dist_mat.shape[1], dist_mat.shape[2]
     if n0 == 0 or n1 == 0:
@@ -54,13 +54,18 @@ def nn_matcher_distmat(dist_mat, nn_thresh, is_mutual_NN=True):
     if np.isnan(dist_mat).any():
         raise ValueError("nn_matcher_distmat: the distance matrix contains NaN")
     dev = _device()
-    d = torch.from_numpy(np.ascontiguousarray(dist_mat[0], dtype=np.float32)).to(dev)
     m01 = torch.empty((n0,), dtype=torch.int32, device=dev)
-    need = nat.lib().linetr_match_distmat_workspace_bytes(n0, n1)
-    ws = _workspace(dev, need)
-    nat.check(nat.lib().linetr_match_distmat(None, d.data_ptr(), n0, n1, float(np.float32(nn_thresh)),
-                                             int(bool(is_mutual_NN)), m01.data_ptr(), ws.data_ptr(), ws.numel(),
-                                             _stream(dev)))
+    L = nat.lib()
+    if dist_mat.dtype == np.float32:
+        d = torch.from_numpy(np.ascontiguousarray(dist_mat[0])).to(dev)
+        ws = _workspace(dev, L.linetr_match_distmat_workspace_bytes(n0, n1))
+        nat.check(L.linetr_match_distmat(None, d.data_ptr(), n0, n1, float(np.float32(nn_thresh)), int(bool(is_mutual_NN)),
+                                         m01.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
+    else:
+        d = torch.from_numpy(np.ascontiguousarray(dist_mat[0], dtype=np.float64)).to(dev)
+        ws = _workspace(dev, L.linetr_match_distmat_f64_workspace_bytes(n0, n1))
+        nat.check(L.linetr_match_distmat_f64(None, d.data_ptr(), n0, n1, float(nn_thresh), int(bool(is_mutual_NN)), m01.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), _stream(dev)))
     return match01_to_matrix(m01.cpu().numpy(), n1)
 
 

@@ -247,6 +247,17 @@ def test_matcher_fuzz_ties_and_threshold_edges():
         got = NM.nn_matcher_distmat(d, thr, mutual)
         want = O.mutual_nn(d, thr, mutual)
         assert got.dtype == np.float64 and np.array_equal(got, want), (case, n0, n1, mutual)
+    # a float64 matrix is compared in float64, like NumPy compares it (linetr_match_distmat_f64): distances that differ below
+    # float32 resolution, and a threshold between two float64 neighbours of 0.8, must come out as the reference says
+    for case in range(100):
+        n0, n1 = rs.randint(1, 41), rs.randint(1, 41)
+        d64 = vals.astype(np.float64)[rs.randint(0, len(vals), (1, n0, n1))] + rs.randint(-2, 3, (1, n0, n1)) * 1e-12
+        d64[d64 < 0] = -1e-12                                      # negatives clip to 0: ties at zero, first index
+        mutual = bool(case % 2)
+        for thr in (0.8, 0.8 + 1e-12):
+            got = NM.nn_matcher_distmat(d64, thr, mutual)
+            want = O.mutual_nn(d64, thr, mutual)
+            assert np.array_equal(got, want), (case, n0, n1, mutual, thr)
 
 
 def test_async_host_tickets_deliver_their_own_data_and_refuse_stale_ones():

@@ -22,11 +22,11 @@ def test_library_exports_every_declared_symbol():
     exp = re.search(r"#ifdef LINETR_EXPERIMENTS(.*?)#endif\s*/\* LINETR_EXPERIMENTS \*/", hdr, re.S)
     assert exp, "experiments section of the header not found"
     product_hdr = hdr.replace(exp.group(0), "")
-    declared = set(re.findall(r"\b(linetr_[a-z_]+)\s*\(", product_hdr))
+    declared = set(re.findall(r"\b(linetr_[a-z0-9_]+)\s*\(", product_hdr))
     assert declared == set(nat.EXPORTS), declared ^ set(nat.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    declared_x = set(re.findall(r"\b(linetr_[a-z_]+)\s*\(", exp.group(1)))
+    declared_x = set(re.findall(r"\b(linetr_[a-z0-9_]+)\s*\(", exp.group(1)))
     assert declared_x == set(nat.EXPERIMENT_EXPORTS), declared_x ^ set(nat.EXPERIMENT_EXPORTS)
     for name in declared_x:
         assert not hasattr(L, name), f"{name} must not be in the product library"
