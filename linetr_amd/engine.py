@@ -608,21 +608,41 @@ class Engine:
         s2l_flat int32) sit at arbitrary offsets of the same two buffers -- the form global matching over the all-gathered
         set uses (parallel.global_match).  dims [P,4] = (n0,k0,n1,k1).
         Returns (Dk_flat, off_dk host [P+1], match01 int32 [sum k0], off_k0 host [P+1])."""
-        dims = np.ascontiguousarray(dims, dtype=np.int32)
         P = len(dims)
         i64 = np.int64
-        if P == 1:                      # latency path of a single pair: no cumsums, no reductions
-            n0, k0, n1, k1 = (int(v) for v in dims[0])
-            off_dk = np.array([0, k0 * k1], dtype=i64)
-            off_k0 = np.array([0, k0], dtype=i64)
-            sum_nn, sum_k = n0 * n1, k0 + k1
-        else:
-            off_dk = np.zeros(P + 1, dtype=i64)
-            np.cumsum(dims[:, 1].astype(i64) * dims[:, 3].astype(i64), out=off_dk[1:])
-            off_k0 = np.zeros(P + 1, dtype=i64)
-            np.cumsum(dims[:, 1].astype(i64), out=off_k0[1:])
-            sum_nn = int((dims[:, 0].astype(i64) * dims[:, 2].astype(i64)).sum()) if P else 0
-            sum_k = int(dims[:, 1].sum() + dims[:, 3].sum()) if P else 0
+        if P == 1:
+            # latency path of a single pair: the seven small host tables of a given (dims, offsets) are built once and kept (a
+            # NumPy array costs ~1 us to make; the call is ~45 us end to end)
+            key1 = (int(dims[0][0]), int(dims[0][1]), int(dims[0][2]), int(dims[0][3]), int(off_n0[0]), int(off_s0[0]), int(off_n1[0]),
+                    int(off_s1[0]))
+            cache = self.__dict__.setdefault("_pair_tables", {})
+            tabs = cache.get(key1)
+            if tabs is None:
+                if len(cache) > 256:
+                    cache.clear()
+                n0, k0, n1, k1 = key1[:4]
+                tabs = cache[key1] = (np.array([key1[:4]], dtype=np.int32), np.array([0, k0 * k1], dtype=i64), np.array([0, k0], dtype=i64),
+                                      np.array([key1[4]], dtype=i64), np.array([key1[6]], dtype=i64), np.array([key1[5]], dtype=i64),
+                                      np.array([key1[7]], dtype=i64), self._L.linetr_match_workspace_bytes(1, n0 * n1, 0, k0 + k1))
+            dims1, off_dk, off_k0, o0, o1, s0, s1, ws_bytes = tabs
+            dk = torch.empty((max(int(off_dk[1]), 1),), dtype=torch.float32, device=self.device)
+            m01 = torch.empty((max(int(off_k0[1]), 1),), dtype=torch.int32, device=self.device)
+            ws = self._workspace("match", ws_bytes)
+            d = desc_flat if (desc_flat.dtype == torch.float32 and desc_flat.is_contiguous() and desc_flat.device == self.device) \
+                else self._f32(desc_flat)
+            nat.check(self._L.linetr_match_gathered(self._h, 1, dims1.ctypes.data, d.data_ptr(), o0.ctypes.data, s2l_flat.data_ptr(),
+                                                    s0.ctypes.data, d.data_ptr(), o1.ctypes.data, s2l_flat.data_ptr(),
+                                                    s1.ctypes.data, float(thr), int(bool(mutual)), dk.data_ptr(),
+                                                    off_dk.ctypes.data, m01.data_ptr(), off_k0.ctypes.data, ws.data_ptr(), ws.numel(),
+                                                    self._stream()), self._L)
+            return dk[:int(off_dk[1])], off_dk, m01[:int(off_k0[1])], off_k0
+        dims = np.ascontiguousarray(dims, dtype=np.int32).reshape(P, 4)
+        off_dk = np.zeros(P + 1, dtype=i64)
+        np.cumsum(dims[:, 1].astype(i64) * dims[:, 3].astype(i64), out=off_dk[1:])
+        off_k0 = np.zeros(P + 1, dtype=i64)
+        np.cumsum(dims[:, 1].astype(i64), out=off_k0[1:])
+        sum_nn = int((dims[:, 0].astype(i64) * dims[:, 2].astype(i64)).sum()) if P else 0
+        sum_k = int(dims[:, 1].sum() + dims[:, 3].sum()) if P else 0
         dk = torch.empty((max(int(off_dk[-1]), 1),), dtype=torch.float32, device=self.device)
         m01 = torch.empty((max(int(off_k0[-1]), 1),), dtype=torch.int32, device=self.device)
         if P == 0:
