@@ -44,7 +44,7 @@ from linetr_amd.engine import Engine  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA
 HBM_PEAK_GBS = 8000.0
-PROFILE_TAG = "r04"             # profiles/<tag>_<workload>_pmc_traffic.json, profiles/<tag>_<workload>_gemm_pmc.json
+PROFILE_TAG = "r05"             # profiles/<tag>_<workload>_pmc_traffic.json, profiles/<tag>_<workload>_gemm_pmc.json
 
 WORKLOADS = {
     # name: (H, W, lines/image, len_lo, len_hi, max_tokens, default pairs per GPU)

@@ -548,6 +548,42 @@ def test_train_mode_forward_golden():
     assert (eval_after.cpu() - want).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("B,n_fix,momentum,wseed", [(1, 7, 0.1, 0), (2, 33, 0.5, 3), (4, 50, 0.1, 0), (3, 1, 0.25, 5)])
+def test_train_mode_forward_vs_oracle_random_batches(B, n_fix, momentum, wseed):
+    """The train-mode forward against the oracle's restatement (pinned to the real reference by test_oracle_golden.py) on batches of
+    other shapes than the fixture's: one sample, a single sub-line per image (BatchNorm over B rows), another momentum, raw seeded
+    weights.  Descriptors <= 1e-4 where the batch statistics are well conditioned, running statistics to 2e-5 relative."""
+    from models.line_transformer import LineTransformer
+    from oracle import linetr_oracle as O
+    sdn = synth.calibrated_state_dict() if wseed == 0 else synth.make_state_dict(wseed)
+    m = LineTransformer({**LT_CFG}).eval()
+    m.load_state_dict(synth.to_torch_state_dict(sdn), strict=True)
+    m = m.to("cuda")
+    keys = ("sublines", "pnt_sublines", "desc_sublines", "score_sublines", "mask_sublines", "resp_sublines", "angle_sublines", "klines")
+    outs = []
+    for b in range(B):
+        dd, ds = synth.synth_dense_maps_np(700 + b, 480, 640)
+        sp = {"dense_descriptor": torch.from_numpy(dd).cuda(), "dense_score": torch.from_numpy(ds).cuda()}
+        outs.append(m.preprocess(synth.array_to_keylines(synth.synth_lines(700 + b, 70, 480, 640)), (1, 1, 480, 640), sp))
+    batch = {k: torch.cat([o[k][:, :n_fix] for o in outs], dim=0) for k in keys}
+    m.train()
+    m.dropout = 0.0
+    for bn in m._bn_layers():
+        bn.momentum = momentum
+    sd_t = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    want = O.forward_train(sd_t, {k: v.cpu() for k, v in batch.items()}, (480, 640), momentum=momentum)["line_desc"]
+    got = m(batch)["line_desc"]
+    assert got.shape == want.shape == (B, 256, n_fix)
+    # three rows per BatchNorm: a variance of three samples divides fp32 round-off by a small number in eight places -- looser bound
+    assert (got.cpu() - want).abs().max().item() < (1e-4 if B * n_fix >= 7 else 2e-3)
+    for k, v in m.state_dict().items():
+        if "running_" in k:
+            ref = sd_t[k].numpy()
+            assert np.abs(v.cpu().numpy() - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max())), k
+        elif k.endswith("num_batches_tracked"):
+            assert int(v) == int(sd_t[k])
+
+
 def test_matching_forward_fused_pair_equals_the_per_image_path(monkeypatch):
     """Matching.forward sends the two images of a pair through ONE fused native call (Matching._describe_fused); every entry of the
     reference's dict must be what the per-image path (preprocess + forward per image) returns: token tensors bit for bit, descriptors

@@ -137,7 +137,9 @@ def test_edited_matrix_is_matched_by_its_contents():
     # same matrices without their maps (cloned: what an .npz reload gives): the contents path must agree exactly
     a, b, c, d, thr = args()
     M_slow, Dk_slow = mt.match_lines(a, b.clone(), c, d.clone(), thr)
-    assert np.array_equal(M_fast, M_slow) and np.array_equal(Dk_fast, Dk_slow)
+    # (same matches; the distances agree to fp32 round-off -- the contents path forms D in the point matcher's launch, whose MFMA
+    # accumulation order is not the fused line matcher's)
+    assert np.array_equal(M_fast, M_slow) and np.abs(Dk_fast - Dk_slow).max() < 2e-6
     # edit in place: key-line 0 of image 0 now ignores its sub-lines (row zeroed) -> Dk row 0 becomes 0, as A0 @ D @ A1^T says
     outs[0]["mat_klines2sublines"][0, 0].zero_()
     assert sub2line_of(outs[0]["mat_klines2sublines"]) is None
