@@ -203,8 +203,9 @@ int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const int32_t* h_cu
  * the batch mean / UNBIASED variance.  Dropout (models/line_attention.py:11,39,84) is taken at probability 0: the caller has to
  * make sure of that (the Python surface refuses otherwise); no gradients are produced.
  * `h` must have been created with bn_batch_stats = 1.  The images of the batch are the n_images entries of h_cu_sub, as in
- * linetr_forward.  d_bn_running (in/out) and d_bn_batch (out, may be NULL) are packed per BatchNorm layer, in state_dict order --
- * word encoder 1,4,7,10 | line encoder 1,4,7,10 | selfattn.layers.l.mlp.1 --, each layer as mean[C] | var[C]; d_bn_batch
+ * linetr_forward.  d_bn_running (in/out) and d_bn_batch (out, may be NULL) are packed per BatchNorm layer in THIS order --
+ * klenc.word_position_enc.encoder.{1,4,7,10} | klenc.line_position_enc.encoder.{1,4,7,10} | selfattn.layers.l.mlp.1 (l = 0 ..) --
+ * (note: the state_dict lists the line encoder first), each layer as mean[C] | var[C]; d_bn_batch
  * receives the batch mean | biased variance.  linetr_bn_stats_floats() = the length of both arrays. */
 int64_t linetr_bn_stats_floats(const LinetrHandle* h);
 int64_t linetr_forward_train_workspace_bytes(const LinetrHandle* h, int32_t N, int32_t max_tokens);

@@ -539,7 +539,7 @@ class Engine:
     def forward_train_tensors(self, sublines, pnt, resp, angle_sub, desc, score, cu_n, bn_running, momentum=0.1, want_batch_stats=False):
         """The training-time forward (train.py:127,163-164) on flat tensors, on an Engine made with bn_batch_stats=True: BatchNorm on
         the statistics of THIS batch; `bn_running` (float32 device tensor of bn_stats_floats() entries: per BatchNorm layer
-        mean[C] | var[C], state_dict order) is updated in place.  Returns line_desc [N,256], and with want_batch_stats the batch mean
+        mean[C] | var[C]; word encoder's four layers, line encoder's four, then one per signature layer) is updated in place.  Returns line_desc [N,256], and with want_batch_stats the batch mean
         | biased variance packed the same way."""
         N, T = int(pnt.shape[0]), int(pnt.shape[1])
         t = nat.Tokens()
