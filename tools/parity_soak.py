@@ -46,6 +46,16 @@ def main():
     ld_c, m01_c, dk_c, ck0 = ld.cpu().numpy(), m01.cpu().numpy(), dk.cpu().numpy(), cs(k[0::2])
     worst = worst_dk = 0.0
     bad_pairs, margin, n_match, t0 = 0, np.inf, 0, time.time()
+    # r05: every pair once more on its own -- the ONE-launch single-pair matcher (pair_match_fused_kernel) where it applies --, which must
+    # give the batched launches' matches
+    bad_single = fused = 0
+    cn, ck = tb.cu_n.astype(np.int64), tb.cu_k.astype(np.int64)
+    for p in range(P):
+        a, b = 2 * p, 2 * p + 1
+        one = eng.match(ld[cn[a]:cn[a + 1]], np.array([0, n[a]]), tb.sub2line[cn[a]:cn[a + 1]], np.array([0, k[a]]),
+                        ld[cn[b]:cn[b + 1]], np.array([0, n[b]]), tb.sub2line[cn[b]:cn[b + 1]], np.array([0, k[b]]), 0.8, True)
+        fused += int(n[b] <= 1024 and k[a] <= 4096 and k[b] <= 4096 and k[a] > 0 and k[b] > 0)
+        bad_single += int(not np.array_equal(one[2].cpu().numpy(), m01_c[ck0[p]:ck0[p] + int(k[a])]))
     for p in range(P):
         outs = []
         for s in range(2):
@@ -68,7 +78,8 @@ def main():
                 margin = min(margin, float((two[:, 1] - two[:, 0]).min()))
     print(f"{P} pairs, {int(tb.N)} descriptors, {n_match} line matches: max |desc - oracle| = {worst:.2e}, max |Dk - oracle| = {worst_dk:.2e}, "
           f"pairs with a differing match matrix = {bad_pairs}, smallest argmin margin = {margin:.2e}, NHWC-fed vs NCHW-fed descriptors "
-          f"max diff = {(ld - ld2).abs().max().item():.1e}  (oracle time {time.time() - t0:.0f} s)")
+          f"max diff = {(ld - ld2).abs().max().item():.1e}; matched pair by pair ({fused} of {P} through the one-launch matcher): "
+          f"{bad_single} pairs differ from the batched matcher  (oracle time {time.time() - t0:.0f} s)")
 
 
 if __name__ == "__main__":
