@@ -877,8 +877,10 @@ def preflight(dist, world, rank, device, backend):
     seen = sorted(int(v) for v in ids.cpu())
     if int(ones.item()) != world or seen != list(range(world)):
         fail_line(f"pre-flight: the collective saw {int(ones.item())} ranks {seen}, expected {world}", world, rank)
-    props = torch.cuda.get_device_properties(device)
-    tag = str(getattr(props, "uuid", "")) or f"{props.name}#{device.index}"
+    # one node (the contract: --nnodes=1): a GPU is identified by the index this rank opened within the set of devices visible to it
+    # (uuid / PCI ids are not relied on: they are not populated by every ROCm / torch build, and a false alarm here would fail a good run)
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES") or ""
+    tag = f"{vis}#{device.index}"
     box = [None] * world
     dist.all_gather_object(box, (rank, device.index, tag))
     distinct = len({t for _r, _i, t in box})
