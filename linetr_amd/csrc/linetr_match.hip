@@ -388,6 +388,7 @@ extern "C" int64_t linetr_pool_distmat_dense_workspace_bytes(int32_t k0, int32_t
 extern "C" int linetr_pool_distmat_dense(LinetrHandle* h, const float* d_dist, int32_t n0, int32_t n1, const float* d_A0, int32_t k0,
                                          const float* d_A1, int32_t k1, float* d_dk, void* d_ws, int64_t ws_bytes, void* stream) {
   if (n0 < 0 || n1 < 0 || k0 < 0 || k1 < 0) return fail(LINETR_E_ARG, "pool_distmat_dense: bad dims");
+  if (k0 > 65535) return fail(LINETR_E_ARG, "pool_distmat_dense: more than 65535 key-lines in image 0 (grid limit of the as-given product)");
   if (k0 == 0 || k1 == 0) return LINETR_OK;
   if (!d_dk || !d_ws || ((n0 > 0 && n1 > 0) && (!d_dist || !d_A0 || !d_A1))) return fail(LINETR_E_ARG, "pool_distmat_dense: null pointer");
   const DensePoolLayout L = dense_pool_layout(k0, n0, k1, n1);
