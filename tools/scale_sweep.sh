@@ -36,6 +36,8 @@ for wl in ("cfg3", "cfg4"):
         d = last_json(p) if os.path.exists(p) else None
         if d is None:
             print(f"{wl:8s} {n:2d}  -- no result"); bad += 1; continue
+        if d.get("error"):           # r05: a run that failed its pre-flight / gathered-rows check prints ONE line with "error" and a null value
+            print(f"{wl:8s} {n:2d}  -- {d['error']}"); bad += 1; continue
         checks = []
         if d["n_gpus"] != n:
             checks.append(f"n_gpus={d['n_gpus']}")
@@ -61,7 +63,9 @@ for wl in ("cfg3", "cfg4"):
         base.setdefault(wl, (n, d["value"]))
         n0, v0 = base[wl]
         eff = d["value"] / (v0 * n / n0)
-        print(f"{wl:8s} {n:2d} {d['value']:12.0f} {d['ms_per_step']:9.3f} {comp:9.3f} {gat:8.3f} {mat:8.3f}  {eff:4.2f}  {'ok' if not checks else '; '.join(checks)}")
+        per_rank = d.get("gather_ms_per_rank")
+        extra = f"  gather/rank {min(per_rank):.3f}-{max(per_rank):.3f} ms" if per_rank else ""
+        print(f"{wl:8s} {n:2d} {d['value']:12.0f} {d['ms_per_step']:9.3f} {comp:9.3f} {gat:8.3f} {mat:8.3f}  {eff:4.2f}  {'ok' if not checks else '; '.join(checks)}{extra}")
 sys.exit(1 if bad else 0)
 PY
 exit $rc
