@@ -432,8 +432,13 @@ class Engine:
 
     def describe_lines(self, lines6, offsets, dense_desc, dense_score, *, remove_borders, min_length, max_keylines,
                        token_distance, max_tokens, align_corners=False, n_streams=1, want_tokens=False,
-                       dense_layout="nchw"):
+                       dense_layout="nchw", angles="native"):
         """prefilter + describe for a batch given as one [sum K,6] array + row offsets [B+1].
+
+        angles: "native" -- (cos 2theta, sin 2theta) from the host pre-filter's libm (the throughput path: nothing of the step runs in
+        Python); "numpy" -- recomputed with NumPy from the filtered lines in one vectorised call, exactly what get_angles of the
+        per-image surface computes (models/line_process.py:28-41): the two can differ in the last float64 ulp (<= 1.2e-7 after the
+        float32 cast), and the batched drop-in surface (Matching.forward_batch) asks for NumPy's so that it returns forward()'s tensors.
 
         With n_streams > 1 the images are cut into contiguous groups that run as independent sub-batches on
         separate HIP streams (forked from / joined back into the current stream).  The descriptor network of one
@@ -447,8 +452,13 @@ class Engine:
         kw = dict(remove_borders=remove_borders, min_length=min_length, max_keylines=max_keylines,
                   token_distance=token_distance, max_tokens=max_tokens)
         G = max(1, min(int(n_streams), B // 4))
+        if angles not in ("native", "numpy"):
+            raise ValueError("angles must be 'native' or 'numpy'")
         if G == 1:
             recs, cu_k, cu_n = self.prefilter(lines6, H, W, offsets=offsets, **kw)
+            if angles == "numpy" and len(recs):
+                from .line_process import get_angles
+                recs["angle"] = get_angles(np.stack([recs["sp"], recs["ep"]], axis=1))     # (records live in the pinned upload slot)
             return self.describe(recs, cu_k, cu_n, dense_desc, dense_score, token_distance=token_distance,
                                  max_tokens=max_tokens, align_corners=align_corners, want_tokens=want_tokens,
                                  dense_layout=dense_layout)
@@ -470,6 +480,9 @@ class Engine:
             with torch.cuda.stream(st):
                 sub_off = offsets[i0:i1 + 1] - offsets[i0]
                 recs, cu_k, cu_n = self.prefilter(lines6[offsets[i0]:offsets[i1]], H, W, offsets=sub_off, **kw)
+                if angles == "numpy" and len(recs):
+                    from .line_process import get_angles
+                    recs["angle"] = get_angles(np.stack([recs["sp"], recs["ep"]], axis=1))
                 self._ws_tag = f"desc{g}"
                 tb, ld = self.describe(recs, cu_k, cu_n, dense_desc[i0:i1], dense_score[i0:i1],
                                        token_distance=token_distance, max_tokens=max_tokens,

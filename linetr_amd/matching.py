@@ -180,7 +180,9 @@ class Matching(torch.nn.Module):
         fused native call (linetr_prefilter_batch + linetr_describe) and the line matching of all P pairs is ONE
         linetr_match call.  Returns a list of P dicts with the keys forward() produces, except that the dense
         per-token tensors (pnt/mask/desc/score_sublines) are not materialised.  Key-line order is forward()'s: the native
-        pre-filter sorts, and images that hold equal lengths are ordered by NumPy's own argsort (Engine.prefilter, tie_order)."""
+        pre-filter sorts, and images that hold equal lengths are ordered by NumPy's own argsort (Engine.prefilter, tie_order); the
+        angles are NumPy's, as in forward() (describe_lines(angles="numpy")): every tensor both return is the same bit for bit,
+        up to the descriptors' fp32 round-off (other GEMM tiles for other row counts)."""
         from .line_process import attach_sub2line, keylines_to_array
         lt = self.linetransformer
         P = len(pairs)
@@ -212,7 +214,7 @@ class Matching(torch.nn.Module):
         align = int(torch.__version__[2]) > 2
         tb, ld = eng.describe_lines(cat, off, dd, ds, remove_borders=c["remove_borders"], min_length=c["min_length"],
                                     max_keylines=c["max_keylines"], token_distance=c["token_distance"],
-                                    max_tokens=c["max_tokens"], align_corners=align, dense_layout=layout)
+                                    max_tokens=c["max_tokens"], align_corners=align, dense_layout=layout, angles="numpy")
         cu_n, cu_k = tb.cu_n, tb.cu_k
         n, k = np.diff(cu_n), np.diff(cu_k)
         dev = ld.device
