@@ -44,15 +44,16 @@ def run(eng, d0, s0, k0, d1, s1, k1, thr, mutual=True):
 
 
 @pytest.mark.parametrize("k0,k1,max_sub,seed", [(199, 199, 1, 0), (37, 53, 3, 1), (1, 7, 2, 2), (16, 16, 1, 3), (17, 300, 4, 4),
-                                                 (600, 599, 2, 5), (130, 1, 1, 6), (250, 400, 1, 7)])
+                                                 (600, 599, 2, 5), (130, 1, 1, 6), (250, 400, 1, 7),
+                                                 (1024, 1024, 1, 8),      # the largest image 1 of the one-launch path: 64 column tiles over 8 blocks per row chunk
+                                                 (1030, 1030, 1, 9),      # one past it: the three launches
+                                                 (512, 700, 1, 10)])      # point-matcher shape (identity maps, n0 != n1)
 def test_fused_single_pair_matcher_vs_oracle_and_three_launches(eng, monkeypatch, k0, k1, max_sub, seed):
     rs = np.random.RandomState(seed)
     dup0 = [(0, min(3, k0 - 1))] if k0 > 3 else []     # two identical key-lines in image 0: a COLUMN-argmin tie -> first index
     dup1 = [(1, min(5, k1 - 1))] if k1 > 5 else []     # two identical key-lines in image 1: a ROW-argmin tie -> first index
     d0, s0, A0 = make_side(rs, k0, max_sub, dup0 if max_sub == 1 else [])
     d1, s1, A1 = make_side(rs, k1, max_sub, dup1 if max_sub == 1 else [])
-    if len(d1) > 1024:
-        pytest.skip("beyond the one-launch path")
     D = O.dist_matrix(d0.T[None], d1.T[None])[0]
     Dk = O.subline2keyline(D, torch.from_numpy(A0), torch.from_numpy(A1))
     for thr, mutual in ((0.8, True), (2.5, True), (1.2, False)):
