@@ -128,3 +128,30 @@ def test_single_image_mat_written_by_the_tokeniser_launch(engine, maps):
         engine.tokenize(*engine.prefilter([rows, rows], *HW, remove_borders=BORDER, min_length=MIN_LEN, max_keylines=-1,
                                           token_distance=8, max_tokens=3), torch.cat([dd, dd]).cuda(),
                         torch.cat([ds, ds]).cuda(), token_distance=8, max_tokens=3, want_mat=True)
+
+
+def test_tokenizer_fuzz_with_an_image_shape_that_is_not_the_maps(engine, maps):
+    """line_tokenizer's `image_shape` argument only sets the end-point clip (models/line_process.py:101,115-116) and the dataset builder
+    passes the (width, height) tuple (dataloaders/utils/util_lines.py:682,703): 630 fuzz lines on the 960 x 1280 maps tokenised with the
+    clip of a (1280, 960) "image" -- end points beyond x = 959.4 are bent, multi-sub-line lines included -- every tensor against the oracle's
+    tokeniser called with the same tuple (the pre-filter's own border clip stays the maps')."""
+    dd, ds = maps
+    td, T = 8, 21
+    rows = [fuzz_lines(555 + i, 210, td, T) for i in range(3)]
+    recs, cu_k, cu_n = engine.prefilter(rows, *HW, remove_borders=BORDER, min_length=MIN_LEN, max_keylines=-1, token_distance=td, max_tokens=T)
+    clip = (HW[1], HW[0])                                                   # (1280, 960) read as (height, width)
+    tb = engine.tokenize(recs, cu_k, cu_n, torch.cat([dd] * 3).cuda(), torch.cat([ds] * 3).cuda(), token_distance=td, max_tokens=T,
+                         align_corners=False, clip_shape=clip)
+    torch.cuda.synchronize()
+    bent = 0
+    for i in range(3):
+        lines = O.keep_long_lines(O.drop_border_lines(O.cv2_to_arrays(synth.array_to_keylines(rows[i])), BORDER, HW[0], HW[1], np.ones(HW)),
+                                  MIN_LEN, -1)
+        bent += int((lines["klines"][:, 1, 0] > clip[1] - 0.6).sum())
+        want = O.tokenize(lines, td, T, dd, ds, clip, False)
+        k0, k1, n0, n1 = tb.cu_k[i], tb.cu_k[i + 1], tb.cu_n[i], tb.cu_n[i + 1]
+        got = {"klines": tb.klines[k0:k1], "sublines": tb.sublines[n0:n1], "pnt_sublines": tb.pnt[n0:n1], "mask_sublines": tb.mask[n0:n1][..., None],
+               "resp_sublines": tb.resp[n0:n1][..., None], "score_sublines": tb.score[n0:n1][..., None]}
+        for k, v in got.items():
+            assert np.array_equal(v.cpu().numpy(), want[k][0].numpy()), (k, i)
+    assert bent > 50, "the clip must bend a good share of the lines"
