@@ -305,6 +305,19 @@ int linetr_match_points(LinetrHandle* h, const float* d_desc0_cn, int32_t n0, co
                         int32_t n1, float nn_thresh, int32_t mutual, float* d_dist, int32_t* d_match01,
                         void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* The matching tail of Matching.forward (models/matching.py:67-84) in ONE call: the point matcher on the two [256,n] SuperPoint
+ * descriptor sets (nn_matcher, models/nn_matcher.py:33-42), the line matcher on the two images' line descriptors (get_dist_matrix +
+ * subline2keyline + nn_matcher_distmat) and the device -> host copies of the four results into ONE caller-provided PINNED host block,
+ * everything asynchronous on `stream` (the caller waits for the stream / an event once).  Either branch is skipped when its sizes are
+ * 0.  linetr_pair_tail_output_bytes returns the size of the block and the byte offsets of its four segments:
+ *   h_offsets[0] point distances [np0][np1] float32, [1] point match01 [np0] int32, [2] Dk [k0][k1] float32, [3] line match01 [k0] int32. */
+int64_t linetr_pair_tail_workspace_bytes(int32_t np0, int32_t np1, int32_t n0, int32_t k0, int32_t n1, int32_t k1);
+int64_t linetr_pair_tail_output_bytes(int32_t np0, int32_t np1, int32_t k0, int32_t k1, int64_t* h_offsets);
+int linetr_pair_tail(LinetrHandle* h, const float* d_pdesc0_cn, int32_t np0, const float* d_pdesc1_cn, int32_t np1, float nn_thresh_points,
+                     const float* d_ldesc0, int32_t n0, const int32_t* d_sub2line0, int32_t k0, const float* d_ldesc1, int32_t n1,
+                     const int32_t* d_sub2line1, int32_t k1, float nn_thresh_lines, int32_t mutual, void* h_pinned_out,
+                     int64_t pinned_bytes, void* d_workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- dense-map producer (section 8(f) "next" row 2) ------------------------------------------------- */
 
 /* Post-processing of SuperPoint's two heads, fused with the layout change the tokeniser needs; replaces

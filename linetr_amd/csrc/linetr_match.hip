@@ -82,6 +82,12 @@ PairSlot* pair_slot(hipStream_t st) {
   return &(slots[{dev, st}] = ps);
 }
 
+// does a single-pair call go to the one-launch matcher (pair_match_fused_kernel)?  LINETR_MATCH_THREE_LAUNCHES is an A/B switch read per call
+bool fused_pair_applies(int n0, int k0, int n1, int k1) {
+  (void)n0;
+  return getenv("LINETR_MATCH_THREE_LAUNCHES") == nullptr && k0 > 0 && k1 > 0 && n1 <= PF_MAX_N1 && k0 <= PF_MAX_K && k1 <= PF_MAX_K;
+}
+
 // ints of argmin scratch one pair needs (layout in lt_match.h)
 int64_t pair_scratch_ints(int k0, int k1) { return 2 * (int64_t)k0 + 2 * (int64_t)k1 + 1 + 2 * (int64_t)cdiv(std::max(k0, 1), PM_ROWS) * k1 + 8; }
 }  // namespace
@@ -162,8 +168,7 @@ extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* 
     // A single pair of ordinary size: ONE launch (pair_match_fused_kernel, lt_match.h).  (r03 built a one-launch form that staged
     // 8 K steps through LDS with a load round trip exposed at each and lost to the three launches, 0.10 vs 0.08 ms; this one keeps
     // whole operand rows in registers -- two exposed round trips in all -- and combines the column argmin with one 64-bit atomicMin.)
-    const bool no_fused = getenv("LINETR_MATCH_THREE_LAUNCHES") != nullptr;    // A/B switch, read per call (tests, tools)
-    if (P == 1 && !no_fused && pd[0].k0 > 0 && pd[0].k1 > 0 && pd[0].n1 <= PF_MAX_N1 && pd[0].k0 <= PF_MAX_K && pd[0].k1 <= PF_MAX_K) {
+    if (P == 1 && fused_pair_applies(pd[0].n0, pd[0].k0, pd[0].n1, pd[0].k1)) {
       PairSlot* ps_ = pair_slot(st);
       if (!ps_) return fail(LINETR_E_HIP, "match: scratch allocation for the single-pair matcher failed");
       const PairDesc& d = pd[0];
@@ -235,7 +240,7 @@ extern "C" int linetr_match_points(LinetrHandle* h, const float* d0_cn, int32_t 
   float* r1 = (float*)base; base += align_up((int64_t)std::max(n1, 1) * D * 4, 256);
   int* id0 = (int*)base; base += align_up((int64_t)n0 * 4, 256);
   int* id1 = (int*)base; base += align_up((int64_t)std::max(n1, 1) * 4, 256);
-  {
+  if (!fused_pair_applies(n0, n0, n1, n1)) {      // (the one-launch identity path never reads the maps: no upload on the latency path)
     int slot = 0;
     const int m = std::max(n0, n1);
     int* iota = (int*)staging_ring().acquire((size_t)m * sizeof(int), &slot);
@@ -252,6 +257,73 @@ extern "C" int linetr_match_points(LinetrHandle* h, const float* d0_cn, int32_t 
   const int64_t zero = 0;
   return linetr_match(h, 1, dims, r0, &zero, id0, r1, &zero, id1, thr, mutual, d_dist, &zero, d_match01, &zero, base,
                       ws_bytes - need_t, stream);
+}
+
+// The matching tail of Matching.forward (models/matching.py:67-84) in ONE call: point matcher (nn_matcher on the two [256,n] SuperPoint
+// descriptor sets), line matcher (get_dist_matrix + subline2keyline + nn_matcher_distmat on the two images' line descriptors) and the
+// four device -> host copies of their results into ONE caller-provided pinned block, all asynchronous on `stream`.  Either branch may
+// be switched off (np0 = 0 / k0 = 0).  Layout of the pinned block (byte offsets returned in h_offsets[4], every segment 256-aligned):
+//   point distances [np0][np1] f32 | point match01 [np0] i32 | key-line distances Dk [k0][k1] f32 | line match01 [k0] i32
+namespace {
+struct TailLayout { int64_t o_pd, o_pm, o_ld, o_lm, out_total, ws_points, ws_lines, ws_total; };
+TailLayout tail_layout(int np0, int np1, int n0, int k0, int n1, int k1) {
+  TailLayout L{};
+  int64_t o = 0;
+  L.o_pd = o; o += align_up((int64_t)np0 * np1 * 4, 256);
+  L.o_pm = o; o += align_up((int64_t)np0 * 4, 256);
+  L.o_ld = o; o += align_up((int64_t)k0 * k1 * 4, 256);
+  L.o_lm = o; o += align_up((int64_t)k0 * 4, 256);
+  L.out_total = o;
+  L.ws_points = np0 > 0 && np1 > 0 ? 4 * (int64_t)(np0 + np1) * (D + 1) + 2048 + linetr_match_workspace_bytes(1, (int64_t)np0 * np1, 0, np0 + np1) : 0;
+  L.ws_lines = k0 > 0 && k1 > 0 ? linetr_match_workspace_bytes(1, (int64_t)n0 * n1, 0, k0 + k1) : 0;
+  L.ws_total = align_up(L.out_total, 256) + align_up(L.ws_points, 256) + align_up(L.ws_lines, 256) + 256;
+  return L;
+}
+}  // namespace
+
+extern "C" int64_t linetr_pair_tail_workspace_bytes(int32_t np0, int32_t np1, int32_t n0, int32_t k0, int32_t n1, int32_t k1) {
+  return tail_layout(std::max(np0, 0), std::max(np1, 0), std::max(n0, 0), std::max(k0, 0), std::max(n1, 0), std::max(k1, 0)).ws_total;
+}
+
+extern "C" int64_t linetr_pair_tail_output_bytes(int32_t np0, int32_t np1, int32_t k0, int32_t k1, int64_t* h_offsets) {
+  const TailLayout L = tail_layout(std::max(np0, 0), std::max(np1, 0), 0, std::max(k0, 0), 0, std::max(k1, 0));
+  if (h_offsets) { h_offsets[0] = L.o_pd; h_offsets[1] = L.o_pm; h_offsets[2] = L.o_ld; h_offsets[3] = L.o_lm; }
+  return L.out_total;
+}
+
+extern "C" int linetr_pair_tail(LinetrHandle* h, const float* d_pdesc0_cn, int32_t np0, const float* d_pdesc1_cn, int32_t np1, float thr_p,
+                                const float* d_ldesc0, int32_t n0, const int32_t* d_s2l0, int32_t k0, const float* d_ldesc1, int32_t n1,
+                                const int32_t* d_s2l1, int32_t k1, float thr_l, int32_t mutual, void* h_pinned_out, int64_t pinned_bytes,
+                                void* d_ws, int64_t ws_bytes, void* stream) {
+  if (np0 < 0 || np1 < 0 || n0 < 0 || n1 < 0 || k0 < 0 || k1 < 0) return fail(LINETR_E_ARG, "pair_tail: bad dims");
+  const bool points = np0 > 0 && np1 > 0, lines = k0 > 0 && k1 > 0;
+  const TailLayout L = tail_layout(np0, np1, n0, k0, n1, k1);
+  if (!h_pinned_out || pinned_bytes < L.out_total) return fail(LINETR_E_CAPACITY, "pair_tail: output block too small (need %lld)", (long long)L.out_total);
+  if (!d_ws || ws_bytes < L.ws_total) return fail(LINETR_E_WORKSPACE, "pair_tail: workspace too small (need %lld)", (long long)L.ws_total);
+  hipStream_t st = (hipStream_t)stream;
+  if (h) LT_HIP(hipSetDevice(h->device));
+  char* dout = (char*)d_ws;                                       // device image of the output block
+  char* wsp = dout + align_up(L.out_total, 256);
+  char* wsl = wsp + align_up(L.ws_points, 256);
+  char* hout = (char*)h_pinned_out;
+  if (points) {
+    if (!d_pdesc0_cn || !d_pdesc1_cn) return fail(LINETR_E_ARG, "pair_tail: null point descriptors");
+    if (int e = linetr_match_points(h, d_pdesc0_cn, np0, d_pdesc1_cn, np1, thr_p, mutual, (float*)(dout + L.o_pd), (int32_t*)(dout + L.o_pm), wsp,
+                                    L.ws_points, stream)) return e;
+    // requested now: the 1 MB distance matrix travels while the line matcher runs
+    LT_HIP(hipMemcpyAsync(hout + L.o_pd, dout + L.o_pd, (size_t)np0 * np1 * 4, hipMemcpyDeviceToHost, st));
+    LT_HIP(hipMemcpyAsync(hout + L.o_pm, dout + L.o_pm, (size_t)np0 * 4, hipMemcpyDeviceToHost, st));
+  }
+  if (lines) {
+    if (!d_ldesc0 || !d_ldesc1 || !d_s2l0 || !d_s2l1) return fail(LINETR_E_ARG, "pair_tail: null line descriptors / maps");
+    const int32_t dims[4] = {n0, k0, n1, k1};
+    const int64_t zero = 0;
+    if (int e = linetr_match(h, 1, dims, d_ldesc0, &zero, d_s2l0, d_ldesc1, &zero, d_s2l1, thr_l, mutual, (float*)(dout + L.o_ld), &zero,
+                             (int32_t*)(dout + L.o_lm), &zero, wsl, L.ws_lines, stream)) return e;
+    LT_HIP(hipMemcpyAsync(hout + L.o_ld, dout + L.o_ld, (size_t)k0 * k1 * 4, hipMemcpyDeviceToHost, st));
+    LT_HIP(hipMemcpyAsync(hout + L.o_lm, dout + L.o_lm, (size_t)k0 * 4, hipMemcpyDeviceToHost, st));
+  }
+  return LINETR_OK;
 }
 
 extern "C" int64_t linetr_match_distmat_workspace_bytes(int32_t n0, int32_t n1) {

@@ -779,6 +779,63 @@ class Engine:
         buffer, then the copies are waited for once (`.cpu()` per tensor would synchronise per tensor)."""
         return self.collect(self.to_host_async(*tensors))
 
+    def pair_tail(self, pdesc0_cn, pdesc1_cn, thr_p, ldesc0, s2l0, k0, ldesc1, s2l1, k1, thr_l, mutual=True):
+        """The matching tail of Matching.forward in ONE native call (linetr_pair_tail): point matcher on the two [256,n] SuperPoint
+        descriptor sets, line matcher on the two [N,256] line-descriptor sets with their sub-line -> key-line maps, and the device ->
+        host copies of the four results into one pinned block.  Asynchronous; returns a ticket for collect_tail().  A branch is
+        skipped when its descriptors are None."""
+        pts = pdesc0_cn is not None and pdesc1_cn is not None
+        lns = ldesc0 is not None and ldesc1 is not None and k0 > 0 and k1 > 0
+        p0, p1 = (self._f32(pdesc0_cn), self._f32(pdesc1_cn)) if pts else (None, None)
+        np0, np1 = (int(p0.shape[1]), int(p1.shape[1])) if pts else (0, 0)
+        l0, l1 = (self._f32(ldesc0), self._f32(ldesc1)) if lns else (None, None)
+        n0, n1 = (int(l0.shape[0]), int(l1.shape[0])) if lns else (0, 0)
+        if not lns:
+            k0 = k1 = 0
+        key = (np0, np1, n0, int(k0), n1, int(k1))
+        cache = self.__dict__.setdefault("_tail_tables", {})
+        tab = cache.get(key)
+        if tab is None:
+            if len(cache) > 256:
+                cache.clear()
+            offs = (C.c_int64 * 4)()
+            out_bytes = int(self._L.linetr_pair_tail_output_bytes(np0, np1, int(k0), int(k1), offs))
+            tab = cache[key] = (out_bytes, tuple(int(v) for v in offs), int(self._L.linetr_pair_tail_workspace_bytes(*key)))
+        out_bytes, offs, ws_bytes = tab
+        ring = self.__dict__.setdefault("_host_ring", {"i": 0, "bufs": [None] * 4, "gen": [0] * 4})
+        i = ring["i"] = (ring["i"] + 1) % len(ring["bufs"])
+        ring["gen"][i] += 1
+        stage = ring["bufs"][i]
+        if stage is None or stage.numel() < out_bytes:
+            stage = ring["bufs"][i] = torch.empty(out_bytes * 2 + 4096, dtype=torch.uint8, pin_memory=True)
+        ws = self._workspace("tail", ws_bytes)
+        s0 = s2l0 if (lns and s2l0.dtype == torch.int32 and s2l0.device == self.device and s2l0.is_contiguous()) else \
+            (s2l0.to(device=self.device, dtype=torch.int32).contiguous() if lns else None)
+        s1 = s2l1 if (lns and s2l1.dtype == torch.int32 and s2l1.device == self.device and s2l1.is_contiguous()) else \
+            (s2l1.to(device=self.device, dtype=torch.int32).contiguous() if lns else None)
+        with torch.cuda.device(self.device):
+            nat.check(self._L.linetr_pair_tail(self._h, p0.data_ptr() if pts else None, np0, p1.data_ptr() if pts else None, np1, float(thr_p),
+                                               l0.data_ptr() if lns else None, n0, s0.data_ptr() if lns else None, int(k0),
+                                               l1.data_ptr() if lns else None, n1, s1.data_ptr() if lns else None, int(k1), float(thr_l),
+                                               int(bool(mutual)), stage.data_ptr(), stage.numel(), ws.data_ptr(), ws.numel(), self._stream()),
+                      self._L)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+        return stage, offs, key, ev, ring["gen"], i, ring["gen"][i], (p0, p1, l0, l1, s0, s1)     # (inputs kept alive until collected)
+
+    @staticmethod
+    def collect_tail(ticket):
+        """Waits for a pair_tail ticket: (point distances [np0,np1] f32, point match01 [np0] i32, Dk [k0,k1] f32, line match01 [k0] i32)
+        as NumPy arrays (copies); the entries of a skipped branch are empty."""
+        stage, offs, (np0, np1, _n0, k0, _n1, k1), ev, gens, i, gen, _keep = ticket
+        ev.synchronize()
+        if gens[i] != gen:
+            raise RuntimeError("pair_tail ticket collected too late: its staging buffer has been reused")
+        host = stage.numpy()
+        f = lambda o, n, dt: host[o:o + 4 * n].view(dt).copy()
+        return (f(offs[0], np0 * np1, np.float32).reshape(np0, np1), f(offs[1], np0, np.int32),
+                f(offs[2], k0 * k1, np.float32).reshape(k0, k1), f(offs[3], k0, np.int32))
+
     def match_points(self, desc0_cn: torch.Tensor, desc1_cn: torch.Tensor, thr, mutual=True):
         """nn_matcher on [256,n] descriptors; returns (dist [n0,n1] device, match01 [n0] device)."""
         d0, d1 = self._f32(desc0_cn), self._f32(desc1_cn)

@@ -108,17 +108,13 @@ class Matching(torch.nn.Module):
             if "keypoints" + s not in data:
                 sp[s] = self.superpoint({"image": data["image" + s]})
                 pred.update({k + s: v for k, v in sp[s].items()})
-        # The point matcher (models/nn_matcher.py:33-42) needs nothing but SuperPoint's descriptors: it is queued now and runs on the
-        # device underneath the host glue of the line branch; its results come to the host with the line matcher's, at the end.
-        from .line_process import _token_engine
+        # Both matchers run BEHIND the descriptors, in one native call that also requests the four device -> host copies of their
+        # results (linetr_pair_tail): nothing is queued in front of the line branch's host glue, which is what the pair waits for.
+        from .line_process import _token_engine, sub2line_of
         d0, d1 = ((sp[s]["descriptors"] if s in sp else data["descriptors" + s])[0].detach() for s in ("0", "1"))
         on_dev = d0.is_cuda and d0.dim() == 2 and d0.shape[0] == 256 and d0.shape[1] > 0 and d1.shape[1] > 0
         thr_p = self.superpoint.config["nn_threshold"]
-        points_q = None
-        if on_dev:
-            eng_m = _token_engine(d0.device)                      # the matchers need no weights (and no weight-version check)
-            dist, m01 = eng_m.match_points(d0, d1, float(np.float32(thr_p)), True)
-            points_q = eng_m.to_host_async(m01, dist)             # the 1 MB distance matrix travels while the line branch runs
+        eng_m = _token_engine(d0.device) if on_dev else None     # the matchers need no weights (and no weight-version check)
         # detect + tokenise + describe the images that need it (matching.py:34-41, :52-59)
         sides = [s for s in ("0", "1") if "klines" + s not in data]
         for s in sides:
@@ -147,21 +143,32 @@ class Matching(torch.nn.Module):
             pred.update({k + s: v for k, v in out.items()})
         data = {**data, **pred}    # (the reference also stacks list entries of this local dict, matching.py:62-64: nothing below reads one)
 
-        # line matches (D -> key-line pooling -> mutual NN, matching.py:77-84) are queued behind the descriptors; then ONE
-        # synchronisation brings the four result arrays of both matchers to the host
+        # point matches (matching.py:67-74) and line matches (D -> key-line pooling -> mutual NN, matching.py:77-84): ONE native call
+        # queued behind the descriptors, ONE synchronisation for the four result arrays
         thr_l = self.linetransformer.config["nn_threshold"]
-        line_args = (data["line_desc0"], data["mat_klines2sublines0"], data["line_desc1"], data["mat_klines2sublines1"], thr_l)
-        lines_q = self._queue_line_match(*line_args) if on_dev else None
-        if on_dev and lines_q is not None:
-            dk, m01_l, K0, K1 = lines_q
-            lines_t = eng_m.to_host_async(m01_l, dk)
-            m01_h, dist_h = eng_m.collect(points_q)               # ready long ago: copied out while the line matcher runs
-            m01_lh, dk_h = eng_m.collect(lines_t)
+        ld0, ld1, mat0, mat1 = data["line_desc0"], data["line_desc1"], data["mat_klines2sublines0"], data["mat_klines2sublines1"]
+        line_args = (ld0, mat0, ld1, mat1, thr_l)
+        K0, K1 = int(mat0.shape[1]), int(mat1.shape[1])
+        tail = have_lines = None
+        if on_dev:
+            # maps made by this package's tokeniser ride along with their (unmodified) matrices; an edited or foreign matrix is read by
+            # its contents on the slower path below
+            s0, s1 = sub2line_of(mat0), sub2line_of(mat1)
+            have_lines = K0 > 0 and K1 > 0 and s0 is not None and s1 is not None and ld0.is_cuda and ld1.is_cuda
+            if have_lines or K0 == 0 or K1 == 0:
+                tail = eng_m.pair_tail(d0, d1, float(np.float32(thr_p)), ld0[0].t() if have_lines else None, s0, K0,
+                                       ld1[0].t() if have_lines else None, s1, K1, float(np.float32(thr_l)), True)
+        if tail is not None:
+            dist_h, m01_h, dk_h, m01_lh = eng_m.collect_tail(tail)
             m_p, d_p = match01_to_matrix(m01_h, int(d1.shape[1])), dist_h[None]
-            m_l, d_l = match01_to_matrix(m01_lh, K1), dk_h.reshape(1, K0, K1)
-        else:   # empty sets / host tensors: the NumPy-in, NumPy-out surface functions, one after the other
+            if have_lines:
+                m_l, d_l = match01_to_matrix(m01_lh, K1), dk_h[None]
+            else:           # a side without key-lines: the reference's matcher returns zeros (nn_matcher.py:9-10)
+                m_l, d_l = np.zeros((1, K0, K1)), np.zeros((1, K0, K1), dtype=np.float32)
+        else:   # edited / foreign matrices, host tensors: the surface functions one after the other
             if on_dev:
-                m01_h, dist_h = eng_m.collect(points_q)
+                dist, m01 = eng_m.match_points(d0, d1, float(np.float32(thr_p)), True)
+                m01_h, dist_h = eng_m.to_host(m01, dist)
                 m_p, d_p = match01_to_matrix(m01_h, int(d1.shape[1])), dist_h[None]
             else:
                 m_p, d_p = nn_matcher(d0.cpu().numpy(), d1.cpu().numpy(), thr_p, is_mutual_NN=True)

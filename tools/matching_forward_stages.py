@@ -20,7 +20,7 @@ def wrap(owner, name, label=None):
             acc[lab] += time.perf_counter() - t0
     setattr(owner, name, g)
 
-for n in ("describe", "prefilter", "pack_many", "match", "match_points", "to_host_async", "_upload_recs"):
+for n in ("describe", "prefilter", "pack_many", "match", "match_points", "to_host_async", "_upload_recs", "pair_tail", "collect_tail"):
     wrap(E.Engine, n, "Engine." + n)
 for n in ("lines_from_rows", "keylines_to_array", "remove_borders", "filter_by_length", "get_angles"):
     wrap(LP, n)
@@ -32,7 +32,7 @@ wrap(torch, "ones_like", "torch.ones_like (valid_mask)")
 wrap(torch, "cat", "torch.cat (the two dense maps side by side)")
 wrap(torch, "empty", "torch.empty")
 from linetr_amd import _native as nat
-for n in ("linetr_describe", "linetr_prefilter_batch", "linetr_match", "linetr_match_points"):
+for n in ("linetr_describe", "linetr_prefilter_batch", "linetr_match", "linetr_match_points", "linetr_pair_tail"):
     wrap(nat.lib(), n, "native " + n)
 
 dev = torch.device("cuda:0")
