@@ -20,7 +20,7 @@ def wrap(owner, name, label=None):
             acc[lab] += time.perf_counter() - t0
     setattr(owner, name, g)
 
-for n in ("describe", "prefilter", "pack_many", "match", "match_points", "to_host_async", "_upload_recs", "pair_tail", "collect_tail"):
+for n in ("describe", "prefilter", "pack_many", "match", "match_points", "to_host_async", "_upload_recs", "pair_tail"):
     wrap(E.Engine, n, "Engine." + n)
 for n in ("lines_from_rows", "keylines_to_array", "remove_borders", "filter_by_length", "get_angles"):
     wrap(LP, n)
