@@ -10,6 +10,7 @@ or injected through the ``superpoint=`` / ``lsd=`` arguments.
 from __future__ import annotations
 
 import importlib
+import os
 
 import numpy as np
 import torch
@@ -155,7 +156,7 @@ class Matching(torch.nn.Module):
             # its contents on the slower path below
             s0, s1 = sub2line_of(mat0), sub2line_of(mat1)
             have_lines = K0 > 0 and K1 > 0 and s0 is not None and s1 is not None and ld0.is_cuda and ld1.is_cuda
-            if have_lines or K0 == 0 or K1 == 0:
+            if (have_lines or K0 == 0 or K1 == 0) and not os.environ.get("LINETR_NO_PAIR_TAIL"):     # (A/B switch: tools/ab_pair_tail.py)
                 tail = eng_m.pair_tail(d0, d1, float(np.float32(thr_p)), ld0[0].t() if have_lines else None, s0, K0,
                                        ld1[0].t() if have_lines else None, s1, K1, float(np.float32(thr_l)), True)
         if tail is not None:
