@@ -89,3 +89,28 @@ def test_fused_matcher_on_several_streams(eng):
         torch.cuda.synchronize()
         for o, r in zip(outs, ref):
             assert np.array_equal(o.cpu().numpy(), r)
+
+
+def test_pair_tail_equals_the_separate_calls(eng):
+    """linetr_pair_tail (the matching tail of Matching.forward in one call: point matcher + line matcher + the four device -> host
+    copies into one pinned block) returns exactly what linetr_match_points and linetr_match return; either branch can be skipped."""
+    rs = np.random.RandomState(21)
+    d0, s0, A0 = make_side(rs, 90, 3)
+    d1, s1, A1 = make_side(rs, 120, 2)
+    p0 = rs.standard_normal((256, 301)).astype(np.float32); p0 /= np.linalg.norm(p0, axis=0, keepdims=True)
+    p1 = rs.standard_normal((256, 257)).astype(np.float32); p1 /= np.linalg.norm(p1, axis=0, keepdims=True)
+    t = lambda a: torch.from_numpy(a).cuda()
+    dist_ref, m_ref = eng.match_points(t(p0), t(p1), 0.7, True)
+    dk_ref, m01_ref = run(eng, d0, s0, 90, d1, s1, 120, 0.8)
+    got = eng.collect_tail(eng.pair_tail(t(p0), t(p1), 0.7, t(d0), t(s0), 90, t(d1), t(s1), 120, 0.8, True))
+    assert np.array_equal(got[0], dist_ref.cpu().numpy()) and np.array_equal(got[1], m_ref.cpu().numpy())
+    assert np.array_equal(got[2], dk_ref) and np.array_equal(got[3], m01_ref)
+    only_pts = eng.collect_tail(eng.pair_tail(t(p0), t(p1), 0.7, None, None, 0, None, None, 0, 0.8, True))
+    assert np.array_equal(only_pts[1], got[1]) and only_pts[2].shape == (0, 0) and only_pts[3].shape == (0,)
+    only_lines = eng.collect_tail(eng.pair_tail(None, None, 0.7, t(d0), t(s0), 90, t(d1), t(s1), 120, 0.8, True))
+    assert only_lines[0].shape == (0, 0) and np.array_equal(only_lines[2], got[2]) and np.array_equal(only_lines[3], got[3])
+    # tickets collected out of order within the ring of four staging buffers
+    a = eng.pair_tail(t(p0), t(p1), 0.7, t(d0), t(s0), 90, t(d1), t(s1), 120, 0.8, True)
+    b = eng.pair_tail(t(p1), t(p0), 0.7, t(d1), t(s1), 120, t(d0), t(s0), 90, 0.8, True)
+    rb, ra = eng.collect_tail(b), eng.collect_tail(a)
+    assert np.array_equal(ra[3], got[3]) and rb[2].shape == (120, 90)
