@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 
 from linetr_amd import parallel
 from workloads import synth  # noqa: E402
-from linetr_amd.engine import Engine  # noqa: E402
+from linetr_amd.engine import DescribePipeline, Engine  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA
@@ -85,10 +85,14 @@ def make_inputs(workload, pairs, rank, device, eng):
 
 
 class Pipeline:
-    def __init__(self, eng, lines, dd, ds, hw, T, world, pairs, n_streams=1, layout="nhwc"):
+    def __init__(self, eng, lines, dd, ds, hw, T, world, pairs, n_streams=1, layout="nhwc", pipelined=False):
         self.eng, self.lines, self.dd, self.ds, self.hw, self.T = eng, lines, dd, ds, hw, T
         self.world, self.pairs = world, pairs
         self.n_streams = n_streams
+        # pipelined: consecutive steps as a two-stream software pipeline (DescribePipeline): step() submits batch i and hands back
+        # batch i - 1; drain() -- part of the barrier that closes every timed region -- joins the batch still in flight
+        self.dpipe = DescribePipeline(eng) if pipelined else None
+        self.last_joined = None
         self.layout = layout
         self.n_img_cap = 2 * pairs
         self.packed = [None, None]      # double-buffered: the all-gather of step i overlaps the compute of step i+1
@@ -119,8 +123,23 @@ class Pipeline:
         return parallel.pack_descriptors(ld, tb.cu_n, self.n_img_cap, self.rows_cap, out, cu_k=tb.cu_k,
                                          sub2line=tb.sub2line, d_cu_n=tb.extra.get("d_cu_n"), d_cu_k=tb.extra.get("d_cu_k"))
 
+    def submit(self):
+        e, c = self.eng, LINE_CFG
+        return self.dpipe.submit(self.cat, self.offsets, self.dd, self.ds, remove_borders=c["remove_borders"],
+                                 min_length=c["min_length"], max_keylines=c["max_keylines"], token_distance=c["token_distance"],
+                                 max_tokens=self.T, dense_layout=self.layout)
+
     def step(self):
-        tb, ld = self.describe()
+        if self.dpipe is not None:
+            done = self.submit()
+            if done is None:            # first step after a drain: nothing to hand back yet (the batch just submitted is in flight)
+                return self.last_joined
+            tb, ld = done
+        else:
+            tb, ld = self.describe()
+        return self.after_describe(tb, ld)
+
+    def after_describe(self, tb, ld):
         gathered = None
         if self.world > 1:
             s = self.slot
@@ -130,10 +149,16 @@ class Pipeline:
             work, gathered = parallel.allgather_descriptors(self.packed[s], async_op=True)
             self.pending[s] = (work, gathered)
             self.slot ^= 1
-        return tb, ld, gathered
+        self.last_joined = (tb, ld, gathered)
+        return self.last_joined
 
     def drain(self):
-        """wait for every outstanding all-gather (called before the closing barrier of a timed region)."""
+        """join the batch still in flight in the describe pipeline (its all-gather included) and wait for every outstanding
+        all-gather (called before the closing barrier of a timed region)."""
+        if self.dpipe is not None:
+            done = self.dpipe.drain()
+            if done is not None:
+                self.after_describe(*done)
         for i, p in enumerate(self.pending):
             if p is not None:
                 p[0].wait()
@@ -923,6 +948,9 @@ def main():
     ap.add_argument("--dense-layout", default="nchw", choices=["nhwc", "nchw"],
                     help="layout of the resident dense descriptor map: nchw = the reference's 'dense_descriptor' (models/superpoint.py:193; "
                          "the metric's input, SURVEY 8d), nhwc = what the repo's own producer emits (reported beside it as value_fed_nhwc)")
+    ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1],
+                    help="1: consecutive steps as the two-stream software pipeline (linetr_describe_submit / _join: the front of step "
+                         "i + 1 under the signature network of step i, full batch in every GEMM); 0: one step after the other on one stream")
     ap.add_argument("--settle-s", type=float, default=2.0, help="minimum seconds of load before anything is timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alt-precisions", action="store_true",
@@ -981,7 +1009,7 @@ def main():
 
     lines, dd_nchw, dd_nhwc, ds, hw, T = make_inputs(args.workload, pairs, rank, device, eng)
     feed = dd_nhwc if args.dense_layout == "nhwc" else dd_nchw
-    pipe = Pipeline(eng, lines, feed, ds, hw, T, world, pairs, args.streams, args.dense_layout)
+    pipe = Pipeline(eng, lines, feed, ds, hw, T, world, pairs, args.streams, args.dense_layout, pipelined=bool(args.pipeline))
     if world > 1:     # every rank's slab must have the same height: the largest sub-line count of any rank
         t = torch.tensor([pipe.rows_cap], dtype=torch.int64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -999,6 +1027,12 @@ def main():
     for _ in range(args.warmup):
         pipe.step()
     elapsed, per_step, host_ms, (tb, ld, _g) = timed_steps(pipe.step, barrier, args.steps, device)
+    if args.pipeline:
+        # the closing barrier joined the last batch; the first step of the region only submits (nothing in flight behind the opening
+        # barrier), so its event interval is empty and the last batch's completion falls behind the last event: the per-step
+        # statistics are taken over the K - 1 completion-to-completion intervals in between
+        tb, ld, _g = pipe.last_joined
+        per_step = per_step[1:] if len(per_step) > 2 else per_step
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -486,6 +486,10 @@ struct TokenStage {            // how the token stage (word MLP + CLS pooling) i
   int Hc = 0, Wc = 0, align_corners = 0;
   bool use_side = false;       // h->side carries the NHWC transpose (ev_nhwc) and may take the line-position MLP
   const BnTrain* bn = nullptr; // training-time forward (linetr_forward_train): BatchNorm on batch statistics, convolutions unfolded
+  // two-stream pipeline (linetr_describe_submit): everything from the line-signature network on is queued on `back`, behind `ev_cut`
+  hipStream_t back = nullptr;
+  hipEvent_t ev_cut = nullptr;
+  int cut = 0;                 // 0: the cut sits in front of the signature network; 1: right behind the pooling + value projection
 };
 
 bool fused_mlp_enabled(const LinetrModelConfig& c) {
@@ -571,6 +575,14 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   const float cx = c.norm_width / 2.f, cy = c.norm_height / 2.f;           // line_transformer.py:30-32
   const float scale = (float)std::max(c.norm_width, c.norm_height) * 0.7f;
   int e;
+  // pipelined call: from the cut on, launches go to the back stream (ordered behind everything queued on `st` so far)
+  auto to_back = [&]() -> int {
+    if (!ts.back || ts.back == st) return LINETR_OK;
+    LT_HIP(hipEventRecord(ts.ev_cut, st));
+    LT_HIP(hipStreamWaitEvent(ts.back, ts.ev_cut, 0));
+    st = ts.back;
+    return LINETR_OK;
+  };
   // experiment (LINETR_PAIRNET=1; measured and not shipped): the whole signature network of a single pair as ONE
   // persistent launch (lt_pairnet.h); its arrival counters are zeroed here, far ahead of it on the stream
 #ifdef LINETR_EXPERIMENTS
@@ -737,6 +749,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   }
   if ((e = run_gemm(h, st, w.pooled, HEADS * POOLW, nullptr, 0, 0, h->Watt, h->batt, nullptr, 0, w.att, D, N, DH, POOLW,
                     ACT_NONE, HEADS, POOLW, (int64_t)DH * POOLW, DH, DH))) return e;
+  if (ts.cut == 1 && (e = to_back())) return e;
 #ifdef LINETR_EXPERIMENTS
   const bool chain = chain_wins(h, N) && !h->sig.empty();
 #else
@@ -770,6 +783,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   }
   }
   // ---- line signature network
+  if ((e = to_back())) return e;
 #ifdef LINETR_EXPERIMENTS
   if (pairnet && !chain) return pairnet_run(h, st, w.zA, d_line_desc, h_cu, n_images, N, w.pn);
 #endif
@@ -1038,11 +1052,14 @@ extern "C" int64_t linetr_describe_workspace_bytes(const LinetrHandle* h, int32_
          fwd_layout(h, std::max(N, 1), rows, n_images, nullptr).total;
 }
 
-extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N, int64_t n_real,
-                               const int32_t* h_cu, const int32_t* d_cu, int32_t n_images, double td, int32_t T,
-                               const float* d_dense_desc, const float* d_dense_score, int32_t height, int32_t width,
-                               int32_t align_corners, int32_t dense_is_nhwc, LinetrTokens out, int32_t* d_sub2line,
-                               float* d_line_desc, void* d_ws, int64_t ws_bytes, void* stream) {
+namespace {
+// linetr_describe proper.  back != nullptr (linetr_describe_submit): the line-signature network of the batch is queued on `back`
+// behind `ev_cut`, everything in front of it on `st`.
+int describe_impl(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N, int64_t n_real,
+                  const int32_t* h_cu, const int32_t* d_cu, int32_t n_images, double td, int32_t T,
+                  const float* d_dense_desc, const float* d_dense_score, int32_t height, int32_t width,
+                  int32_t align_corners, int32_t dense_is_nhwc, const LinetrTokens& out, int32_t* d_sub2line,
+                  float* d_line_desc, void* d_ws, int64_t ws_bytes, hipStream_t st, hipStream_t back, hipEvent_t ev_cut, int cut) {
   if (!h) return fail(LINETR_E_ARG, "describe: null handle");
   if (h->cfg.bn_batch_stats) return fail(LINETR_E_ARG, "describe: a training-mode handle (bn_batch_stats = 1) runs linetr_forward_train only");
   if (int e = check_cu(h_cu, n_images)) return e;
@@ -1058,7 +1075,6 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
     return fail(LINETR_E_WORKSPACE, "describe: workspace too small");
   const int64_t rows = n_real + n_images;
   if (rows > INT32_MAX / 8) return fail(LINETR_E_ARG, "describe: batch too large");
-  hipStream_t st = (hipStream_t)stream;
   LT_HIP(hipSetDevice(h->device));
   DescWs dw = desc_layout(n_images, height, width, N, rows, (char*)d_ws);
   FwdWs w = fwd_layout(h, N, rows, n_images, (char*)d_ws + dw.fwd_off);
@@ -1072,7 +1088,7 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
   float* resp = out.resp ? out.resp : dw.resp;
   float* angle_sub = out.angle_sub ? out.angle_sub : dw.angle_sub;
   const float* nhwc_map = dense_is_nhwc ? d_dense_desc : dw.nhwc;
-  const bool use_side = side_stream_ready(h, N);
+  const bool use_side = !back && side_stream_ready(h, N);
   if (use_side && !dense_is_nhwc) {  // NHWC transpose on the side stream, concurrent with tokenise + token MLP
     // (measured: while this grid drains, the fused word MLP -- one fat wave per SIMD -- gets most of its blocks placed
     // 140-175 us late and ends about when the transposition does; deferring the transposition behind it, or making it
@@ -1125,9 +1141,91 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
   ts.cpnt = dw.cpnt; ts.cscore = dw.cscore; ts.nhwc = nhwc_map; ts.recs = d_recs; ts.sub2line_g = dw.s2l_g;
   ts.rows = rows; ts.first_pad = n_real; ts.Hc = Hc; ts.Wc = Wc; ts.align_corners = align_corners;
   ts.use_side = use_side;
+  ts.back = back; ts.ev_cut = ev_cut; ts.cut = cut;
   const int e = forward_core(h, st, ts, sublines, resp, angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);
   if (e && use_side) join_side_after_error(h, st);
   return e;
+}
+
+// the two streams and six events of the describe pipeline, made at the first submit: all or nothing
+int pipe_ready(LinetrHandle* h) {
+  LinetrHandle::Pipe& p = h->pipe;
+  if (p.front) return LINETR_OK;
+  if (p.failed) return fail(LINETR_E_HIP, "describe_submit: the pipeline's streams could not be created");
+  hipStream_t s[2] = {nullptr, nullptr};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // numerically lower = higher priority
+  int pf = lo, pb = lo;
+  if (const char* v = getenv("LINETR_PIPE_PRIO")) {     // TUNING (r06, to be removed): 1 = back stream high, 2 = front stream high
+    if (atoi(v) == 1) pb = hi;
+    if (atoi(v) == 2) pf = hi;
+  }
+  bool ok = hipStreamCreateWithPriority(&s[0], hipStreamNonBlocking, pf) == hipSuccess &&
+            hipStreamCreateWithPriority(&s[1], hipStreamNonBlocking, pb) == hipSuccess;
+  for (int i = 0; ok && i < 6; ++i) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t x : s) if (x) (void)hipStreamDestroy(x);
+    (void)hipGetLastError();
+    p.failed = true;
+    return fail(LINETR_E_HIP, "describe_submit: the pipeline's streams could not be created");
+  }
+  p.front = s[0]; p.back = s[1];
+  for (int i = 0; i < 2; ++i) { p.fork[i] = ev[3 * i]; p.front_done[i] = ev[3 * i + 1]; p.back_done[i] = ev[3 * i + 2]; }
+  return LINETR_OK;
+}
+}  // namespace
+
+extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N, int64_t n_real,
+                               const int32_t* h_cu, const int32_t* d_cu, int32_t n_images, double td, int32_t T,
+                               const float* d_dense_desc, const float* d_dense_score, int32_t height, int32_t width,
+                               int32_t align_corners, int32_t dense_is_nhwc, LinetrTokens out, int32_t* d_sub2line,
+                               float* d_line_desc, void* d_ws, int64_t ws_bytes, void* stream) {
+  return describe_impl(h, d_recs, K, N, n_real, h_cu, d_cu, n_images, td, T, d_dense_desc, d_dense_score, height, width, align_corners,
+                       dense_is_nhwc, out, d_sub2line, d_line_desc, d_ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr, 0);
+}
+
+extern "C" int linetr_describe_submit(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N, int64_t n_real,
+                                      const int32_t* h_cu, const int32_t* d_cu, int32_t n_images, double td, int32_t T,
+                                      const float* d_dense_desc, const float* d_dense_score, int32_t height, int32_t width,
+                                      int32_t align_corners, int32_t dense_is_nhwc, LinetrTokens out, int32_t* d_sub2line,
+                                      float* d_line_desc, void* d_ws, int64_t ws_bytes, int32_t slot, void* stream) {
+  if (!h) return fail(LINETR_E_ARG, "describe_submit: null handle");
+  if (slot < 0 || slot > 1) return fail(LINETR_E_ARG, "describe_submit: slot must be 0 or 1");
+  LT_HIP(hipSetDevice(h->device));
+  if (int e = pipe_ready(h)) return e;
+  LinetrHandle::Pipe& p = h->pipe;
+  hipStream_t st = (hipStream_t)stream;
+  // host run-ahead is bounded to the two batches in flight: the slot's previous batch (two submits ago) must have left the GPU before
+  // its workspace is handed to the device again
+  if (p.submitted[slot]) LT_HIP(hipEventSynchronize(p.back_done[slot]));
+  // fork: the front stream starts behind everything the caller has queued so far (the upload of d_recs, the producer of the maps,
+  // and -- through the caller's join of the batch before last -- the previous user of this slot's workspace)
+  LT_HIP(hipEventRecord(p.fork[slot], st));
+  LT_HIP(hipStreamWaitEvent(p.front, p.fork[slot], 0));
+  static const int cut = getenv("LINETR_PIPE_CUT") ? atoi(getenv("LINETR_PIPE_CUT")) : 0;   // TUNING (r06, to be removed)
+  const int e = describe_impl(h, d_recs, K, N, n_real, h_cu, d_cu, n_images, td, T, d_dense_desc, d_dense_score, height, width,
+                              align_corners, dense_is_nhwc, out, d_sub2line, d_line_desc, d_ws, ws_bytes, p.front, p.back,
+                              p.front_done[slot], cut);
+  if (e) {   // leave both streams idle and the slot free: a failed submit must not leave half a batch behind
+    (void)hipStreamSynchronize(p.front);
+    (void)hipStreamSynchronize(p.back);
+    p.submitted[slot] = false;
+    return e;
+  }
+  // (an empty batch queues nothing: the event then completes with whatever the back stream already holds)
+  LT_HIP(hipEventRecord(p.back_done[slot], p.back));
+  p.submitted[slot] = true;
+  return LINETR_OK;
+}
+
+extern "C" int linetr_describe_join(LinetrHandle* h, int32_t slot, void* stream) {
+  if (!h) return fail(LINETR_E_ARG, "describe_join: null handle");
+  if (slot < 0 || slot > 1) return fail(LINETR_E_ARG, "describe_join: slot must be 0 or 1");
+  if (!h->pipe.front || !h->pipe.submitted[slot]) return fail(LINETR_E_ARG, "describe_join: nothing was submitted to this slot");
+  LT_HIP(hipStreamWaitEvent((hipStream_t)stream, h->pipe.back_done[slot], 0));
+  return LINETR_OK;
 }
 
 extern "C" int linetr_debug_posenc(LinetrHandle* h, int32_t which, const float* d_in0, const float* d_in1,

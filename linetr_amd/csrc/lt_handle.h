@@ -56,6 +56,15 @@ struct LinetrHandle {
   hipStream_t side = nullptr;
   bool side_failed = false;
   hipEvent_t ev_fork = nullptr, ev_tok = nullptr, ev_nhwc = nullptr, ev_lpos = nullptr;
+  // two-stream software pipeline of CONSECUTIVE describe calls (linetr_describe_submit / linetr_describe_join): the front of a batch
+  // (layout pass, tokeniser, token MLP, CLS pooling + tail: HBM-bound for half of its time) runs on `front`, its line-signature
+  // network (MFMA-bound, tile rounds that leave CUs empty) on `back`; batch i + 1's front overlaps batch i's back.  Slot s = i mod 2.
+  struct Pipe {
+    hipStream_t front = nullptr, back = nullptr;
+    hipEvent_t fork[2] = {nullptr, nullptr}, front_done[2] = {nullptr, nullptr}, back_done[2] = {nullptr, nullptr};
+    bool submitted[2] = {false, false};
+    bool failed = false;
+  } pipe;
   // stream-K workspace of the 128x256 GEMM (partial accumulator tiles + flags, one slot per CU; lt_gemm_split.h)
   float* zeros = nullptr;   // 4096 zero floats: the "no bias" vector of the split-tile GEMM (lt_gemm_st.h)
   float* sk_ws = nullptr;

@@ -366,10 +366,14 @@ class Engine:
         return tb
 
     def describe(self, recs, cu_k, cu_n, dense_desc, dense_score, *, token_distance, max_tokens, align_corners=False,
-                 want_tokens=False, dense_layout="nchw", want_mat=False):
+                 want_tokens=False, dense_layout="nchw", want_mat=False, pipeline_slot=None):
         """Fused tokenise + descriptor network for a batch (linetr_describe): real tokens only, descriptors sampled
         on the fly.  Returns (TokenBatch, line_desc [N,256]).  With want_tokens=False the dense [N,T,...] token
-        tensors (pnt / mask / score / desc) are not materialised (zero-sized in the TokenBatch)."""
+        tensors (pnt / mask / score / desc) are not materialised (zero-sized in the TokenBatch).
+
+        pipeline_slot = 0 / 1: linetr_describe_submit -- the batch runs on the library's front / back stream pair, overlapped with the
+        batch submitted to the other slot, and is NOT joined: the returned tensors may be read only after describe_join(slot)
+        (class DescribePipeline does the bookkeeping)."""
         B = len(cu_k) - 1
         K, N, T = int(cu_k[-1]), int(cu_n[-1]), int(max_tokens)
         dense_desc = self._f32(dense_desc)
@@ -421,18 +425,27 @@ class Engine:
             if B == 1:
                 tb.mat = tb.mat.view(K, N)
         nbytes = self._L.linetr_describe_workspace_bytes(self._h, B, H, W, N, n_real)
-        ws = self._workspace(getattr(self, "_ws_tag", None) or "desc", nbytes)
         cu = np.ascontiguousarray(cu_n, dtype=np.int32)
-        nat.check(self._L.linetr_describe(self._h, d_recs.data_ptr(), K, N, n_real, nat.np_ptr(cu),
-                                          d_cu.data_ptr() if d_cu is not None else None, B, float(token_distance), T,
-                                          dense_desc.data_ptr(), dense_score.data_ptr(), H, W, int(bool(align_corners)),
-                                          int(nhwc), ct, tb.sub2line.data_ptr(), ld.data_ptr(), ws.data_ptr(),
-                                          ws.numel(), self._stream()), self._L)
+        args = (self._h, d_recs.data_ptr(), K, N, n_real, nat.np_ptr(cu), d_cu.data_ptr() if d_cu is not None else None, B,
+                float(token_distance), T, dense_desc.data_ptr(), dense_score.data_ptr(), H, W, int(bool(align_corners)), int(nhwc), ct,
+                tb.sub2line.data_ptr(), ld.data_ptr())
+        if pipeline_slot is None:
+            ws = self._workspace(getattr(self, "_ws_tag", None) or "desc", nbytes)
+            nat.check(self._L.linetr_describe(*args, ws.data_ptr(), ws.numel(), self._stream()), self._L)
+        else:
+            slot = int(pipeline_slot)
+            ws = self._workspace(f"desc_pipe{slot}", nbytes)      # one workspace per slot: two batches are in flight
+            tb.extra["dense"] = (dense_desc, dense_score)          # read by the front stream after this call returns
+            nat.check(self._L.linetr_describe_submit(*args, ws.data_ptr(), ws.numel(), slot, self._stream()), self._L)
         return tb, ld
+
+    def describe_join(self, slot: int):
+        """The current stream waits for the batch last submitted to `slot` (linetr_describe_join)."""
+        nat.check(self._L.linetr_describe_join(self._h, int(slot), self._stream()), self._L)
 
     def describe_lines(self, lines6, offsets, dense_desc, dense_score, *, remove_borders, min_length, max_keylines,
                        token_distance, max_tokens, align_corners=False, n_streams=1, want_tokens=False,
-                       dense_layout="nchw", angles="native"):
+                       dense_layout="nchw", angles="native", pipeline_slot=None):
         """prefilter + describe for a batch given as one [sum K,6] array + row offsets [B+1].
 
         angles: "native" -- (cos 2theta, sin 2theta) from the host pre-filter's libm (the throughput path: nothing of the step runs in
@@ -461,7 +474,9 @@ class Engine:
                 recs["angle"] = get_angles(np.stack([recs["sp"], recs["ep"]], axis=1))     # (records live in the pinned upload slot)
             return self.describe(recs, cu_k, cu_n, dense_desc, dense_score, token_distance=token_distance,
                                  max_tokens=max_tokens, align_corners=align_corners, want_tokens=want_tokens,
-                                 dense_layout=dense_layout)
+                                 dense_layout=dense_layout, pipeline_slot=pipeline_slot)
+        if pipeline_slot is not None:
+            raise ValueError("pipeline_slot and n_streams > 1 are two different schedules: pick one")
         # contiguous image groups of (nearly) equal line count
         target = offsets[-1] / G
         cuts = [0] + [int(np.searchsorted(offsets, target * g)) for g in range(1, G)] + [B]
@@ -955,3 +970,39 @@ class Engine:
         nat.check(self._L.linetr_get_profile(self._h, arr, 64, C.byref(n)), self._L)
         return [dict(name=arr[i].name.decode(), calls=arr[i].calls, ms=arr[i].ms, flops=arr[i].flops,
                      bytes=arr[i].bytes) for i in range(min(n.value, 64))]
+
+
+class DescribePipeline:
+    """Software pipeline over CONSECUTIVE batches of Engine.describe_lines (linetr_describe_submit / linetr_describe_join, SURVEY.md
+    section 7 step 5): batch i + 1's front (layout pass, tokeniser, token MLP, pooling -- half of it HBM-bound) runs on the GPU under batch
+    i's line-signature network (MFMA-bound).  Each batch is described whole -- every GEMM sees the full batch -- and its results are
+    those of describe_lines bit for bit; what is traded is one batch of latency:
+
+        pipe = DescribePipeline(engine)
+        for batch in batches:
+            done = pipe.submit(lines6, offsets, dense_desc, dense_score, ...)   # -> (TokenBatch, line_desc) of the PREVIOUS batch, or None
+            if done: consume(*done)
+        consume(*pipe.drain())
+
+    The tensors a submit returns belong to the previous batch and are ordered on the current stream like describe_lines' own."""
+
+    def __init__(self, engine: "Engine"):
+        self.eng = engine
+        self.slot = 0
+        self.inflight = None          # (slot, (tb, ld)) of the batch submitted last, not joined yet
+
+    def _join(self, entry):
+        slot, (tb, ld) = entry
+        if tb.K > 0 and tb.N > 0:     # an empty batch queues nothing
+            self.eng.describe_join(slot)
+        return tb, ld
+
+    def submit(self, *args, **kw):
+        cur = self.eng.describe_lines(*args, pipeline_slot=self.slot, **kw)
+        prev, self.inflight = self.inflight, (self.slot, cur)
+        self.slot ^= 1
+        return self._join(prev) if prev is not None else None
+
+    def drain(self):
+        prev, self.inflight = self.inflight, None
+        return self._join(prev) if prev is not None else None

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
         LX = nat.lib(nat.EXPERIMENTS_LIB_PATH)
         for name in declared | declared_x:
             assert hasattr(LX, name), name
-    assert L.linetr_abi_version() == 4
+    assert L.linetr_abi_version() == 5
     assert C.sizeof(nat.LineRec) == 80
 
 
