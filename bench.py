@@ -91,7 +91,7 @@ class Pipeline:
         self.n_streams = n_streams
         # pipelined: consecutive steps as a two-stream software pipeline (DescribePipeline): step() submits batch i and hands back
         # batch i - 1; drain() -- part of the barrier that closes every timed region -- joins the batch still in flight
-        self.dpipe = DescribePipeline(eng) if pipelined else None
+        self.dpipe = DescribePipeline(eng, int(pipelined)) if pipelined else None
         self.last_joined = None
         self.layout = layout
         self.n_img_cap = 2 * pairs
@@ -156,8 +156,7 @@ class Pipeline:
         """join the batch still in flight in the describe pipeline (its all-gather included) and wait for every outstanding
         all-gather (called before the closing barrier of a timed region)."""
         if self.dpipe is not None:
-            done = self.dpipe.drain()
-            if done is not None:
+            for done in self.dpipe.drain():
                 self.after_describe(*done)
         for i, p in enumerate(self.pending):
             if p is not None:
@@ -948,9 +947,9 @@ def main():
     ap.add_argument("--dense-layout", default="nchw", choices=["nhwc", "nchw"],
                     help="layout of the resident dense descriptor map: nchw = the reference's 'dense_descriptor' (models/superpoint.py:193; "
                          "the metric's input, SURVEY 8d), nhwc = what the repo's own producer emits (reported beside it as value_fed_nhwc)")
-    ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1],
-                    help="1: consecutive steps as the two-stream software pipeline (linetr_describe_submit / _join: the front of step "
-                         "i + 1 under the signature network of step i, full batch in every GEMM); 0: one step after the other on one stream")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[0, 2, 3, 4],
+                    help="batches in flight: 2-4 = consecutive steps as the software pipeline (linetr_describe_submit / _join: the front "
+                         "of step i + 1 under the signature network of step i, full batch in every GEMM); 0: one step after the other on one stream")
     ap.add_argument("--settle-s", type=float, default=2.0, help="minimum seconds of load before anything is timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alt-precisions", action="store_true",
@@ -1009,7 +1008,7 @@ def main():
 
     lines, dd_nchw, dd_nhwc, ds, hw, T = make_inputs(args.workload, pairs, rank, device, eng)
     feed = dd_nhwc if args.dense_layout == "nhwc" else dd_nchw
-    pipe = Pipeline(eng, lines, feed, ds, hw, T, world, pairs, args.streams, args.dense_layout, pipelined=bool(args.pipeline))
+    pipe = Pipeline(eng, lines, feed, ds, hw, T, world, pairs, args.streams, args.dense_layout, pipelined=args.pipeline)
     if world > 1:     # every rank's slab must have the same height: the largest sub-line count of any rank
         t = torch.tensor([pipe.rows_cap], dtype=torch.int64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1030,9 +1029,9 @@ def main():
     if args.pipeline:
         # the closing barrier joined the last batch; the first step of the region only submits (nothing in flight behind the opening
         # barrier), so its event interval is empty and the last batch's completion falls behind the last event: the per-step
-        # statistics are taken over the K - 1 completion-to-completion intervals in between
+        # statistics are taken over the K - depth + 1 completion-to-completion intervals in between
         tb, ld, _g = pipe.last_joined
-        per_step = per_step[1:] if len(per_step) > 2 else per_step
+        per_step = per_step[args.pipeline - 1:] if len(per_step) > args.pipeline else per_step
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

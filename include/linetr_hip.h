@@ -233,26 +233,27 @@ int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int
                     int32_t* d_sub2line, float* d_line_desc, void* d_workspace, int64_t workspace_bytes,
                     void* stream);
 
-/* linetr_describe as a two-stream software pipeline over CONSECUTIVE batches ("batch/varlen plumbing +
- * stream pipelining"; the reference is serial per pair, models/matching.py:34-60).  The batch's front -- layout pass, tokeniser,
- * positional-encoder MLPs, CLS pooling, descriptive-layer tail: HBM-bound for half of its time -- is queued on a library-owned front
- * stream, its line-signature network (seven attention + MLP layers and the final projection: MFMA-bound, launches whose tile rounds
- * leave CUs empty) on a library-owned back stream; the front of batch i + 1 therefore runs under the signature network of batch i.
- * Every GEMM still sees the FULL batch (nothing is split), and the results are bit-identical to linetr_describe's: the same kernels
- * on the same data.
- *   linetr_describe_submit  same arguments as linetr_describe + slot (0 / 1; alternate it from batch to batch).  The work starts behind
- *                           everything already queued on `stream` (the upload of d_recs, the producer of the dense maps) and is NOT
- *                           joined back: `stream` does not wait for it.  Every slot needs its OWN d_workspace and output buffers, alive
- *                           until the slot is joined.  Host run-ahead is bounded: a submit to a slot first waits (on the host) for the
- *                           batch previously submitted to that slot, so at most two batches are in flight.
+/* linetr_describe as a software pipeline over CONSECUTIVE batches ("batch/varlen plumbing + stream
+ * pipelining"; the reference is serial per pair, models/matching.py:34-60).  A batch is cut into stages at fixed points of the network
+ * -- e.g. front = layout pass, tokeniser, positional-encoder MLPs, CLS pooling, descriptive-layer tail (HBM-bound for half of its
+ * time); back = the line-signature network (MFMA-bound, launches whose tile rounds leave CUs empty) -- and stage k of every batch is
+ * queued on the k-th of a set of library-owned streams, so stage k of batch i + 1 runs under stage k + 1 of batch i.  Every GEMM still
+ * sees the FULL batch (nothing is split), and the results are bit-identical to linetr_describe's: the same kernels on the same data.
+ *   linetr_describe_submit  same arguments as linetr_describe + slot and n_slots: the caller keeps n_slots (2 .. linetr_pipeline_max_slots())
+ *                           batches in flight and gives batch i the slot i mod n_slots.  The work starts behind everything already
+ *                           queued on `stream` (the upload of d_recs, the producer of the dense maps) and is NOT joined back: `stream`
+ *                           does not wait for it.  Every slot needs its OWN d_workspace and output buffers, alive until the slot is
+ *                           joined.  Host run-ahead is bounded: a submit first waits (on the host) for the batch previously submitted
+ *                           to the same slot.
  *   linetr_describe_join    `stream` waits for the batch last submitted to `slot`; its outputs may be read on `stream` afterwards.
- * A caller pipelines by  submit(i + 1, slot ^ 1); join(i, slot);  -- one batch of latency for the overlap. */
+ * A caller pipelines by  submit(i, i mod n);  join(i - n + 1, (i - n + 1) mod n);  -- n - 1 batches of latency for the overlap. */
 int linetr_describe_submit(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N, int64_t n_real_tokens,
                            const int32_t* h_cu_sub, const int32_t* d_cu_sub, int32_t n_images, double token_distance,
                            int32_t max_tokens, const float* d_dense_desc, const float* d_dense_score, int32_t height,
                            int32_t width, int32_t align_corners, int32_t dense_is_nhwc, LinetrTokens out,
                            int32_t* d_sub2line, float* d_line_desc, void* d_workspace, int64_t workspace_bytes,
-                           int32_t slot, void* stream);
+                           int32_t slot, int32_t n_slots, void* stream);
+int32_t linetr_pipeline_max_slots(void);
 int linetr_describe_join(LinetrHandle* h, int32_t slot, void* stream);
 
 /* ---- device: matcher ------------------------------------------------------------------------ */

@@ -82,8 +82,9 @@ def lib(path=None):
     L.linetr_describe.argtypes = [vp, vp, i32, i32, i64, vp, vp, i32, f64, i32, vp, vp, i32, i32, i32, i32, Tokens, vp, vp,
                                   vp, i64, vp]
     L.linetr_describe_submit.argtypes = [vp, vp, i32, i32, i64, vp, vp, i32, f64, i32, vp, vp, i32, i32, i32, i32, Tokens, vp, vp,
-                                         vp, i64, i32, vp]
+                                         vp, i64, i32, i32, vp]
     L.linetr_describe_join.argtypes = [vp, i32, vp]
+    L.linetr_pipeline_max_slots.argtypes = []
     L.linetr_tokenize_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.linetr_tokenize_workspace_bytes.restype = i64
     L.linetr_tokenize.argtypes = [vp, vp, i32, i32, f64, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, Tokens, vp, vp, i64, vp]
@@ -145,7 +146,7 @@ def lib(path=None):
 
 EXPORTS = ["linetr_abi_version", "linetr_last_error", "linetr_create", "linetr_destroy", "linetr_prefilter",
            "linetr_prefilter_batch", "linetr_prefilter_tied_images", "linetr_pack_lines", "linetr_tokenize_workspace_bytes", "linetr_tokenize", "linetr_forward_workspace_bytes",
-           "linetr_forward", "linetr_bn_stats_floats", "linetr_forward_train_workspace_bytes", "linetr_forward_train", "linetr_describe_workspace_bytes", "linetr_describe", "linetr_describe_submit", "linetr_describe_join", "linetr_match_workspace_bytes", "linetr_match", "linetr_match_gathered", "linetr_match_points",
+           "linetr_forward", "linetr_bn_stats_floats", "linetr_forward_train_workspace_bytes", "linetr_forward_train", "linetr_describe_workspace_bytes", "linetr_describe", "linetr_describe_submit", "linetr_describe_join", "linetr_pipeline_max_slots", "linetr_match_workspace_bytes", "linetr_match", "linetr_match_gathered", "linetr_match_points",
            "linetr_match_distmat", "linetr_match_distmat_workspace_bytes", "linetr_match_distmat_f64", "linetr_match_distmat_f64_workspace_bytes", "linetr_pair_tail_workspace_bytes", "linetr_pair_tail_output_bytes", "linetr_pair_tail", "linetr_superpoint_heads", "linetr_set_precision", "linetr_get_precision", "linetr_debug_posenc", "linetr_debug_gemm", "linetr_allgather_desc", "linetr_set_allgather_fn", "linetr_pack_slab", "linetr_sample_descriptors_workspace_bytes",
            "linetr_sample_descriptors", "linetr_pool_distmat_workspace_bytes", "linetr_pool_distmat", "linetr_pool_distmat_dense_workspace_bytes", "linetr_pool_distmat_dense", "linetr_set_profiling", "linetr_get_profile"]
 

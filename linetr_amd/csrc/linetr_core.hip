@@ -465,11 +465,14 @@ extern "C" void linetr_destroy(LinetrHandle* h) {
   if (h->side) (void)hipStreamDestroy(h->side);
   for (hipEvent_t e : {h->ev_fork, h->ev_tok, h->ev_nhwc, h->ev_lpos})
     if (e) (void)hipEventDestroy(e);
-  if (h->pipe.front) { (void)hipStreamSynchronize(h->pipe.front); (void)hipStreamDestroy(h->pipe.front); }
-  if (h->pipe.back) { (void)hipStreamSynchronize(h->pipe.back); (void)hipStreamDestroy(h->pipe.back); }
-  for (int s = 0; s < 2; ++s)
-    for (hipEvent_t e : {h->pipe.fork[s], h->pipe.front_done[s], h->pipe.back_done[s]})
+  for (hipStream_t x : h->pipe.stream)
+    if (x) { (void)hipStreamSynchronize(x); (void)hipStreamDestroy(x); }
+  for (int s = 0; s < LinetrHandle::PIPE_SLOTS; ++s) {
+    for (hipEvent_t e : {h->pipe.fork[s], h->pipe.done[s]})
       if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->pipe.cut[s])
+      if (e) (void)hipEventDestroy(e);
+  }
   if (h->arena) (void)hipFree(h->arena);
   if (h->split_arena) (void)hipFree(h->split_arena);
   if (h->zeros) (void)hipFree(h->zeros);

@@ -474,6 +474,30 @@ extern "C" int64_t linetr_forward_workspace_bytes(const LinetrHandle* h, int32_t
 }
 
 namespace {
+// Cut points of a pipelined batch (linetr_describe_submit), in launch order.  Stage k = the launches between cut k - 1 and cut k, on
+// stream k of the handle's pipeline; the next stage's stream waits for an event recorded at the cut.
+enum {
+  CUT_TOKENS = 0,     // behind the tokeniser and the layout pass
+  CUT_MLP = 1,        // behind the positional encoders' MLPs
+  CUT_POOL = 2,       // behind the CLS pooling + value projection
+  CUT_SENTENCE = 3,   // behind the descriptive layer's tail: in front of the line-signature network
+  CUT_SIG0 = 4        // CUT_SIG0 + l: behind signature layer l
+};
+struct PipeStages {
+  hipStream_t stream[LinetrHandle::PIPE_STREAMS];
+  hipEvent_t ev[LinetrHandle::PIPE_STREAMS - 1];
+  int cut[LinetrHandle::PIPE_STREAMS - 1];
+  int n_cuts = 0, next = 0;
+};
+// at position `pos` of the launch sequence: if the plan cuts here, everything that follows is queued on the next stage's stream
+int pipe_boundary(PipeStages* p, int pos, hipStream_t& st) {
+  if (!p || p->next >= p->n_cuts || p->cut[p->next] != pos) return LINETR_OK;
+  LT_HIP(hipEventRecord(p->ev[p->next], st));
+  LT_HIP(hipStreamWaitEvent(p->stream[p->next + 1], p->ev[p->next], 0));
+  st = p->stream[++p->next];
+  return LINETR_OK;
+}
+
 struct TokenStage {            // how the token stage (word MLP + CLS pooling) is fed
   // dense path (linetr_forward): [N,T] tensors of the reference
   const float *pnt = nullptr, *score = nullptr, *desc = nullptr;
@@ -486,10 +510,7 @@ struct TokenStage {            // how the token stage (word MLP + CLS pooling) i
   int Hc = 0, Wc = 0, align_corners = 0;
   bool use_side = false;       // h->side carries the NHWC transpose (ev_nhwc) and may take the line-position MLP
   const BnTrain* bn = nullptr; // training-time forward (linetr_forward_train): BatchNorm on batch statistics, convolutions unfolded
-  // two-stream pipeline (linetr_describe_submit): everything from the line-signature network on is queued on `back`, behind `ev_cut`
-  hipStream_t back = nullptr;
-  hipEvent_t ev_cut = nullptr;
-  int cut = 0;                 // 0: the cut sits in front of the signature network; 1: right behind the pooling + value projection
+  PipeStages* pipe = nullptr;  // pipelined call (linetr_describe_submit): where the launch sequence moves on to the next stream
 };
 
 bool fused_mlp_enabled(const LinetrModelConfig& c) {
@@ -575,14 +596,6 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   const float cx = c.norm_width / 2.f, cy = c.norm_height / 2.f;           // line_transformer.py:30-32
   const float scale = (float)std::max(c.norm_width, c.norm_height) * 0.7f;
   int e;
-  // pipelined call: from the cut on, launches go to the back stream (ordered behind everything queued on `st` so far)
-  auto to_back = [&]() -> int {
-    if (!ts.back || ts.back == st) return LINETR_OK;
-    LT_HIP(hipEventRecord(ts.ev_cut, st));
-    LT_HIP(hipStreamWaitEvent(ts.back, ts.ev_cut, 0));
-    st = ts.back;
-    return LINETR_OK;
-  };
   // experiment (LINETR_PAIRNET=1; measured and not shipped): the whole signature network of a single pair as ONE
   // persistent launch (lt_pairnet.h); its arrival counters are zeroed here, far ahead of it on the stream
 #ifdef LINETR_EXPERIMENTS
@@ -708,6 +721,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     LT_HIP(hipEventRecord(h->ev_lpos, h->side));
     if (ts.cpnt) LT_HIP(hipStreamWaitEvent(st, h->ev_nhwc, 0));   // the pooling kernel samples the NHWC copy
   }
+  if ((e = pipe_boundary(ts.pipe, CUT_MLP, st))) return e;
   // ---- CLS-row attention pooling + value/last-MLP projection
   if (ts.cpnt) {
 #ifdef LINETR_EXPERIMENTS
@@ -749,7 +763,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   }
   if ((e = run_gemm(h, st, w.pooled, HEADS * POOLW, nullptr, 0, 0, h->Watt, h->batt, nullptr, 0, w.att, D, N, DH, POOLW,
                     ACT_NONE, HEADS, POOLW, (int64_t)DH * POOLW, DH, DH))) return e;
-  if (ts.cut == 1 && (e = to_back())) return e;
+  if ((e = pipe_boundary(ts.pipe, CUT_POOL, st))) return e;
 #ifdef LINETR_EXPERIMENTS
   const bool chain = chain_wins(h, N) && !h->sig.empty();
 #else
@@ -783,7 +797,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   }
   }
   // ---- line signature network
-  if ((e = to_back())) return e;
+  if ((e = pipe_boundary(ts.pipe, CUT_SENTENCE, st))) return e;
 #ifdef LINETR_EXPERIMENTS
   if (pairnet && !chain) return pairnet_run(h, st, w.zA, d_line_desc, h_cu, n_images, N, w.pn);
 #endif
@@ -831,6 +845,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
       if ((e = run_gemm(h, st, zc, ldz, w.hid, 2 * D, D, S.Wnext, S.bnext, nullptr, 0, zq, 4 * D, N, 4 * D, 3 * D, ACT_NONE))) return e;
       zc = zq; ldz = 4 * D; qkv_in = zq + D; ldq = 4 * D;
       std::swap(zq, zq_next);
+      if ((e = pipe_boundary(ts.pipe, CUT_SIG0 + (int)l, st))) return e;
       continue;
     }
     // q/k/v projection + attention of an (image, head) in one launch (lt_attn_fused.h): images of up to 256 sub-lines, and
@@ -915,6 +930,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     if (l + 1 == h->sig.size()) break;   // the last layer's second MLP GEMM is folded into the final projection below
     if ((e = run_gemm(h, st, w.hid, 2 * D, nullptr, 0, 0, S.W2, S.b2, z, D, zn, D, N, D, 2 * D, ACT_NONE))) return e;
     std::swap(z, zn);
+    if ((e = pipe_boundary(ts.pipe, CUT_SIG0 + (int)l, st))) return e;
   }
   NormSpec l2; l2.mode = 2;      // F.normalize(final_proj(.), dim=1)  (line_transformer.py:245-246)
   if (h->sig.empty()) {
@@ -1053,13 +1069,13 @@ extern "C" int64_t linetr_describe_workspace_bytes(const LinetrHandle* h, int32_
 }
 
 namespace {
-// linetr_describe proper.  back != nullptr (linetr_describe_submit): the line-signature network of the batch is queued on `back`
-// behind `ev_cut`, everything in front of it on `st`.
+// linetr_describe proper.  pipe != nullptr (linetr_describe_submit): the launch sequence moves from stream to stream at the plan's
+// cut points; `st` is the first stage's stream.
 int describe_impl(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N, int64_t n_real,
                   const int32_t* h_cu, const int32_t* d_cu, int32_t n_images, double td, int32_t T,
                   const float* d_dense_desc, const float* d_dense_score, int32_t height, int32_t width,
                   int32_t align_corners, int32_t dense_is_nhwc, const LinetrTokens& out, int32_t* d_sub2line,
-                  float* d_line_desc, void* d_ws, int64_t ws_bytes, hipStream_t st, hipStream_t back, hipEvent_t ev_cut, int cut) {
+                  float* d_line_desc, void* d_ws, int64_t ws_bytes, hipStream_t st, PipeStages* pipe) {
   if (!h) return fail(LINETR_E_ARG, "describe: null handle");
   if (h->cfg.bn_batch_stats) return fail(LINETR_E_ARG, "describe: a training-mode handle (bn_batch_stats = 1) runs linetr_forward_train only");
   if (int e = check_cu(h_cu, n_images)) return e;
@@ -1088,7 +1104,7 @@ int describe_impl(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32
   float* resp = out.resp ? out.resp : dw.resp;
   float* angle_sub = out.angle_sub ? out.angle_sub : dw.angle_sub;
   const float* nhwc_map = dense_is_nhwc ? d_dense_desc : dw.nhwc;
-  const bool use_side = !back && side_stream_ready(h, N);
+  const bool use_side = !pipe && side_stream_ready(h, N);
   if (use_side && !dense_is_nhwc) {  // NHWC transpose on the side stream, concurrent with tokenise + token MLP
     // (measured: while this grid drains, the fused word MLP -- one fat wave per SIMD -- gets most of its blocks placed
     // 140-175 us late and ends about when the transposition does; deferring the transposition behind it, or making it
@@ -1141,29 +1157,24 @@ int describe_impl(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32
   ts.cpnt = dw.cpnt; ts.cscore = dw.cscore; ts.nhwc = nhwc_map; ts.recs = d_recs; ts.sub2line_g = dw.s2l_g;
   ts.rows = rows; ts.first_pad = n_real; ts.Hc = Hc; ts.Wc = Wc; ts.align_corners = align_corners;
   ts.use_side = use_side;
-  ts.back = back; ts.ev_cut = ev_cut; ts.cut = cut;
+  ts.pipe = pipe;
+  if (int e = pipe_boundary(pipe, CUT_TOKENS, st)) return e;
   const int e = forward_core(h, st, ts, sublines, resp, angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);
   if (e && use_side) join_side_after_error(h, st);
   return e;
 }
 
-// the two streams and six events of the describe pipeline, made at the first submit: all or nothing
+// the streams and events of the describe pipeline, made at the first submit: all or nothing
 int pipe_ready(LinetrHandle* h) {
   LinetrHandle::Pipe& p = h->pipe;
-  if (p.front) return LINETR_OK;
+  if (p.stream[0]) return LINETR_OK;
   if (p.failed) return fail(LINETR_E_HIP, "describe_submit: the pipeline's streams could not be created");
-  hipStream_t s[2] = {nullptr, nullptr};
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  int lo = 0, hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // numerically lower = higher priority
-  int pf = lo, pb = lo;
-  if (const char* v = getenv("LINETR_PIPE_PRIO")) {     // TUNING (r06, to be removed): 1 = back stream high, 2 = front stream high
-    if (atoi(v) == 1) pb = hi;
-    if (atoi(v) == 2) pf = hi;
-  }
-  bool ok = hipStreamCreateWithPriority(&s[0], hipStreamNonBlocking, pf) == hipSuccess &&
-            hipStreamCreateWithPriority(&s[1], hipStreamNonBlocking, pb) == hipSuccess;
-  for (int i = 0; ok && i < 6; ++i) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+  constexpr int NS = LinetrHandle::PIPE_STREAMS, NL = LinetrHandle::PIPE_SLOTS, NE = NL * (NS + 1);
+  hipStream_t s[NS] = {};
+  hipEvent_t ev[NE] = {};
+  bool ok = true;
+  for (int i = 0; ok && i < NS; ++i) ok = hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; ok && i < NE; ++i) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
     for (hipStream_t x : s) if (x) (void)hipStreamDestroy(x);
@@ -1171,9 +1182,34 @@ int pipe_ready(LinetrHandle* h) {
     p.failed = true;
     return fail(LINETR_E_HIP, "describe_submit: the pipeline's streams could not be created");
   }
-  p.front = s[0]; p.back = s[1];
-  for (int i = 0; i < 2; ++i) { p.fork[i] = ev[3 * i]; p.front_done[i] = ev[3 * i + 1]; p.back_done[i] = ev[3 * i + 2]; }
+  for (int i = 0; i < NS; ++i) p.stream[i] = s[i];
+  for (int l = 0, k = 0; l < NL; ++l) {
+    p.fork[l] = ev[k++]; p.done[l] = ev[k++];
+    for (int c = 0; c < NS - 1; ++c) p.cut[l][c] = ev[k++];
+  }
   return LINETR_OK;
+}
+
+// How a batch is cut into stages when the caller keeps `n_slots` batches in flight.
+struct PipePlan { bool stream_per_slot = false; int n_cuts = 0; int cut[LinetrHandle::PIPE_STREAMS - 1] = {0, 0, 0}; };
+PipePlan pipe_plan(const LinetrHandle* h, int n_slots, int n_images, int N, int64_t rows) {
+  PipePlan pl;
+  if (const char* v = getenv("LINETR_PIPE_CUTS")) {     // TUNING (r06, to be removed): "slot" or a comma list of cut positions
+    if (!strcmp(v, "slot")) { pl.stream_per_slot = true; return pl; }
+    for (const char* q = v; *q && pl.n_cuts < LinetrHandle::PIPE_STREAMS - 1;) {
+      pl.cut[pl.n_cuts++] = atoi(q);
+      q = strchr(q, ',');
+      if (!q) break;
+      ++q;
+    }
+    return pl;
+  }
+  // measured on MI355X (profiles/r06_pipeline_sweep.txt): balanced stages win over "front | signature network" (the front is a third
+  // of a batch), and three stages over two; a fourth slot only lets the host run one more batch ahead
+  const int n_sig = (int)h->sig.size();
+  if (n_slots == 2 || n_sig < 5) { pl.n_cuts = 1; pl.cut[0] = n_sig >= 3 ? CUT_SIG0 + 2 : CUT_SENTENCE; }
+  else { pl.n_cuts = 2; pl.cut[0] = CUT_SIG0; pl.cut[1] = CUT_SIG0 + 3; }
+  return pl;
 }
 }  // namespace
 
@@ -1183,48 +1219,55 @@ extern "C" int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int
                                int32_t align_corners, int32_t dense_is_nhwc, LinetrTokens out, int32_t* d_sub2line,
                                float* d_line_desc, void* d_ws, int64_t ws_bytes, void* stream) {
   return describe_impl(h, d_recs, K, N, n_real, h_cu, d_cu, n_images, td, T, d_dense_desc, d_dense_score, height, width, align_corners,
-                       dense_is_nhwc, out, d_sub2line, d_line_desc, d_ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr, 0);
+                       dense_is_nhwc, out, d_sub2line, d_line_desc, d_ws, ws_bytes, (hipStream_t)stream, nullptr);
 }
+
+extern "C" int32_t linetr_pipeline_max_slots(void) { return LinetrHandle::PIPE_SLOTS; }
 
 extern "C" int linetr_describe_submit(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N, int64_t n_real,
                                       const int32_t* h_cu, const int32_t* d_cu, int32_t n_images, double td, int32_t T,
                                       const float* d_dense_desc, const float* d_dense_score, int32_t height, int32_t width,
                                       int32_t align_corners, int32_t dense_is_nhwc, LinetrTokens out, int32_t* d_sub2line,
-                                      float* d_line_desc, void* d_ws, int64_t ws_bytes, int32_t slot, void* stream) {
+                                      float* d_line_desc, void* d_ws, int64_t ws_bytes, int32_t slot, int32_t n_slots, void* stream) {
   if (!h) return fail(LINETR_E_ARG, "describe_submit: null handle");
-  if (slot < 0 || slot > 1) return fail(LINETR_E_ARG, "describe_submit: slot must be 0 or 1");
+  if (n_slots < 1 || n_slots > LinetrHandle::PIPE_SLOTS || slot < 0 || slot >= n_slots)
+    return fail(LINETR_E_ARG, "describe_submit: need 0 <= slot < n_slots <= %d", LinetrHandle::PIPE_SLOTS);
   LT_HIP(hipSetDevice(h->device));
   if (int e = pipe_ready(h)) return e;
   LinetrHandle::Pipe& p = h->pipe;
   hipStream_t st = (hipStream_t)stream;
-  // host run-ahead is bounded to the two batches in flight: the slot's previous batch (two submits ago) must have left the GPU before
-  // its workspace is handed to the device again
-  if (p.submitted[slot]) LT_HIP(hipEventSynchronize(p.back_done[slot]));
-  // fork: the front stream starts behind everything the caller has queued so far (the upload of d_recs, the producer of the maps,
-  // and -- through the caller's join of the batch before last -- the previous user of this slot's workspace)
+  // host run-ahead is bounded to the batches in flight: the slot's previous batch (n_slots submits ago) must have left the GPU
+  // before its workspace is handed to the device again
+  if (p.submitted[slot]) LT_HIP(hipEventSynchronize(p.done[slot]));
+  const PipePlan plan = pipe_plan(h, n_slots, n_images, N, n_real + n_images);
+  PipeStages stg;
+  if (plan.stream_per_slot) stg.stream[0] = p.stream[slot % LinetrHandle::PIPE_STREAMS];
+  else {
+    for (int i = 0; i < LinetrHandle::PIPE_STREAMS; ++i) stg.stream[i] = p.stream[i];
+    stg.n_cuts = plan.n_cuts;
+    for (int i = 0; i < plan.n_cuts; ++i) { stg.cut[i] = plan.cut[i]; stg.ev[i] = p.cut[slot][i]; }
+  }
+  // fork: the first stage starts behind everything the caller has queued so far (the upload of d_recs, the producer of the maps)
   LT_HIP(hipEventRecord(p.fork[slot], st));
-  LT_HIP(hipStreamWaitEvent(p.front, p.fork[slot], 0));
-  static const int cut = getenv("LINETR_PIPE_CUT") ? atoi(getenv("LINETR_PIPE_CUT")) : 0;   // TUNING (r06, to be removed)
+  LT_HIP(hipStreamWaitEvent(stg.stream[0], p.fork[slot], 0));
   const int e = describe_impl(h, d_recs, K, N, n_real, h_cu, d_cu, n_images, td, T, d_dense_desc, d_dense_score, height, width,
-                              align_corners, dense_is_nhwc, out, d_sub2line, d_line_desc, d_ws, ws_bytes, p.front, p.back,
-                              p.front_done[slot], cut);
-  if (e) {   // leave both streams idle and the slot free: a failed submit must not leave half a batch behind
-    (void)hipStreamSynchronize(p.front);
-    (void)hipStreamSynchronize(p.back);
+                              align_corners, dense_is_nhwc, out, d_sub2line, d_line_desc, d_ws, ws_bytes, stg.stream[0], &stg);
+  if (e) {   // leave the streams idle and the slot free: a failed submit must not leave half a batch behind
+    for (hipStream_t x : p.stream) (void)hipStreamSynchronize(x);
     p.submitted[slot] = false;
     return e;
   }
-  // (an empty batch queues nothing: the event then completes with whatever the back stream already holds)
-  LT_HIP(hipEventRecord(p.back_done[slot], p.back));
+  // the stream of the last stage reached (an empty batch queues nothing: the event then completes with what that stream already holds)
+  LT_HIP(hipEventRecord(p.done[slot], stg.stream[stg.next]));
   p.submitted[slot] = true;
   return LINETR_OK;
 }
 
 extern "C" int linetr_describe_join(LinetrHandle* h, int32_t slot, void* stream) {
   if (!h) return fail(LINETR_E_ARG, "describe_join: null handle");
-  if (slot < 0 || slot > 1) return fail(LINETR_E_ARG, "describe_join: slot must be 0 or 1");
-  if (!h->pipe.front || !h->pipe.submitted[slot]) return fail(LINETR_E_ARG, "describe_join: nothing was submitted to this slot");
-  LT_HIP(hipStreamWaitEvent((hipStream_t)stream, h->pipe.back_done[slot], 0));
+  if (slot < 0 || slot >= LinetrHandle::PIPE_SLOTS) return fail(LINETR_E_ARG, "describe_join: bad slot");
+  if (!h->pipe.stream[0] || !h->pipe.submitted[slot]) return fail(LINETR_E_ARG, "describe_join: nothing was submitted to this slot");
+  LT_HIP(hipStreamWaitEvent((hipStream_t)stream, h->pipe.done[slot], 0));
   return LINETR_OK;
 }
 

@@ -14,6 +14,8 @@
 // 3 VALU ops / element, hidden under the MFMAs).  LDS rows hold the PL planes of a 32-wide K chunk
 // back to back + 16 B pad: row stride 36 (PL=2) / 52 (PL=3) dwords = 4*odd, so ds_read_b128 of the
 // 8-element MFMA fragments is bank-conflict-free (same argument as lt_gemm.h).
+// The STORES into that image are conflict-free by lane assignment (r06; the r03-r05 counter passes showed 18 % of the LDS-active
+// cycles in bank conflicts, all of it from the two store streams -- `stage_row` / `stage_piece` below).
 #pragma once
 #include "lt_gemm.h"
 
@@ -175,7 +177,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
   const int nkw = g.K / 32;          // K tiles of the whole problem (row stride of the split weights)
   int nk = nkw, kbase = 0;           // K tiles of the current segment and its first K tile (stream-K: a part of a tile's K range)
 
-  const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
+  // A staging: 8 lanes per row (one 8-byte ds_write per plane each).  A 16-lane store group covers two rows; rows 1 apart sit
+  // 36 / 52 dwords apart and share four banks, rows 4 apart sit 16 banks apart: lanes 8-15 of a group take row + 4.
+  const int lrow = (tid >> 6) * 8 + (lane >> 4) + 4 * ((lane >> 3) & 1), lc4 = (tid & 7) * 4;
+  // W staging (16-byte pieces, PL * 4 per row): an 8-lane store group writing 8 consecutive pieces of the global image crosses a
+  // row's 16-byte pad when PL = 3 (12 pieces per row) and hits four banks twice.  Instead a thread's first BN * 8 / NT pieces are
+  // pieces 0-7 of a row (an 8-lane group = 128 contiguous bytes of ONE row), its last BN * 4 / NT pair the remaining pieces 8-11 of rows
+  // r and r + 4 (the pad moves those 16 banks apart).  Piece i of a thread sits a fixed number of rows behind piece i - 1 of the same
+  // kind, so the compiler keeps two base offsets and immediates (an irregular mapping spilled 16 VGPRs of the 128x256 kernel).
+  constexpr int B_ROWPCS = PL == 3 ? BN * 8 / NT : B_PCS;
+  static_assert(PL != 3 || ((BN * 8) % NT == 0 && (BN * 4) % NT == 0 && BN % 8 == 0), "W staging: whole 8-lane groups per thread slot");
+  auto stage_piece = [&](int i, int& r, int& pc) {
+    if constexpr (PL == 3) {
+      if (i < B_ROWPCS) { const int a = tid + i * NT; r = a >> 3; pc = a & 7; }
+      else { const int q = tid + (i - B_ROWPCS) * NT, gq = q >> 3, l = q & 7; r = (gq >> 2) * 8 + (gq & 3) + 4 * (l >> 2); pc = 8 + (l & 3); }
+    } else { const int q = tid + i * NT; r = q / (PL * 4); pc = q % (PL * 4); }
+  };
   static_assert(PFD >= 1 && (DB || PFD == 1) && (!PIPE || PFD <= 2), "deep prefetch needs the double-buffered LDS");
   f32x4 ra_[PFD][A_F4];   // PFD tiles in flight in registers (PFD > 1: small-M launches, where one tile's MFMAs are
   f32x4 rb_[PFD][B_PCS];  // far shorter than the L2/HBM latency and one-deep prefetch leaves the CU waiting)
@@ -191,8 +208,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
     }
 #pragma unroll
     for (int i = 0; i < B_PCS; ++i) {
-      const int p = tid + i * NT;
-      const int r = p / (PL * 4), pc = p % (PL * 4);
+      int r, pc;
+      stage_piece(i, r, pc);
       rb[i] = *reinterpret_cast<const f32x4*>(Wsp + ((int64_t)(n0 + r) * nkw + kbase + kt) * (PL * 64) + pc * 16);
     }
   };
@@ -208,8 +225,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
     }
 #pragma unroll
     for (int i = 0; i < B_PCS; ++i) {
-      const int p = tid + i * NT;
-      const int r = p / (PL * 4), pc = p % (PL * 4);
+      int r, pc;
+      stage_piece(i, r, pc);
       *reinterpret_cast<f32x4*>(Bs + (buf * BN + r) * RS + pc * 16) = rb[i];
     }
   };
@@ -330,8 +347,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
           r = r < g.M ? r : g.M - 1;
           ra[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)r * ld + kk + lc4);
         } else {
-          const int pq = tid + (u - A_F4) * NT;
-          const int r = pq / (PL * 4), pc = pq % (PL * 4);
+          int r, pc;
+          stage_piece(u - A_F4, r, pc);
           rb[u - A_F4] = *reinterpret_cast<const f32x4*>(Wsp + ((int64_t)(n0 + r) * nkw + kbase + kt) * (PL * 64) + pc * 16);
         }
       };
@@ -350,8 +367,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
 #pragma unroll
           for (int pp = 0; pp < PL; ++pp) *reinterpret_cast<u32x2*>(dst + pp * 64) = u32x2{a[pp], b[pp]};
         } else {
-          const int pq = tid + (u - A_F4) * NT;
-          const int r = pq / (PL * 4), pc = pq % (PL * 4);
+          int r, pc;
+          stage_piece(u - A_F4, r, pc);
           *reinterpret_cast<f32x4*>(Bs + (buf * BN + r) * RS + pc * 16) = rb[u - A_F4];
         }
       };

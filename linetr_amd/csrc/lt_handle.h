@@ -56,13 +56,15 @@ struct LinetrHandle {
   hipStream_t side = nullptr;
   bool side_failed = false;
   hipEvent_t ev_fork = nullptr, ev_tok = nullptr, ev_nhwc = nullptr, ev_lpos = nullptr;
-  // two-stream software pipeline of CONSECUTIVE describe calls (linetr_describe_submit / linetr_describe_join): the front of a batch
-  // (layout pass, tokeniser, token MLP, CLS pooling + tail: HBM-bound for half of its time) runs on `front`, its line-signature
-  // network (MFMA-bound, tile rounds that leave CUs empty) on `back`; batch i + 1's front overlaps batch i's back.  Slot s = i mod 2.
+  // software pipeline of CONSECUTIVE describe calls (linetr_describe_submit / linetr_describe_join): a batch is cut into stages at
+  // fixed points of the network (PipePlan), stage k of every batch runs on stream k, so stage k of batch i + 1 overlaps stage k + 1 of
+  // batch i -- HBM-bound kernels under MFMA-bound ones, and the CUs a GEMM's last tile round leaves empty under another launch.
+  // A batch in flight owns slot i mod LT_PIPE_SLOTS (its workspace + events).
+  static constexpr int PIPE_SLOTS = 4, PIPE_STREAMS = 4;
   struct Pipe {
-    hipStream_t front = nullptr, back = nullptr;
-    hipEvent_t fork[2] = {nullptr, nullptr}, front_done[2] = {nullptr, nullptr}, back_done[2] = {nullptr, nullptr};
-    bool submitted[2] = {false, false};
+    hipStream_t stream[PIPE_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork[PIPE_SLOTS] = {}, done[PIPE_SLOTS] = {}, cut[PIPE_SLOTS][PIPE_STREAMS - 1] = {};
+    bool submitted[PIPE_SLOTS] = {false, false, false, false};
     bool failed = false;
   } pipe;
   // stream-K workspace of the 128x256 GEMM (partial accumulator tiles + flags, one slot per CU; lt_gemm_split.h)

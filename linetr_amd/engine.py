@@ -371,8 +371,8 @@ class Engine:
         on the fly.  Returns (TokenBatch, line_desc [N,256]).  With want_tokens=False the dense [N,T,...] token
         tensors (pnt / mask / score / desc) are not materialised (zero-sized in the TokenBatch).
 
-        pipeline_slot = 0 / 1: linetr_describe_submit -- the batch runs on the library's front / back stream pair, overlapped with the
-        batch submitted to the other slot, and is NOT joined: the returned tensors may be read only after describe_join(slot)
+        pipeline_slot = (slot, n_slots): linetr_describe_submit -- the batch runs on the library's stage streams, overlapped with the
+        batches submitted to the other slots, and is NOT joined: the returned tensors may be read only after describe_join(slot)
         (class DescribePipeline does the bookkeeping)."""
         B = len(cu_k) - 1
         K, N, T = int(cu_k[-1]), int(cu_n[-1]), int(max_tokens)
@@ -433,10 +433,10 @@ class Engine:
             ws = self._workspace(getattr(self, "_ws_tag", None) or "desc", nbytes)
             nat.check(self._L.linetr_describe(*args, ws.data_ptr(), ws.numel(), self._stream()), self._L)
         else:
-            slot = int(pipeline_slot)
-            ws = self._workspace(f"desc_pipe{slot}", nbytes)      # one workspace per slot: two batches are in flight
-            tb.extra["dense"] = (dense_desc, dense_score)          # read by the front stream after this call returns
-            nat.check(self._L.linetr_describe_submit(*args, ws.data_ptr(), ws.numel(), slot, self._stream()), self._L)
+            slot, n_slots = (int(v) for v in pipeline_slot)
+            ws = self._workspace(f"desc_pipe{slot}", nbytes)      # one workspace per slot: n_slots batches are in flight
+            tb.extra["dense"] = (dense_desc, dense_score)          # read by the stage streams after this call returns
+            nat.check(self._L.linetr_describe_submit(*args, ws.data_ptr(), ws.numel(), slot, n_slots, self._stream()), self._L)
         return tb, ld
 
     def describe_join(self, slot: int):
@@ -974,22 +974,25 @@ class Engine:
 
 class DescribePipeline:
     """Software pipeline over CONSECUTIVE batches of Engine.describe_lines (linetr_describe_submit / linetr_describe_join, SURVEY.md
-    section 7 step 5): batch i + 1's front (layout pass, tokeniser, token MLP, pooling -- half of it HBM-bound) runs on the GPU under batch
-    i's line-signature network (MFMA-bound).  Each batch is described whole -- every GEMM sees the full batch -- and its results are
-    those of describe_lines bit for bit; what is traded is one batch of latency:
+    section 7 step 5): a batch is cut into stages that run on their own streams, so batch i + 1's front (layout pass, tokeniser, token
+    MLP, pooling -- half of it HBM-bound) runs on the GPU under batch i's line-signature network (MFMA-bound).  Each batch is described
+    whole -- every GEMM sees the full batch -- and its results are those of describe_lines bit for bit; what is traded is depth - 1
+    batches of latency:
 
-        pipe = DescribePipeline(engine)
+        pipe = DescribePipeline(engine)            # depth 2: two batches in flight
         for batch in batches:
-            done = pipe.submit(lines6, offsets, dense_desc, dense_score, ...)   # -> (TokenBatch, line_desc) of the PREVIOUS batch, or None
+            done = pipe.submit(lines6, offsets, dense_desc, dense_score, ...)   # -> (TokenBatch, line_desc) of an EARLIER batch, or None
             if done: consume(*done)
-        consume(*pipe.drain())
+        for done in pipe.drain(): consume(*done)
 
-    The tensors a submit returns belong to the previous batch and are ordered on the current stream like describe_lines' own."""
+    The tensors a submit returns are ordered on the current stream like describe_lines' own."""
 
-    def __init__(self, engine: "Engine"):
-        self.eng = engine
-        self.slot = 0
-        self.inflight = None          # (slot, (tb, ld)) of the batch submitted last, not joined yet
+    def __init__(self, engine: "Engine", depth: int = 2):
+        if not 2 <= depth <= engine._L.linetr_pipeline_max_slots():
+            raise ValueError(f"depth must be 2 .. {engine._L.linetr_pipeline_max_slots()}")
+        self.eng, self.depth = engine, int(depth)
+        self.i = 0
+        self.inflight = []            # [(slot, (tb, ld))] submitted and not joined yet, oldest first
 
     def _join(self, entry):
         slot, (tb, ld) = entry
@@ -998,11 +1001,13 @@ class DescribePipeline:
         return tb, ld
 
     def submit(self, *args, **kw):
-        cur = self.eng.describe_lines(*args, pipeline_slot=self.slot, **kw)
-        prev, self.inflight = self.inflight, (self.slot, cur)
-        self.slot ^= 1
-        return self._join(prev) if prev is not None else None
+        slot = self.i % self.depth
+        self.i += 1
+        self.inflight.append((slot, self.eng.describe_lines(*args, pipeline_slot=(slot, self.depth), **kw)))
+        return self._join(self.inflight.pop(0)) if len(self.inflight) >= self.depth else None
 
     def drain(self):
-        prev, self.inflight = self.inflight, None
-        return self._join(prev) if prev is not None else None
+        """joins and returns every batch still in flight, oldest first."""
+        out = [self._join(e) for e in self.inflight]
+        self.inflight = []
+        return out

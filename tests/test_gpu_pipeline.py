@@ -52,16 +52,16 @@ def test_pipelined_batches_equal_the_serial_calls(eng):
     for cat, off, dd, ds in batches:
         serial.append(eng.describe_lines(cat, off, dd, ds, **CFG))
     torch.cuda.synchronize()
-    for layout in ("nchw", "nhwc"):
-        pipe = DescribePipeline(eng)
+    for layout, depth in (("nchw", 2), ("nhwc", 2), ("nchw", 3), ("nhwc", 4)):
+        pipe = DescribePipeline(eng, depth)
         got = []
         for cat, off, dd, ds in batches:
             feed = dd if layout == "nchw" else dd.permute(0, 2, 3, 1).contiguous()
             done = pipe.submit(cat, off, feed, ds, dense_layout=layout, **CFG)
             if done is not None:
                 got.append(done)
-        got.append(pipe.drain())
-        assert pipe.drain() is None
+        got += pipe.drain()
+        assert pipe.drain() == []
         torch.cuda.synchronize()
         assert len(got) == len(serial)
         for a, b in zip(got, serial):
@@ -82,7 +82,7 @@ def test_pipeline_with_an_empty_batch_and_a_late_reader(eng):
     b = pipe.submit(*full, **CFG)             # "joins" the empty one
     assert b[0].N == 0 and b[1].shape[0] == 0
     c = pipe.submit(*full, **CFG)
-    d = pipe.drain()
+    (d,) = pipe.drain()
     # nothing was synchronised on the host so far: the reads below are ordered by the joins alone
     for got in (a, c, d):
         same(got, ref)
@@ -94,8 +94,8 @@ def test_submit_without_alternating_slots_is_safe(eng):
     full = batch(32, 9600)
     ref = eng.describe_lines(*full, **CFG)
     torch.cuda.synchronize()
-    r0 = eng.describe_lines(*full, pipeline_slot=0, **CFG)
-    r1 = eng.describe_lines(*full, pipeline_slot=0, **CFG)
+    r0 = eng.describe_lines(*full, pipeline_slot=(0, 2), **CFG)
+    r1 = eng.describe_lines(*full, pipeline_slot=(0, 2), **CFG)
     eng.describe_join(0)
     same(r1, ref)
     same(r0, ref)      # r0's outputs are its own tensors; batch 0 completed before batch 1 was queued
@@ -108,4 +108,7 @@ def test_join_of_an_unused_slot_is_refused():
     with pytest.raises(nat.NativeError):
         e.describe_join(1)
     with pytest.raises(nat.NativeError):
-        e.describe_join(2)
+        e.describe_join(7)
+    with pytest.raises(ValueError):
+        from linetr_amd.engine import DescribePipeline
+        DescribePipeline(e, 9)

@@ -6,7 +6,7 @@
 tag=${1:-rXX}; wl=${2:-cfg3}; shift; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-BENCH="python bench.py --workload $wl --steps 2 --warmup 1 --settle-s 0 --no-cpu-baseline --no-sub-workloads $*"
+BENCH="python bench.py --workload $wl --pipeline 0 --steps 2 --warmup 1 --settle-s 0 --no-cpu-baseline --no-sub-workloads $*"
 pass() {  # name counters...
   name=$1; shift
   timeout 600 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$name -o p -- $BENCH > gpurun_out/pmc_$name.log 2>&1
