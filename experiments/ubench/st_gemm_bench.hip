@@ -1,8 +1,8 @@
-// Ablation bench of the split-tile GEMM (csrc/lt_gemm_st.h): the same kernel with MFMAs / in-loop DMA / fragment reads /
+// Ablation bench of the split-tile GEMM (experiments/csrc/lt_gemm_st.h): the same kernel with MFMAs / in-loop DMA / fragment reads /
 // epilogue compiled out, timed with HIP events on the signature network's shapes.  Operands are ST images of random floats.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/st_gemm_bench.hip -o tools/ubench/st_gemm_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ilinetr_amd/csrc -Iinclude experiments/ubench/st_gemm_bench.hip -o experiments/ubench/st_gemm_bench
 #include "../../linetr_amd/csrc/lt_common.h"
-#include "../../linetr_amd/csrc/lt_gemm_st.h"
+#include "../csrc/lt_gemm_st.h"
 namespace lt {
 inline bool small_gemm_wins(const GemmArgs&, int) { return false; }
 inline bool split16_wins(const GemmArgs&, int) { return false; }

@@ -365,7 +365,10 @@ int linetr_superpoint_heads(LinetrHandle* h, const float* d_score_logits, const 
  *                       (measured 1.1e-6 on the descriptors vs 4.4e-7 for BF16X6), but every GEMM operand must
  *                       stay below 65504 in magnitude (fp16 range)                  (833 TF-equivalent)
  * Default: LINETR_PREC_BF16X6, overridable with the environment variable LINETR_PRECISION=f32|bf16x6|bf16x3|f16x3
- * at linetr_create time.  The signature attention and every non-GEMM stage are fp32 in all modes. */
+ * at linetr_create time.  The signature attention's two contractions (S^T = K Q^T and O^T = V^T P^T) follow the mode as well: exact
+ * fp32 MFMA in LINETR_PREC_F32, the six-product bf16 split (fp32-faithful) in the three split modes; its softmax, the token sampler,
+ * the pooling, LayerNorm / L2 normalisation and every other non-GEMM stage are fp32 in all modes.  The matcher's distance products
+ * are exact fp32 MFMA in all modes (an argmin must not inherit a split's error). */
 enum { LINETR_PREC_F32 = 0, LINETR_PREC_BF16X3 = 1, LINETR_PREC_BF16X6 = 2, LINETR_PREC_F16X3 = 3 };
 int linetr_set_precision(LinetrHandle* h, int32_t mode);
 int linetr_get_precision(const LinetrHandle* h);

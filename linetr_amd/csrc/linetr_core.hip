@@ -177,6 +177,10 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
   // pointers to their elements until the arena is uploaded)
   int bn_slot = 0;
   if (cfg->bn_batch_stats) {
+    // the statistics scratch of linetr_forward_train is sized for BN_MAX_CHANNELS channels per BatchNorm layer
+    if (std::max(std::max(e0, e1), std::max(std::max(e2, e3), 2 * D)) > lt::BN_MAX_CHANNELS)
+      return fail(LINETR_E_ARG, "create: a training-mode handle (bn_batch_stats = 1) takes keyline_encoder widths up to %d (got %d, %d, %d, %d)",
+                  lt::BN_MAX_CHANNELS, e0, e1, e2, e3);
     H->bn_g.reserve(8 + cfg->n_sig_layers); H->bn_b.reserve(8 + cfg->n_sig_layers); H->bn_c.reserve(8 + cfg->n_sig_layers);
   }
   // ---- positional encoders: 4 x (conv + BN + ReLU) + linear ------------------------------------
@@ -462,9 +466,6 @@ extern "C" void linetr_destroy(LinetrHandle* h) {
   (void)hipSetDevice(h->device);
   for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : h->event_pool) (void)hipEventDestroy(e);
-  if (h->side) (void)hipStreamDestroy(h->side);
-  for (hipEvent_t e : {h->ev_fork, h->ev_tok, h->ev_nhwc, h->ev_lpos})
-    if (e) (void)hipEventDestroy(e);
   for (hipStream_t x : h->pipe.stream)
     if (x) { (void)hipStreamSynchronize(x); (void)hipStreamDestroy(x); }
   for (int s = 0; s < LinetrHandle::PIPE_SLOTS; ++s) {

@@ -58,7 +58,10 @@ PinnedRing& staging_ring() {   // one ring per device (its events belong to the 
 
 // Scratch of the one-launch single-pair matcher (pair_match_fused_kernel): column keys, row results, arrival counter.  One slot per
 // (device, stream): launches on a stream are ordered and the kernel leaves its slot clean, so a slot is never shared by two
-// launches in flight.  Allocated and initialised once (column and row keys all-ones, counter 0); leaked at exit like the staging ring.
+// launches in flight.  A slot is initialised (column and row keys all-ones, counter 0) by memsets queued on ITS stream in front of
+// its first launch -- nothing is synchronised.  At most PAIR_SLOTS_MAX slots are kept (they are never freed: a stream handle may still
+// have work in flight); a caller beyond that, or one whose allocation fails, gets nullptr and takes the three launches.
+constexpr size_t PAIR_SLOTS_MAX = 256;
 PairSlot* pair_slot(hipStream_t st) {
   static std::mutex m;
   static std::map<std::pair<int, hipStream_t>, PairSlot> slots;
@@ -67,11 +70,13 @@ PairSlot* pair_slot(hipStream_t st) {
   std::lock_guard<std::mutex> lk(m);
   auto it = slots.find({dev, st});
   if (it != slots.end()) return &it->second;
+  if (slots.size() >= PAIR_SLOTS_MAX) return nullptr;
   char* mem = nullptr;
   const size_t bytes = (size_t)PF_MAX_K * 16 + 256;
-  if (hipMalloc((void**)&mem, bytes) != hipSuccess) return nullptr;
-  if (hipMemset(mem, 0xff, (size_t)PF_MAX_K * 16) != hipSuccess || hipMemset(mem + (size_t)PF_MAX_K * 16, 0, 256) != hipSuccess ||
-      hipDeviceSynchronize() != hipSuccess) {
+  if (hipMalloc((void**)&mem, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMemsetAsync(mem, 0xff, (size_t)PF_MAX_K * 16, st) != hipSuccess ||
+      hipMemsetAsync(mem + (size_t)PF_MAX_K * 16, 0, 256, st) != hipSuccess) {
+    (void)hipGetLastError();
     (void)hipFree(mem);
     return nullptr;
   }
@@ -82,10 +87,32 @@ PairSlot* pair_slot(hipStream_t st) {
   return &(slots[{dev, st}] = ps);
 }
 
-// does a single-pair call go to the one-launch matcher (pair_match_fused_kernel)?  LINETR_MATCH_THREE_LAUNCHES is an A/B switch read per call
+// the one-launch matcher needs up to pair_fused_lds(PF_MAX_N1, PF_MAX_N1) bytes of dynamic LDS: raised once per device; a device that
+// refuses keeps the three launches
+bool fused_pair_lds_ok() {
+  static unsigned long long done = 0, bad = 0;
+  const unsigned long long dev_bit = current_device_bit();
+  if (!(done & dev_bit)) {
+    const int want = (int)pair_fused_lds(PF_MAX_N1, PF_MAX_N1);
+    const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(pair_match_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(pair_match_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); bad |= dev_bit; }
+    done |= dev_bit;
+  }
+  return !(bad & dev_bit);
+}
+
+// does a single-pair call have the sizes of the one-launch matcher (pair_match_fused_kernel)?
 bool fused_pair_applies(int n0, int k0, int n1, int k1) {
   (void)n0;
-  return getenv("LINETR_MATCH_THREE_LAUNCHES") == nullptr && k0 > 0 && k1 > 0 && n1 <= PF_MAX_N1 && k0 <= PF_MAX_K && k1 <= PF_MAX_K;
+  return k0 > 0 && k1 > 0 && n1 <= PF_MAX_N1 && k0 <= PF_MAX_K && k1 <= PF_MAX_K;
+}
+
+// the scratch slot of a single-pair call that takes the one-launch matcher, or nullptr (sizes beyond it, no LDS, no slot): then the
+// three launches run.  Idempotent per (device, stream): linetr_match_points asks first (it skips the identity maps the one-launch
+// path never reads) and linetr_match_gathered gets the same answer.
+PairSlot* fused_pair_slot(int n0, int k0, int n1, int k1, hipStream_t st) {
+  return fused_pair_applies(n0, k0, n1, k1) && fused_pair_lds_ok() ? pair_slot(st) : nullptr;
 }
 
 // ints of argmin scratch one pair needs (layout in lt_match.h)
@@ -168,20 +195,10 @@ extern "C" int linetr_match_gathered(LinetrHandle* h, int32_t P, const int32_t* 
     // A single pair of ordinary size: ONE launch (pair_match_fused_kernel, lt_match.h).  (r03 built a one-launch form that staged
     // 8 K steps through LDS with a load round trip exposed at each and lost to the three launches, 0.10 vs 0.08 ms; this one keeps
     // whole operand rows in registers -- two exposed round trips in all -- and combines the column argmin with one 64-bit atomicMin.)
-    if (P == 1 && fused_pair_applies(pd[0].n0, pd[0].k0, pd[0].n1, pd[0].k1)) {
-      PairSlot* ps_ = pair_slot(st);
-      if (!ps_) return fail(LINETR_E_HIP, "match: scratch allocation for the single-pair matcher failed");
+    PairSlot* ps_ = P == 1 ? fused_pair_slot(pd[0].n0, pd[0].k0, pd[0].n1, pd[0].k1, st) : nullptr;
+    if (ps_) {    // (no slot / no LDS: the three launches below)
       const PairDesc& d = pd[0];
       const size_t lds = pair_fused_lds(d.n1, d.k1);
-      static unsigned long long attr_done = 0;
-      const unsigned long long dev_bit = current_device_bit();
-      if (!(attr_done & dev_bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_match_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)pair_fused_lds(PF_MAX_N1, PF_MAX_N1));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_match_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)pair_fused_lds(PF_MAX_N1, PF_MAX_N1));
-        attr_done |= dev_bit;
-      }
       ProfScope ps(h, st, "pair_match_fused", flops, 4.0 * ((double)(d.n0 + d.n1) * D + (double)d.k0 * d.k1));
       // one sub-line per key-line on both sides (known from the counts alone: the maps are onto): Dk = D, columns split over two
       // blocks when a wave would otherwise multiply two tiles
@@ -240,7 +257,7 @@ extern "C" int linetr_match_points(LinetrHandle* h, const float* d0_cn, int32_t 
   float* r1 = (float*)base; base += align_up((int64_t)std::max(n1, 1) * D * 4, 256);
   int* id0 = (int*)base; base += align_up((int64_t)n0 * 4, 256);
   int* id1 = (int*)base; base += align_up((int64_t)std::max(n1, 1) * 4, 256);
-  if (!fused_pair_applies(n0, n0, n1, n1)) {      // (the one-launch identity path never reads the maps: no upload on the latency path)
+  if (!fused_pair_slot(n0, n0, n1, n1, st)) {      // (the one-launch identity path never reads the maps: no upload on the latency path)
     int slot = 0;
     const int m = std::max(n0, n1);
     int* iota = (int*)staging_ring().acquire((size_t)m * sizeof(int), &slot);

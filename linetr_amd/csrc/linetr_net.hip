@@ -7,8 +7,9 @@
 #include "lt_gemm.h"
 #include "lt_gemm_split.h"
 #include "lt_gemm_split16.h"
-#include "lt_gemm_st.h"
+#include "lt_st_image.h"
 #ifdef LINETR_EXPERIMENTS
+#include "lt_gemm_st.h"
 #include "lt_gemm_ro.h"
 #include "lt_gemm_chain.h"
 #endif
@@ -29,34 +30,6 @@
 using namespace lt;
 
 namespace {
-
-// Side stream (NHWC transposition / line-position MLP next to the token-MLP GEMMs): OFF by default since r02.
-// Measured on MI355X at cfg3: whenever the host runs a few steps ahead of the GPU -- the normal state of the batched
-// path -- roughly every third step lost ~1 ms to the interplay of the two hardware queues (per-step HIP events:
-// 2.84 ms median, 3.8-3.9 ms on the slow steps, mean 3.0); with everything on one stream every step takes 2.82 ms
-// (8.9 M vs 8.4 M descriptors/s; NCHW-fed 8.27 M vs 7.94 M).  LINETR_SIDE_STREAM=1 turns the fork back on for
-// experiments; it still only applies to large batches (for a single pair the event waits cost more than they hide).
-bool side_stream_ready(LinetrHandle* h, int n_sublines) {
-  static const bool on = LT_XENV("LINETR_SIDE_STREAM") != nullptr && LT_XENV("LINETR_NO_SIDE_STREAM") == nullptr;
-  if (!on || n_sublines < 8192) return false;
-  if (h->side) return true;
-  if (h->side_failed) return false;
-  // create into locals and publish only when all five objects exist: a half-built set must never be used
-  hipStream_t s = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool ok = hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
-  for (int i = 0; ok && i < 4; ++i) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
-  if (!ok) {
-    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
-    if (s) (void)hipStreamDestroy(s);
-    (void)hipGetLastError();
-    h->side_failed = true;
-    return false;
-  }
-  h->side = s;
-  h->ev_fork = ev[0]; h->ev_tok = ev[1]; h->ev_nhwc = ev[2]; h->ev_lpos = ev[3];
-  return true;
-}
 
 const char* gemm_class_name(const GemmArgs& g, int groups, const char* kind) {
   const char* tile;
@@ -508,7 +481,6 @@ struct TokenStage {            // how the token stage (word MLP + CLS pooling) i
   int64_t rows = 0;            // rows of the word-MLP GEMMs (N*T dense, n_real + n_images fused)
   int64_t first_pad = 0;
   int Hc = 0, Wc = 0, align_corners = 0;
-  bool use_side = false;       // h->side carries the NHWC transpose (ev_nhwc) and may take the line-position MLP
   const BnTrain* bn = nullptr; // training-time forward (linetr_forward_train): BatchNorm on batch statistics, convolutions unfolded
   PipeStages* pipe = nullptr;  // pipelined call (linetr_describe_submit): where the launch sequence moves on to the next stream
 };
@@ -599,7 +571,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   // experiment (LINETR_PAIRNET=1; measured and not shipped): the whole signature network of a single pair as ONE
   // persistent launch (lt_pairnet.h); its arrival counters are zeroed here, far ahead of it on the stream
 #ifdef LINETR_EXPERIMENTS
-  const bool pairnet = !ts.use_side && pairnet_fits(h, n_images, N, h_cu);
+  const bool pairnet = pairnet_fits(h, n_images, N, h_cu);
   if (pairnet && (e = pairnet_prepare(h, st, N, w.pn))) return e;
 #endif
   // ---- word positional encoder up to the last ReLU (a4); its final linear layer is applied after pooling
@@ -637,31 +609,32 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
       const int64_t o = off; off += 2 * C;
       return bn_train_layer(st, bt, zbuf, r, C, C, h->bn_g[layer], h->bn_b[layer], o);
     };
+#define LT_BN(layer, zbuf, r, C) do { if ((e = bn(layer, zbuf, r, C))) return e; } while (0)
     hipLaunchKernelGGL(word_mlp1_kernel<false>, dim3((unsigned)cdiv((int)(rows * 8), 256)), dim3(256), 0, st, ts.pnt, ts.score, rows,
                        cx, cy, scale, h->wW1, h->wb1, w.a1);
     LT_LAUNCH_CHECK();
-    bn(0, w.a1, rows, e0);
+    LT_BN(0, w.a1, rows, e0);
     if ((e = run_gemm(h, st, w.a1, e0, nullptr, 0, 0, h->wW2, h->wb2, nullptr, 0, w.a2, e1, (int)rows, e1, e0, ACT_NONE))) return e;
-    bn(1, w.a2, rows, e1);
+    LT_BN(1, w.a2, rows, e1);
     if ((e = run_gemm(h, st, w.a2, e1, nullptr, 0, 0, h->wW3, h->wb3, nullptr, 0, w.a3, e2, (int)rows, e2, e1, ACT_NONE))) return e;
-    bn(2, w.a3, rows, e2);
+    LT_BN(2, w.a3, rows, e2);
     if ((e = run_gemm(h, st, w.a3, e2, nullptr, 0, 0, h->wW4, h->wb4, nullptr, 0, w.a4, e3, (int)rows, e3, e2, ACT_NONE))) return e;
-    bn(3, w.a4, rows, e3);
+    LT_BN(3, w.a4, rows, e3);
     hipLaunchKernelGGL(line_mlp1_kernel<false>, dim3(cdiv(N * 8, 256)), dim3(256), 0, st, sublines, resp, angle_sub, N, cx, cy, scale,
                        h->lW1, h->lb1, w.l1);
     LT_LAUNCH_CHECK();
-    bn(4, w.l1, N, e0);
+    LT_BN(4, w.l1, N, e0);
     if ((e = run_gemm(h, st, w.l1, e0, nullptr, 0, 0, h->lW2, h->lb2, nullptr, 0, w.l2, e1, N, e1, e0, ACT_NONE))) return e;
-    bn(5, w.l2, N, e1);
+    LT_BN(5, w.l2, N, e1);
     if ((e = run_gemm(h, st, w.l2, e1, nullptr, 0, 0, h->lW3, h->lb3, nullptr, 0, w.l3, e2, N, e2, e1, ACT_NONE))) return e;
-    bn(6, w.l3, N, e2);
+    LT_BN(6, w.l3, N, e2);
     if ((e = run_gemm(h, st, w.l3, e2, nullptr, 0, 0, h->lW4, h->lb4, nullptr, 0, w.l4, e3, N, e3, e2, ACT_NONE))) return e;
-    bn(7, w.l4, N, e3);
-    LT_LAUNCH_CHECK();
+    LT_BN(7, w.l4, N, e3);
+#undef LT_BN
     line_done = true;
   } else
   // both encoders in ONE launch: side by side for a small batch, one after the other inside every persistent block for a large one
-  if (tok_mlp && line_mlp && !ts.use_side && rows > 0 && N > 0 && !LT_XENV("LINETR_NO_DUAL_MLP")) {
+  if (tok_mlp && line_mlp && rows > 0 && N > 0 && !LT_XENV("LINETR_NO_DUAL_MLP")) {
     ProfScope ps(h, st, "pos_mlp_dual_bf16x6", 2.0 * rows * (3 * e0 + e0 * e1 + e1 * e2 + e2 * e3) + 2.0 * N * (5 * e0 + e0 * e1 + e1 * e2 + e2 * e3),
                  (double)rows * (12 + 4 * e3) + (double)N * (28 + 4 * e3));
     if ((e = tok_mlp_launch_dual(amw, aml, st))) return e;
@@ -691,8 +664,8 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   }
   if ((e = run_gemm(h, st, w.a3, e2, nullptr, 0, 0, h->wW4, h->wb4, nullptr, 0, w.a4, e3, (int)rows, e3, e2, ACT_RELU))) return e;
   }
-  // ---- line positional encoder: independent of everything above -> side stream when available
-  hipStream_t ls = ts.use_side ? h->side : st;
+  // ---- line positional encoder
+  hipStream_t ls = st;
   if (line_done) {
   } else if (line_mlp) {   // layers 1-4 in one kernel, as for the word encoder
     ProfScope ps(h, ls, "line_mlp_bf16x6", 2.0 * N * (5 * e0 + e0 * e1 + e1 * e2 + e2 * e3), (double)N * (28 + 4 * e3));
@@ -717,10 +690,6 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   if ((e = run_gemm(h, ls, w.l3, e2, nullptr, 0, 0, h->lW4, h->lb4, nullptr, 0, w.l4, e3, N, e3, e2, ACT_RELU))) return e;
   }
   if ((e = run_gemm(h, ls, w.l4, e3, nullptr, 0, 0, h->lW5, h->lb5, nullptr, 0, w.lpos, D, N, D, e3, ACT_NONE))) return e;
-  if (ts.use_side) {
-    LT_HIP(hipEventRecord(h->ev_lpos, h->side));
-    if (ts.cpnt) LT_HIP(hipStreamWaitEvent(st, h->ev_nhwc, 0));   // the pooling kernel samples the NHWC copy
-  }
   if ((e = pipe_boundary(ts.pipe, CUT_MLP, st))) return e;
   // ---- CLS-row attention pooling + value/last-MLP projection
   if (ts.cpnt) {
@@ -772,7 +741,6 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
   float *z = w.zA, *zn = w.zB;
 #ifdef LINETR_EXPERIMENTS
   if (chain) {
-    if (ts.use_side) LT_HIP(hipStreamWaitEvent(st, h->ev_lpos, 0));
     // [fc + LN] -> [w_1, GELU] -> [w_2 + residual + LN (+ line position)] -> [q/k/v of signature layer 0]: one launch
     ChainBuilder cb(h);
     NormSpec ns1; ns1.mode = 1; ns1.gamma = h->ln1g; ns1.beta = h->ln1b; ns1.eps = 1e-6f;
@@ -790,7 +758,6 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     if ((e = run_gemm_norm(h, st, w.att, D, nullptr, 0, 0, h->Wfc, h->bfc, nullptr, w.fc, w.o, N, D, ns))) return e;
   }
   if ((e = run_gemm(h, st, w.o, D, nullptr, 0, 0, h->Wf1, h->bf1, nullptr, 0, w.f1, c.d_inner, N, c.d_inner, D, ACT_GELU))) return e;
-  if (ts.use_side) LT_HIP(hipStreamWaitEvent(st, h->ev_lpos, 0));
   {  // sentence = line_pos + LN(w_2(gelu(w_1 o)) + o)  (line_attention.py:79-83, line_transformer.py:128)
     NormSpec ns; ns.mode = 1; ns.gamma = h->ln2g; ns.beta = h->ln2b; ns.add2 = w.lpos; ns.eps = 1e-6f;
     if ((e = run_gemm_norm(h, st, w.f1, c.d_inner, nullptr, 0, 0, h->Wf2, h->bf2, w.o, w.f2, w.zA, N, c.d_inner, ns))) return e;
@@ -840,7 +807,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
         LT_LAUNCH_CHECK();
       }
       if ((e = run_gemm(h, st, zc, ldz, w.msgp, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ts.bn ? ACT_NONE : ACT_RELU))) return e;
-      if (ts.bn) bn_train_layer(st, *ts.bn, w.hid, N, 2 * D, 2 * D, h->bn_g[8 + l], h->bn_b[8 + l], sig_bn_off + (int64_t)l * 4 * D);
+      if (ts.bn && (e = bn_train_layer(st, *ts.bn, w.hid, N, 2 * D, 2 * D, h->bn_g[8 + l], h->bn_b[8 + l], sig_bn_off + (int64_t)l * 4 * D))) return e;
       if (l + 1 == h->sig.size()) break;
       if ((e = run_gemm(h, st, zc, ldz, w.hid, 2 * D, D, S.Wnext, S.bnext, nullptr, 0, zq, 4 * D, N, 4 * D, 3 * D, ACT_NONE))) return e;
       zc = zq; ldz = 4 * D; qkv_in = zq + D; ldq = 4 * D;
@@ -859,11 +826,11 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
       static unsigned long long attr_done = 0;
       const unsigned long long dev_bit = current_device_bit();
       if (!(attr_done & dev_bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sig_qkv_attn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, FQA_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sig_qkv_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FQA_LDS);
         attr_done |= dev_bit;
       }
       ProfScope ps(h, st, "sig_qkv_attn_bf16x6", fl, (double)N * D * 8);
-      hipLaunchKernelGGL(sig_qkv_attn_kernel<0>, dim3(n_images, HEADS), dim3(512), FQA_LDS, st, z, h->split_arena + it->second.offst,
+      hipLaunchKernelGGL(sig_qkv_attn_kernel, dim3(n_images, HEADS), dim3(512), FQA_LDS, st, z, h->split_arena + it->second.offst,
                          S.bqkv, cu_dev, w.msgp);
       LT_LAUNCH_CHECK();
     } else {
@@ -926,7 +893,7 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     }
 #endif
     if ((e = run_gemm(h, st, z, D, w.msgp, D, D, S.W1, S.b1, nullptr, 0, w.hid, 2 * D, N, 2 * D, 2 * D, ts.bn ? ACT_NONE : ACT_RELU))) return e;
-    if (ts.bn) bn_train_layer(st, *ts.bn, w.hid, N, 2 * D, 2 * D, h->bn_g[8 + l], h->bn_b[8 + l], sig_bn_off + (int64_t)l * 4 * D);
+    if (ts.bn && (e = bn_train_layer(st, *ts.bn, w.hid, N, 2 * D, 2 * D, h->bn_g[8 + l], h->bn_b[8 + l], sig_bn_off + (int64_t)l * 4 * D))) return e;
     if (l + 1 == h->sig.size()) break;   // the last layer's second MLP GEMM is folded into the final projection below
     if ((e = run_gemm(h, st, w.hid, 2 * D, nullptr, 0, 0, S.W2, S.b2, z, D, zn, D, N, D, 2 * D, ACT_NONE))) return e;
     std::swap(z, zn);
@@ -941,13 +908,6 @@ int forward_core(LinetrHandle* h, hipStream_t st, const TokenStage& ts, const fl
     if ((e = run_gemm_norm(h, st, zc, ldz, w.hid, 2 * D, D, h->Wfin2, h->bfin2, nullptr, zn, d_line_desc, N, 3 * D, l2))) return e;
   }
   return LINETR_OK;
-}
-
-// an error return between fork and join must not leave work on the side stream un-ordered with the caller's stream
-void join_side_after_error(LinetrHandle* h, hipStream_t st) {
-  if (!h->side) return;
-  if (hipEventRecord(h->ev_lpos, h->side) == hipSuccess) (void)hipStreamWaitEvent(st, h->ev_lpos, 0);
-  else (void)hipStreamSynchronize(h->side);
 }
 
 int check_cu(const int32_t* h_cu, int n_images) {
@@ -981,14 +941,7 @@ extern "C" int linetr_forward(LinetrHandle* h, const LinetrTokens* tok, const in
   }
   TokenStage ts;
   ts.pnt = tok->pnt; ts.score = tok->score; ts.desc = tok->desc; ts.rows = (int64_t)N * T;
-  if (side_stream_ready(h, N)) {   // fork: the side stream may only start after everything already queued on `st`
-    ts.use_side = true;
-    LT_HIP(hipEventRecord(h->ev_fork, st));
-    LT_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-  }
-  const int e = forward_core(h, st, ts, tok->sublines, tok->resp, tok->angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);
-  if (e && ts.use_side) join_side_after_error(h, st);
-  return e;
+  return forward_core(h, st, ts, tok->sublines, tok->resp, tok->angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);
 }
 
 // Training-time forward (train.py:127,163-164): linetr_forward's dense token path with BatchNorm on batch
@@ -1001,7 +954,7 @@ extern "C" int64_t linetr_bn_stats_floats(const LinetrHandle* h) {
 
 extern "C" int64_t linetr_forward_train_workspace_bytes(const LinetrHandle* h, int32_t N, int32_t T) {
   if (!h) return -1;
-  return linetr_forward_workspace_bytes(h, N, T) + (int64_t)BN_MAX_BLOCKS * 2 * 512 * 8 + 2 * 512 * 4 + 512;
+  return linetr_forward_workspace_bytes(h, N, T) + (int64_t)BN_MAX_BLOCKS * 2 * BN_MAX_CHANNELS * 8 + 2 * BN_MAX_CHANNELS * 4 + 512;
 }
 
 extern "C" int linetr_forward_train(LinetrHandle* h, const LinetrTokens* tok, const int32_t* h_cu, const int32_t* d_cu, int32_t n_images,
@@ -1024,7 +977,7 @@ extern "C" int linetr_forward_train(LinetrHandle* h, const LinetrTokens* tok, co
   BnTrain bt;
   bt.running = d_bn_running; bt.batch = d_bn_batch; bt.momentum = momentum;
   bt.partial = (double*)((char*)d_ws + align_up(w.total, 256));
-  bt.affine = (float*)((char*)bt.partial + (int64_t)BN_MAX_BLOCKS * 2 * 512 * 8);
+  bt.affine = (float*)((char*)bt.partial + (int64_t)BN_MAX_BLOCKS * 2 * BN_MAX_CHANNELS * 8);
   const int* cu_dev = d_cu;
   if (!cu_dev) {
     LT_HIP(hipMemcpyAsync(w.cu, h_cu, (n_images + 1) * sizeof(int), hipMemcpyHostToDevice, st));
@@ -1104,18 +1057,6 @@ int describe_impl(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32
   float* resp = out.resp ? out.resp : dw.resp;
   float* angle_sub = out.angle_sub ? out.angle_sub : dw.angle_sub;
   const float* nhwc_map = dense_is_nhwc ? d_dense_desc : dw.nhwc;
-  const bool use_side = !pipe && side_stream_ready(h, N);
-  if (use_side && !dense_is_nhwc) {  // NHWC transpose on the side stream, concurrent with tokenise + token MLP
-    // (measured: while this grid drains, the fused word MLP -- one fat wave per SIMD -- gets most of its blocks placed
-    // 140-175 us late and ends about when the transposition does; deferring the transposition behind it, or making it
-    // persistent with <= 2 blocks per CU, moves the step by < 1 %, so the plain launch stays)
-    LT_HIP(hipEventRecord(h->ev_fork, st));
-    LT_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    ProfScope ps(h, h->side, "nchw_to_nhwc", 0, 2.0 * n_images * P * D * 4);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(P, 64), D / 64, n_images), dim3(256), 0, h->side, d_dense_desc,
-                       dw.nhwc, D, P);
-    LT_LAUNCH_CHECK();
-  }
   {
     ProfScope ps(h, st, "line_fill", 0, (double)K * 80 + (double)N * 8);
     hipLaunchKernelGGL(line_fill_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, d_recs, K, (double)width - 0.6,
@@ -1131,22 +1072,13 @@ int describe_impl(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32
                        n_images, (int64_t)n_real, out.mat, k2s);
     LT_LAUNCH_CHECK();
   }
-  if (use_side) {
-    if (dense_is_nhwc) {  // nothing to transpose: the fork only carries the line-position MLP
-      LT_HIP(hipEventRecord(h->ev_fork, st));
-      LT_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    }
-    LT_HIP(hipEventRecord(h->ev_nhwc, h->side));   // joined by forward_core before the pooling kernel
-    LT_HIP(hipEventRecord(h->ev_tok, st));         // sub-lines / resp / angles exist: the line-position MLP may start
-    LT_HIP(hipStreamWaitEvent(h->side, h->ev_tok, 0));
-  } else if (!dense_is_nhwc) {
+  if (!dense_is_nhwc) {
     ProfScope ps(h, st, "nchw_to_nhwc", 0, 2.0 * n_images * P * D * 4);
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(P, 64), D / 64, n_images), dim3(256), 0, st, d_dense_desc,
                        dw.nhwc, D, P);
     LT_LAUNCH_CHECK();
   }
   if (out.desc) {  // the reference's dense tensor was asked for as well
-    if (use_side) LT_HIP(hipStreamWaitEvent(st, h->ev_nhwc, 0));
     const int64_t ntok = (int64_t)N * T;
     ProfScope ps(h, st, "sample_desc", 0, (double)ntok * D * 4 * 2);
     hipLaunchKernelGGL(sample_desc_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, st, out.pnt, dw.s2l_g, d_recs,
@@ -1156,12 +1088,9 @@ int describe_impl(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32
   TokenStage ts;
   ts.cpnt = dw.cpnt; ts.cscore = dw.cscore; ts.nhwc = nhwc_map; ts.recs = d_recs; ts.sub2line_g = dw.s2l_g;
   ts.rows = rows; ts.first_pad = n_real; ts.Hc = Hc; ts.Wc = Wc; ts.align_corners = align_corners;
-  ts.use_side = use_side;
   ts.pipe = pipe;
   if (int e = pipe_boundary(pipe, CUT_TOKENS, st)) return e;
-  const int e = forward_core(h, st, ts, sublines, resp, angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);
-  if (e && use_side) join_side_after_error(h, st);
-  return e;
+  return forward_core(h, st, ts, sublines, resp, angle_sub, h_cu, cu_dev, n_images, N, T, d_line_desc, w);
 }
 
 // the streams and events of the describe pipeline, made at the first submit: all or nothing
@@ -1191,19 +1120,9 @@ int pipe_ready(LinetrHandle* h) {
 }
 
 // How a batch is cut into stages when the caller keeps `n_slots` batches in flight.
-struct PipePlan { bool stream_per_slot = false; int n_cuts = 0; int cut[LinetrHandle::PIPE_STREAMS - 1] = {0, 0, 0}; };
+struct PipePlan { int n_cuts = 0; int cut[LinetrHandle::PIPE_STREAMS - 1] = {0, 0, 0}; };
 PipePlan pipe_plan(const LinetrHandle* h, int n_slots, int n_images, int N, int64_t rows) {
   PipePlan pl;
-  if (const char* v = getenv("LINETR_PIPE_CUTS")) {     // TUNING (r06, to be removed): "slot" or a comma list of cut positions
-    if (!strcmp(v, "slot")) { pl.stream_per_slot = true; return pl; }
-    for (const char* q = v; *q && pl.n_cuts < LinetrHandle::PIPE_STREAMS - 1;) {
-      pl.cut[pl.n_cuts++] = atoi(q);
-      q = strchr(q, ',');
-      if (!q) break;
-      ++q;
-    }
-    return pl;
-  }
   // measured on MI355X (profiles/r06_pipeline_sweep.txt): balanced stages win over "front | signature network" (the front is a third
   // of a batch), and three stages over two; a fourth slot only lets the host run one more batch ahead
   const int n_sig = (int)h->sig.size();
@@ -1241,12 +1160,9 @@ extern "C" int linetr_describe_submit(LinetrHandle* h, const LinetrLineRec* d_re
   if (p.submitted[slot]) LT_HIP(hipEventSynchronize(p.done[slot]));
   const PipePlan plan = pipe_plan(h, n_slots, n_images, N, n_real + n_images);
   PipeStages stg;
-  if (plan.stream_per_slot) stg.stream[0] = p.stream[slot % LinetrHandle::PIPE_STREAMS];
-  else {
-    for (int i = 0; i < LinetrHandle::PIPE_STREAMS; ++i) stg.stream[i] = p.stream[i];
-    stg.n_cuts = plan.n_cuts;
-    for (int i = 0; i < plan.n_cuts; ++i) { stg.cut[i] = plan.cut[i]; stg.ev[i] = p.cut[slot][i]; }
-  }
+  for (int i = 0; i < LinetrHandle::PIPE_STREAMS; ++i) stg.stream[i] = p.stream[i];
+  stg.n_cuts = plan.n_cuts;
+  for (int i = 0; i < plan.n_cuts; ++i) { stg.cut[i] = plan.cut[i]; stg.ev[i] = p.cut[slot][i]; }
   // fork: the first stage starts behind everything the caller has queued so far (the upload of d_recs, the producer of the maps)
   LT_HIP(hipEventRecord(p.fork[slot], st));
   LT_HIP(hipStreamWaitEvent(stg.stream[0], p.fork[slot], 0));
@@ -1376,10 +1292,3 @@ extern "C" int linetr_debug_gemm_st(LinetrHandle* h, const void* d_A1, int32_t K
 }
 
 #endif  // LINETR_EXPERIMENTS
-#ifdef LT_MLP_STAMPS
-extern "C" int linetr_debug_mlp_stamps(unsigned long long* out) {   // debug build only (tools/mlp_stamps.py)
-  LT_HIP(hipDeviceSynchronize());
-  LT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(lt::lt_mlp_stamps), sizeof(unsigned long long) * 1024 * 16));
-  return LINETR_OK;
-}
-#endif

@@ -6,7 +6,7 @@
 // reads straight back.  Here a block of eight waves owns one (image, head):
 //   1. projection, computed TRANSPOSED (weights = MFMA A operand): wave w owns rows 32 w .. 32 w + 31 of the image and all
 //      192 output channels of the head (q | k | v: six 32 x 32 accumulator tiles).  A K step's operands -- the weight panel
-//      (192 rows x 16 k x 3 planes = 18 KiB, pre-split in the split-tile image of lt_gemm_st.h) and the image's activations
+//      (192 rows x 16 k x 3 planes = 18 KiB, pre-split in the split-tile image of lt_st_image.h) and the image's activations
 //      (256 rows x 16 fp32 = 16 KiB, gathered row by row) -- travel by LDS-DMA into a ring of four slots with counted vmcnt
 //      waits, exactly like the ST GEMM; a lane reads the 8 fp32 of ITS OWN row back and splits them into the three bf16
 //      planes on the fly (no ordinary global load in the loop, no staging registers).
@@ -18,7 +18,7 @@
 //      accumulator registers, V^T fragments by transposing LDS reads; the message leaves as fp32 rows.
 // q, k, v never reach HBM; one launch per layer instead of two.  Images of up to 256 sub-lines (eight waves).
 #pragma once
-#include "lt_gemm_st.h"
+#include "lt_st_image.h"
 #include "lt_model.h"
 
 namespace lt {
@@ -48,15 +48,6 @@ __device__ __forceinline__ void fr_wait(u32x2 (&o)[3][2]) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0][0]), "+v"(o[0][1]), "+v"(o[1][0]), "+v"(o[1][1]), "+v"(o[2][0]), "+v"(o[2][1]) : : "memory");
 }
 
-// DBG (tools/ubench/fqa_bench.hip only): 1 no projection MFMAs, 2 no attention phase, 4 projection without its barriers / DMA
-// waits (wrong data, timing only), 8 no K / V staging + conversion, 16 phase time stamps (wall_clock64, 100 MHz) of wave 0
-#ifdef LT_FQA_STAMPS
-__device__ unsigned long long fqa_stamps[512][8];
-#define FQA_STAMP(k) do { if ((DBG & 16) && tid == 0) fqa_stamps[(img * 4 + head) & 511][k] = wall_clock64(); } while (0)
-#else
-#define FQA_STAMP(k) do { } while (0)
-#endif
-template <int DBG = 0>
 __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restrict__ z /*[N][256]*/,
                                                            const unsigned char* __restrict__ Wst /*ST image of Wqkv [768][256]*/,
                                                            const float* __restrict__ bqkv /*[768]*/,
@@ -71,7 +62,6 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
   const int q = wave * 32 + lq;                          // row of the image this lane owns (query AND key)
   const bool wave_active = wave * 32 < Ni;               // wave-uniform
   constexpr int RBW = 3 * D / 16, NK = D / 16;           // 48 row blocks of the weight image, 16 K steps
-  FQA_STAMP(0);
 
   // ---- 1. projection --------------------------------------------------------------------------------------------
   // Ring slot of a K step (34 KiB): [weights: (q | k | v) x 4 row blocks x 3 planes x 512 B = 18 KiB][activations: 256 rows x 16
@@ -130,7 +120,6 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
   wait_dma(2);                                             // steps 0 and 1 landed
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  FQA_STAMP(1);
 
   const int lfrag = ((lane >> 4) & 1) * ST_RB + (lane >> 5) * 256 + (lane & 15) * 16;
   const int zoff = FQA_W_BYTES + (wave * 32 + lq) * 64 + h2 * 32;
@@ -170,7 +159,7 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
       const int i = m / 6, t = m % 6;
       bf16x8 (&wc)[3] = (i & 1) ? wfB : wfA;
       bf16x8 (&wn)[3] = (i & 1) ? wfA : wfB;
-      if (!(DBG & 1)) acc[i] = mfma_split<0>(wc[TW[t]], zc[TA[t]], acc[i]);
+      acc[i] = mfma_split<0>(wc[TW[t]], zc[TA[t]], acc[i]);
       if (t < 3) {                                         // next weight fragments: n-tile i+1 of this step, or n-tile 0 of the next
         if (i < 5) read_w(s, i + 1, t, wn);
         else read_w(s + 1, 0, t, wn);                      // (past the last step: reads a slot that is never used; harmless)
@@ -182,7 +171,7 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
       __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (more && !(DBG & 4)) {
+    if (more) {
       wait_dma(s + 3 < NK ? 1 : 0);                        // step s+2 has landed; step s+3 may stay in flight
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -195,7 +184,6 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
     step(s + 1, zfB, zfA);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  FQA_STAMP(2);
 
   // ---- 2. Q to B fragments (registers), K / V pieces (registers until their half is staged) ----------------------------
   // piece g of accumulator tile i = channels 32 (i & 1) + 16 g + 8 h2 .. + 8 of this lane's row, after the half-wave swap
@@ -242,8 +230,6 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
       }
     }
   };
-
-  FQA_STAMP(3);
   // ---- 3. attention over two halves of 128 keys ----------------------------------------------------------------------
   f32x16 o0, o1;
 #pragma unroll
@@ -345,15 +331,14 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
   for (int half = 0; half < 2; ++half) {
     if (half * FQA_KEYS >= Ni) break;                      // block-uniform
     __syncthreads();                                       // the ring / the previous half is dead
-    if ((wave >> 2) == half && wave_active && !(DBG & 8)) stage_kv();
+    if ((wave >> 2) == half && wave_active) stage_kv();
     __syncthreads();
-    if (!wave_active || (DBG & 2)) continue;
+    if (!wave_active) continue;
     const int k0 = half * FQA_KEYS;
     if (k0 < Ni) chunk(k0, std::integral_constant<int, 0>{});
     if (k0 + 32 < Ni) chunk(k0 + 32, std::integral_constant<int, 32>{});
     if (k0 + 64 < Ni) chunk(k0 + 64, std::integral_constant<int, 64>{});
     if (k0 + 96 < Ni) chunk(k0 + 96, std::integral_constant<int, 96>{});
-    FQA_STAMP(4 + half);
   }
 
   // ---- 4. epilogue: O^T / l -> 8 consecutive d per lane -> dwordx4 stores ------------------------------------------------
@@ -372,7 +357,6 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
       }
     }
   }
-  FQA_STAMP(6);
 }
 
 }  // namespace lt

@@ -16,6 +16,7 @@
 namespace lt {
 
 constexpr int BN_MAX_BLOCKS = 512;     // row chunks of bn_partial_kernel (two per CU)
+// (BN_MAX_CHANNELS, lt_handle.h: the widest BatchNorm layer the statistics scratch is sized for)
 
 // what a training-time forward hands down to forward_core (linetr_forward_train)
 struct BnTrain {
@@ -102,12 +103,16 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(float* __restrict__ 
 inline int bn_train_layer(hipStream_t st, const BnTrain& bt, float* z, int64_t rows, int C, int ld, const float* gamma,
                           const float* beta, int64_t off) {
   if (rows <= 0) return 0;
+  if (C > BN_MAX_CHANNELS || C % 4) return fail(LINETR_E_ARG, "BatchNorm(train): %d channels (the statistics scratch holds %d, multiples of 4)", C, BN_MAX_CHANNELS);
   const int nb = (int)std::min<int64_t>(BN_MAX_BLOCKS, std::max<int64_t>(1, rows / 64));
   hipLaunchKernelGGL(bn_partial_kernel, dim3(nb), dim3(256), 0, st, (const float*)z, rows, C, ld, bt.partial);
+  LT_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)bt.partial, nb, C, rows, gamma, beta,
                      1e-5f, bt.momentum, bt.running + off, bt.batch ? bt.batch + off : nullptr, bt.affine);
+  LT_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_apply_relu_kernel, dim3((unsigned)((rows * (C / 4) + 255) / 256)), dim3(256), 0, st, z, rows, C, ld,
                      (const float*)bt.affine);
+  LT_LAUNCH_CHECK();
   return 0;
 }
 

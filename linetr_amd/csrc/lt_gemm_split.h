@@ -36,14 +36,6 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <int PL, int FMT = 0>
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&out)[PL]) {
   float r0 = x0, r1 = x1;
-#ifdef LT_ABLATE_SPLIT   // timing experiment only (wrong numerics): one conversion, no remainders -- the VALU cost a pre-split operand would save
-  {
-    const bf16x2 h0 = __builtin_convertvector(f32x2{r0, r1}, bf16x2);
-#pragma unroll
-    for (int p = 0; p < PL; ++p) out[p] = __builtin_bit_cast(unsigned, h0);
-    return;
-  }
-#endif
 #pragma unroll
   for (int p = 0; p < PL; ++p) {
     if constexpr (FMT == 0) {
@@ -68,9 +60,6 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&out)[P
 
 template <int FMT>
 __device__ __forceinline__ f32x16 mfma_split(const bf16x8& a, const bf16x8& b, const f32x16& c) {
-#ifdef LT_ABLATE_MFMA    // timing experiment only: everything but the MFMAs
-  if (blockDim.y != 7) return c;
-#endif
   if constexpr (FMT == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -314,31 +303,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
       // cross terms, smallest first: (pa, pb) with pa + pb descending
       constexpr int TPA[6] = {PL == 3 ? 2 : 1, PL == 3 ? 1 : 0, 0, 1, 0, 0};
       constexpr int TPB[6] = {0, 1, PL == 3 ? 2 : 0, 0, 1, 0};
-#ifdef LT_GEMM_DEBUG_SKIP   // debug builds (tools/gemm_skip_sweep.sh): bit mask of components compiled out of the main loop
-      constexpr int dbg_mode = LT_GEMM_DEBUG_SKIP;
-#else
-      constexpr int dbg_mode = 0;
-#endif
       auto step_mma = [&](int m, const bf16x8 (&af)[MI][PL], const bf16x8 (&bf)[NI][PL]) {
-        if (dbg_mode & 8) return;
         const int t = m / (MI * NI), ij = m % (MI * NI), i = ij / NI, j = ij % NI;
         acc[i][j] = mfma_split<FMT>(af[i][TPA[t]], bf[j][TPB[t]], acc[i][j]);
       };
       // Fragment k of a K step, in the order the MFMAs consume them (lowest planes last).
       auto step_read = [&](int k, int buf, int s, bf16x8 (&af)[MI][PL], bf16x8 (&bf)[NI][PL]) {
-        if (dbg_mode & 32) return;
         const unsigned char* Ab = As + (buf * BM + wm * TM + frow) * RS + fk + s * 32;
         const unsigned char* Bb = Bs + (buf * BN + wn * TN + frow) * RS + fk + s * 32;
         if (k < MI * PL) { const int i = k / PL, pp = k % PL; af[i][pp] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * RS + pp * 64); }
         else { const int q = k - MI * PL, j = q / PL, pp = q % PL; bf[j][pp] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * RS + pp * 64); }
       };
       auto step_gload = [&](int u, int kt, f32x4 (&ra)[A_F4], f32x4 (&rb)[B_PCS]) {
-        if (dbg_mode & 2) return;
-        if (dbg_mode & 1) {
-          if (u < A_F4) ra[u] = *reinterpret_cast<const f32x4*>(A + (int64_t)(lrow + u * (NT / 8)) * g.lda + lc4);
-          else { const int pq = tid + (u - A_F4) * NT; rb[u - A_F4] = *reinterpret_cast<const f32x4*>(Wsp + (int64_t)(pq / (PL * 4)) * nkw * (PL * 64) + (pq % (PL * 4)) * 16); }
-          return;
-        }
         if (u < A_F4) {
           const int k0 = (kbase + kt) * 32;
           const float* src = A; int ld = g.lda; int kk = k0;
@@ -353,16 +329,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
         }
       };
       auto step_store = [&](int u, int buf, const f32x4 (&ra)[A_F4], const f32x4 (&rb)[B_PCS]) {
-        if (dbg_mode & 4) return;
         if (u < A_F4) {
           unsigned a[PL], b[PL];
-          if (dbg_mode & 64) {   // debug: ds_writes without the split VALU
-#pragma unroll
-            for (int pp = 0; pp < PL; ++pp) { a[pp] = __builtin_bit_cast(unsigned, ra[u][pp & 1]); b[pp] = __builtin_bit_cast(unsigned, ra[u][2 + (pp & 1)]); }
-          } else {
-            split_pair<PL, FMT>(ra[u][0], ra[u][1], a);
-            split_pair<PL, FMT>(ra[u][2], ra[u][3], b);
-          }
+          split_pair<PL, FMT>(ra[u][0], ra[u][1], a);
+          split_pair<PL, FMT>(ra[u][2], ra[u][3], b);
           unsigned char* dst = As + (buf * BM + lrow + u * (NT / 8)) * RS + lc4 * 2;
 #pragma unroll
           for (int pp = 0; pp < PL; ++pp) *reinterpret_cast<u32x2*>(dst + pp * 64) = u32x2{a[pp], b[pp]};
@@ -372,19 +342,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
           *reinterpret_cast<f32x4*>(Bs + (buf * BN + r) * RS + pc * 16) = rb[u - A_F4];
         }
       };
-      // Slot assignment.  tools/gemm_skip_sweep.sh (components compiled out one at a time, bf16x6 8192x4096x4096):
+      // Slot assignment.  An r02 sweep of ablation builds (components compiled out one at a time, bf16x6 8192x4096x4096; HISTORY.md):
       // MFMAs + barrier alone run at 2.07 PF; the fragment reads add 39 % to that, the global loads + LDS stores 31 %
       // (almost all of it the vmcnt waits in front of the stores), the split VALU 4 %, the barrier 1 %.  The spans
       // below say over which part of a half the LDS instructions are spread; PFD is how many tiles ahead the global
       // loads run (register sets).
-#ifndef LT_RSPAN_PCT
-#define LT_RSPAN_PCT 100   // measured: spreading over the whole half (100/100) beats front-loading (50/75) by 1-2 %
-#endif
-#ifndef LT_SSPAN_PCT
-#define LT_SSPAN_PCT 100
-#endif
-      constexpr int R_SPAN = (N_MMA * LT_RSPAN_PCT / 100) > N_FRAG ? (N_MMA * LT_RSPAN_PCT / 100) : N_FRAG;
-      constexpr int S_SPAN = N_MMA * LT_SSPAN_PCT / 100;
+      // (measured: spreading the LDS instructions over the whole half beats front-loading them -- 50 / 75 % spans -- by 1-2 %)
+      constexpr int R_SPAN = N_MMA > N_FRAG ? N_MMA : N_FRAG;
+      constexpr int S_SPAN = N_MMA;
       // first half of tile kt: MFMAs of K step 0.  Memory stream 1: fragment reads of step 1.  Stream 2: for every
       // staged register, split + ds_write (tile kt+1) followed one step later by its refill (tile kt+1+PFD).
       auto first_half = [&](int kt, f32x4 (&ra)[A_F4], f32x4 (&rb)[B_PCS]) {
@@ -428,7 +393,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
       if constexpr (PFD == 1) {
         for (int kt = 0; kt < nk; ++kt) {
           first_half(kt, ra_[0], rb_[0]);
-          if (!(dbg_mode & 16)) __syncthreads();   // tile kt+1 visible; every wave holds its step-1 fragments of tile kt
+          __syncthreads();   // tile kt+1 visible; every wave holds its step-1 fragments of tile kt
           __builtin_amdgcn_sched_barrier(0);
           second_half(kt, ra_[0], rb_[0]);
         }
@@ -582,13 +547,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(SplitGemmArgs 
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] += rres[it][c];
       }
-#ifdef LT_ABLATE_STORE   // timing experiment only: the output never leaves the CU
-      if (row < g.M && blockDim.y == 7) *reinterpret_cast<f32x4*>(Y + (int64_t)row * g.ldy + gcol) = v;
-#else
       // write-through (sc1) stores: the fresh activations leave the XCD's L2 while the launch is still running instead of
       // being written back behind it (same-box A/B at cfg3: 9.72 -> 9.82 M descriptors/s, twice)
       if (row < g.M) sk_store16(Y + (int64_t)row * g.ldy + gcol, v);
-#endif
     }
     return;
   }

@@ -4,7 +4,7 @@
 // per 64 KiB of output); here the WEIGHTS stay put and the token rows stream through:
 //   * a block of 8 waves lives for the whole launch (one per CU); wave w keeps the three bf16 planes of output channels
 //     32 w .. 32 w + 31 in 96 VGPRs, as the A operand of the transposed product D^T = W . X^T (8 K steps x 3 planes), read once
-//     from the split-tile image of lt_gemm_st.h;
+//     from the split-tile image of lt_st_image.h;
 //   * token rows arrive 64 at a time: a thread loads two 32-byte runs of one row, splits them into planes ONCE (a tiled kernel
 //     splits every activation element once per column tile) and stores them as 16-byte pieces of a split-tile image in LDS
 //     (48 KiB, double-buffered), from which every wave reads its B fragments with conflict-free ds_read_b128 -- one read per two
@@ -19,7 +19,7 @@
 // Since lt_tokmlp.h runs all four MLP layers of both positional encoders in one kernel (its layer-4 stage IS this kernel's slot loop),
 // this GEMM is the stand-alone form: taken when the one-kernel MLP does not apply (non-reference channel widths) and by the unit tests.
 #pragma once
-#include "lt_gemm_st.h"
+#include "lt_st_image.h"
 
 namespace lt {
 
@@ -35,10 +35,6 @@ constexpr int WS_TM = 64, WS_NK = 8, WS_N = 256, WS_K = 128;
 constexpr int WS_BUF = WS_NK * (WS_TM / 16) * ST_RB;      // 49 152: [K step][16-token block][plane][k half][token] x 16 B
 constexpr int WS_LDS = 2 * WS_BUF + WS_N * 4;             // + the bias vector
 
-// DBG (tools/ubench/ws_gemm_bench.hip only): 1 no output stores (kept alive behind a never-true test), 2 no row loads after the
-// first two tiles, 4 no MFMAs, 8 write-through (sc1) stores, 16 nontemporal stores, 32 no B-fragment reads in the
-// slot loop (wrong data, timing only)
-template <int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(WsGemmArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char ws_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -131,19 +127,11 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsGemmArgs a) {
       const int part = e - 9, o = 8 * part;
       const int row = t * WS_TM + 32 * j + lq;
       bool ok = (unsigned)row < (unsigned)a.M;             // also false for the pass before the first tile (t = -1)
-      if (DBG & 1) ok = ok && acc[o] == 12345.678f;
       if (ok) {
         float* yp = a.Y + (int64_t)row * a.ldy + 32 * wave + 8 * h2 + 16 * part;
-        if (DBG & 8) {
-          sk_store16(yp, f32x4{acc[o], acc[o + 1], acc[o + 2], acc[o + 3]});
-          sk_store16(yp + 4, f32x4{acc[o + 4], acc[o + 5], acc[o + 6], acc[o + 7]});
-        } else if (DBG & 16) {
-          __builtin_nontemporal_store(f32x4{acc[o], acc[o + 1], acc[o + 2], acc[o + 3]}, reinterpret_cast<f32x4*>(yp));
-          __builtin_nontemporal_store(f32x4{acc[o + 4], acc[o + 5], acc[o + 6], acc[o + 7]}, reinterpret_cast<f32x4*>(yp + 4));
-        } else {
+        // (plain stores: write-through / nontemporal stores DOUBLE this kernel -- a wave writes 32-byte runs the L2 has to merge)
         *reinterpret_cast<f32x4*>(yp) = f32x4{acc[o], acc[o + 1], acc[o + 2], acc[o + 3]};
         *reinterpret_cast<f32x4*>(yp + 4) = f32x4{acc[o + 4], acc[o + 5], acc[o + 6], acc[o + 7]};
-        }
       }
     }
   };
@@ -182,14 +170,12 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsGemmArgs a) {
     for (int m = 0; m < 96; ++m) {
       const int g = m / 6, t = m % 6, kt = g & 7;
       if (m == 48) init_acc(acc1);
-      if (DBG & 4) {
-        if (t == 0) { if (g < 8) acc0[kt] += __builtin_bit_cast(float, (unsigned)z[g % 3][0][0] << 16 | (unsigned)wreg[kt][0][0]); else acc1[kt] += __builtin_bit_cast(float, (unsigned)z[g % 3][1][0] << 16 | (unsigned)wreg[kt][1][0]); }
-      } else if (g < 8) acc0 = mfma_split<0>(wreg[kt][TW[t]], z[g % 3][TA[t]], acc0);
+      if (g < 8) acc0 = mfma_split<0>(wreg[kt][TW[t]], z[g % 3][TA[t]], acc0);
       else acc1 = mfma_split<0>(wreg[kt][TW[t]], z[g % 3][TA[t]], acc1);
-      if (t < 3 && g + 2 < 16 && !(DBG & 32)) read_z1(g + 2, t);   // into the set group g - 1 has just left
+      if (t < 3 && g + 2 < 16) read_z1(g + 2, t);   // into the set group g - 1 has just left
       if (m >= 2 && m < 13) epi_step(acc1, prev_tile, 1, m - 2);
       if (m >= 30 && m < 42) split_step(m - 30, (it & 1) ^ 1);
-      if (m == 44 && !(DBG & 2)) load_tile(tile + 2 * step);
+      if (m == 44) load_tile(tile + 2 * step);
       if (m >= 50 && m < 61) epi_step(acc0, tile, 0, m - 50);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -212,7 +198,7 @@ inline int gemm_ws_launch(const WsGemmArgs& a, hipStream_t st) {
   static unsigned long long attr_done = 0;
   const unsigned long long dev_bit = current_device_bit();
   if (!(attr_done & dev_bit)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
     attr_done |= dev_bit;
   }
   static int n_cu = 0;
@@ -223,7 +209,7 @@ inline int gemm_ws_launch(const WsGemmArgs& a, hipStream_t st) {
   }
   const int ntiles = cdiv(a.M, WS_TM);
   // two blocks per CU in sequence: measured 4-6 % faster than one (the second block's weight prologue hides under the first one's tail)
-  hipLaunchKernelGGL(gemm_ws_kernel<0>, dim3(std::min(ntiles, 2 * n_cu)), dim3(512), WS_LDS, st, a);
+  hipLaunchKernelGGL(gemm_ws_kernel, dim3(std::min(ntiles, 2 * n_cu)), dim3(512), WS_LDS, st, a);
   LT_LAUNCH_CHECK();
   return 0;
 }

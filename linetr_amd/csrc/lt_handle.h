@@ -48,14 +48,9 @@ struct LinetrHandle {
   // split-bf16 copies of every GEMM weight (2 and 3 planes), keyed by the fp32 pointer
   int precision = LINETR_PREC_BF16X6;
   unsigned char* split_arena = nullptr;
-  struct SplitW { size_t off2, off3; int64_t rows; int K; size_t offh = 0; size_t offst = 0; };  // bf16x2 planes, bf16x3 planes, fp16x2 planes, ST image (lt_gemm_st.h; 0 = none)
+  struct SplitW { size_t off2, off3; int64_t rows; int K; size_t offh = 0; size_t offst = 0; };  // bf16x2 planes, bf16x3 planes, fp16x2 planes, ST image (lt_st_image.h; 0 = none)
   std::map<const float*, SplitW> split;
   std::map<const float*, unsigned char*> debug_split;  // linetr_debug_gemm(cache_weights=1)
-  // side stream: work that is independent of the token-MLP GEMMs (NHWC transpose, line-position MLP) runs here and
-  // is joined back with events; created lazily, disabled with LINETR_NO_SIDE_STREAM=1
-  hipStream_t side = nullptr;
-  bool side_failed = false;
-  hipEvent_t ev_fork = nullptr, ev_tok = nullptr, ev_nhwc = nullptr, ev_lpos = nullptr;
   // software pipeline of CONSECUTIVE describe calls (linetr_describe_submit / linetr_describe_join): a batch is cut into stages at
   // fixed points of the network (PipePlan), stage k of every batch runs on stream k, so stage k of batch i + 1 overlaps stage k + 1 of
   // batch i -- HBM-bound kernels under MFMA-bound ones, and the CUs a GEMM's last tile round leaves empty under another launch.
@@ -68,7 +63,7 @@ struct LinetrHandle {
     bool failed = false;
   } pipe;
   // stream-K workspace of the 128x256 GEMM (partial accumulator tiles + flags, one slot per CU; lt_gemm_split.h)
-  float* zeros = nullptr;   // 4096 zero floats: the "no bias" vector of the split-tile GEMM (lt_gemm_st.h)
+  float* zeros = nullptr;   // 4096 zero floats: the "no bias" vector of the split-tile GEMM (experiments/csrc/lt_gemm_st.h)
   float* sk_ws = nullptr;
   unsigned* sk_flags = nullptr;
   unsigned sk_epoch = 0;
@@ -87,6 +82,10 @@ struct LinetrHandle {
 };
 
 namespace lt {
+
+// widest BatchNorm layer the statistics scratch of linetr_forward_train is sized for (2 D of the signature MLPs at D = 256, lt_bntrain.h);
+// linetr_create refuses a training-mode handle with a wider layer
+constexpr int BN_MAX_CHANNELS = 512;
 
 inline int prof_class(LinetrHandle* h, const char* name) {
   for (size_t i = 0; i < h->classes.size(); ++i)

@@ -83,12 +83,6 @@ __device__ __forceinline__ void line_feat(const float* __restrict__ sublines, co
   const float ex = (sl[2] - cx) / scale, ey = (sl[3] - cy) / scale;
   in[0] = (sx + ex) / 2.f; in[1] = (sy + ey) / 2.f; in[2] = resp[row]; in[3] = angle[row * 2]; in[4] = angle[row * 2 + 1];
 }
-#ifdef LT_MLP_STAMPS   // debug build: 100 MHz wall-clock stamps of one wave per block (tools/mlp_stamps.py)
-__device__ unsigned long long lt_mlp_stamps[1024 * 16];
-#define LT_MLP_STAMP(i) do { if (WORD && threadIdx.x == 0 && blockIdx.x < 1024) lt_mlp_stamps[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
-#else
-#define LT_MLP_STAMP(i) do {} while (0)
-#endif
 // K index served by register r of an accumulator tile in lane half h (see above)
 __device__ __forceinline__ constexpr int cd_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -105,7 +99,6 @@ __global__ __launch_bounds__(256) void mlp123_kernel(const float* __restrict__ p
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t r_begin = wave * rows_per_wave;
   const int64_t r_end = r_begin + rows_per_wave < rows ? r_begin + rows_per_wave : rows;
-  LT_MLP_STAMP(0);
   // Stage W2 / W3 / biases in LDS once per block (coalesced float4 loads; row strides 33 / 65 floats so that the
   // per-lane gathers below are bank-conflict-free) -- per-lane gathers straight from global touch 32 lines per load.
   // LDS: the weight images are dead once every wave has gathered its registers; the per-wave output staging tiles
@@ -144,7 +137,6 @@ __global__ __launch_bounds__(256) void mlp123_kernel(const float* __restrict__ p
   if (threadIdx.x < 64) sB[threadIdx.x] = b2[threadIdx.x];
   else if (threadIdx.x < 192) sB[threadIdx.x] = b3[threadIdx.x - 64];
   __syncthreads();
-  LT_MLP_STAMP(1);
   // resident A operands.  Layer 2: K step s uses k = 2s + h (layer 1 is computed straight into that order).
   // Layer 3: K step (i, r) uses k = 32 i + cd_row(r, h), the order layer 2's accumulators come out in.
   float w2[2][16], w3[4][32];
@@ -167,11 +159,7 @@ __global__ __launch_bounds__(256) void mlp123_kernel(const float* __restrict__ p
     if constexpr (WORD) word_feat(p0, p1, row, cx, cy, scale, feat);
     else line_feat(p0, p1, p2, row, cx, cy, scale, feat);
   }
-  LT_MLP_STAMP(2);
-  int it_ = 0;
-  for (int64_t base = r_begin; base < r_end; base += 32, ++it_) {
-    if (it_ == 0) LT_MLP_STAMP(3);
-    if (it_ == 1) LT_MLP_STAMP(8);
+  for (int64_t base = r_begin; base < r_end; base += 32) {
     {  // next step's inputs are requested now and consumed after this step's 160 MFMAs
       int64_t row = base + 32 + col;
       row = row < r_end ? row : r_end - 1;
@@ -194,7 +182,6 @@ __global__ __launch_bounds__(256) void mlp123_kernel(const float* __restrict__ p
         a1[s1] = fmaxf(t, 0.f);
       }
     }
-    if (it_ == 0) LT_MLP_STAMP(4);
     // layer 2: a2^T[64 neurons][32 rows] = W2 a1^T + b2.  The two 32-neuron tiles are interleaved: a chain of
     // dependent MFMAs on ONE accumulator runs at a fraction of the pipe rate (measured 4x slower per step).
     f32x16 acc2[2];
@@ -213,7 +200,6 @@ __global__ __launch_bounds__(256) void mlp123_kernel(const float* __restrict__ p
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[i][r] = fmaxf(acc2[i][r], 0.f);
-    if (it_ == 0) LT_MLP_STAMP(5);
     // layer 3, two 32-neuron tiles at a time (two independent accumulator chains); the 16 registers of a tile are
     // 4 runs of 4 consecutive neurons
 #pragma unroll
@@ -251,12 +237,9 @@ __global__ __launch_bounds__(256) void mlp123_kernel(const float* __restrict__ p
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if (it_ == 0) LT_MLP_STAMP(6);
 #pragma unroll
     for (int i = 0; i < IN; ++i) feat[i] = feat_next[i];
-    if (it_ == 0) LT_MLP_STAMP(7);
   }
-  LT_MLP_STAMP(9);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -203,6 +203,17 @@ __global__ __launch_bounds__(64) void tokenize_kernel(
 // token's loads in flight while it works on the current one -----------------------------------------------
 struct TapSet { f32x4 v[4]; float w[4]; };   // nw, ne, sw, se values and weights
 
+// grid_sample's un-normalisation in the operation order of PyTorch's CPU kernel (the reference runs it on the CPU; its vectorised
+// grid sampler computes (g + 1) * (size / 2) - 0.5 with ONE rounding -- the compiler contracts the multiply-add of its vector
+// operators -- and (g + 1) * ((size - 1) / 2) with align_corners).  r06: established by matching torch 2.10's CPU output bit for bit
+// on 20 000 points per map size (60 x 80 and 120 x 160 cells: 100 % identical samples with this form; the former
+// ((g + 1) * size - 1) / 2 left 1-3 % of the samples up to 2e-6 off, 4e-6 after normalisation on 960 x 1280 images).
+__device__ __forceinline__ float grid_unnormalize(float g, int size, int align_corners) {
+#pragma clang fp contract(off)
+  if (align_corners) return (g + 1.f) * ((float)(size - 1) / 2.f);
+  return __builtin_fmaf(g + 1.f, (float)size / 2.f, -0.5f);
+}
+
 // Bilinear tap geometry of one point (sample_descriptors' grid arithmetic, models/line_process.py:86-98, and
 // grid_sample's unnormalisation): 4 cell offsets (clamped, in cells) and weights (0 for taps outside the map: zero padding).
 __device__ __forceinline__ void tap_coords(float px, float py, int Hc, int Wc, int align_corners, int (&off)[4],
@@ -213,14 +224,7 @@ __device__ __forceinline__ void tap_coords(float px, float py, int Hc, int Wc, i
   float gy = ((py - s / 2) + 0.5f) / ((float)Hc * s - s / 2 - 0.5f);
   gx = gx * 2.f - 1.f;
   gy = gy * 2.f - 1.f;
-  float ix, iy;
-  if (align_corners) {
-    ix = ((gx + 1.f) / 2.f) * (float)(Wc - 1);
-    iy = ((gy + 1.f) / 2.f) * (float)(Hc - 1);
-  } else {
-    ix = ((gx + 1.f) * (float)Wc - 1.f) / 2.f;
-    iy = ((gy + 1.f) * (float)Hc - 1.f) / 2.f;
-  }
+  const float ix = grid_unnormalize(gx, Wc, align_corners), iy = grid_unnormalize(gy, Hc, align_corners);
   const float x_w = floorf(ix), y_n = floorf(iy);
   const float w = ix - x_w, e = 1.f - w, nn = iy - y_n, ss = 1.f - nn;
   const float wv[4] = {ss * e, ss * w, nn * e, nn * w};
@@ -263,10 +267,10 @@ __device__ __forceinline__ f32x4 taps_finish(const TapSet& t) {
   float sq = 0.f;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    float v = t.v[0][c] * t.w[0];
-    v = v + t.v[1][c] * t.w[1];
-    v = v + t.v[2][c] * t.w[2];
-    v = v + t.v[3][c] * t.w[3];
+    float v = t.v[0][c] * t.w[0];                  // nw * w_nw, then one fused multiply-add per further tap: the CPU kernel's order
+    v = __builtin_fmaf(t.v[1][c], t.w[1], v);
+    v = __builtin_fmaf(t.v[2][c], t.w[2], v);
+    v = __builtin_fmaf(t.v[3][c], t.w[3], v);
     o[c] = v;
     sq += v * v;
   }
@@ -293,14 +297,7 @@ __device__ __forceinline__ f32x4 sample_one(float px, float py, const float* __r
   float gy = ((py - s / 2) + 0.5f) / ((float)Hc * s - s / 2 - 0.5f);
   gx = gx * 2.f - 1.f;
   gy = gy * 2.f - 1.f;
-  float ix, iy;  // grid_sampler_unnormalize
-  if (align_corners) {
-    ix = ((gx + 1.f) / 2.f) * (float)(Wc - 1);
-    iy = ((gy + 1.f) / 2.f) * (float)(Hc - 1);
-  } else {
-    ix = ((gx + 1.f) * (float)Wc - 1.f) / 2.f;
-    iy = ((gy + 1.f) * (float)Hc - 1.f) / 2.f;
-  }
+  const float ix = grid_unnormalize(gx, Wc, align_corners), iy = grid_unnormalize(gy, Hc, align_corners);
   const float x_w = floorf(ix), y_n = floorf(iy);
   const float w = ix - x_w, e = 1.f - w, nn = iy - y_n, ss = 1.f - nn;
   const float nw = ss * e, ne = ss * w, sw = nn * e, se = nn * w;
@@ -315,10 +312,10 @@ __device__ __forceinline__ f32x4 sample_one(float px, float py, const float* __r
   float sq = 0.f;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    float v = v_nw[c] * nw;
-    v = v + v_ne[c] * ne;
-    v = v + v_sw[c] * sw;
-    v = v + v_se[c] * se;
+    float v = v_nw[c] * nw;                        // (nw_val * nw) + (ne_val * ne) + ... as the CPU kernel evaluates it: fused
+    v = __builtin_fmaf(v_ne[c], ne, v);
+    v = __builtin_fmaf(v_sw[c], sw, v);
+    v = __builtin_fmaf(v_se[c], se, v);
     o[c] = v;
     sq += v * v;
   }

@@ -7,7 +7,7 @@
 //
 // A block of 8 waves per CU lives for the whole launch and walks tiles of 64 token rows.  Layer 4's weights stay in registers (96
 // VGPRs per wave, as in lt_gemm_ws.h: wave w owns output channels 32 w .. + 31), those of layers 2 and 3 in LDS as split-tile images
-// (lt_gemm_st.h), and every layer's activations go to the next one through LDS as split-tile images of bf16 planes:
+// (lt_st_image.h), and every layer's activations go to the next one through LDS as split-tile images of bf16 planes:
 //   A  layer 1 on the VALU, rounded like mlp123_kernel (wave & 3 = 8 channels, lane = token), in the MFMA slots
 //      of the PREVIOUS tile's D                                                                                 -> image A1 [64 x 32]
 //   B  layer 2, 4 tiles of 32 channels x 32 tokens, K = 32 (waves 0-3)                                          -> image A2 [64 x 64]

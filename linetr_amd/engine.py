@@ -430,7 +430,7 @@ class Engine:
                 float(token_distance), T, dense_desc.data_ptr(), dense_score.data_ptr(), H, W, int(bool(align_corners)), int(nhwc), ct,
                 tb.sub2line.data_ptr(), ld.data_ptr())
         if pipeline_slot is None:
-            ws = self._workspace(getattr(self, "_ws_tag", None) or "desc", nbytes)
+            ws = self._workspace("desc", nbytes)
             nat.check(self._L.linetr_describe(*args, ws.data_ptr(), ws.numel(), self._stream()), self._L)
         else:
             slot, n_slots = (int(v) for v in pipeline_slot)
@@ -444,7 +444,7 @@ class Engine:
         nat.check(self._L.linetr_describe_join(self._h, int(slot), self._stream()), self._L)
 
     def describe_lines(self, lines6, offsets, dense_desc, dense_score, *, remove_borders, min_length, max_keylines,
-                       token_distance, max_tokens, align_corners=False, n_streams=1, want_tokens=False,
+                       token_distance, max_tokens, align_corners=False, want_tokens=False,
                        dense_layout="nchw", angles="native", pipeline_slot=None):
         """prefilter + describe for a batch given as one [sum K,6] array + row offsets [B+1].
 
@@ -453,75 +453,22 @@ class Engine:
         per-image surface computes (models/line_process.py:28-41): the two can differ in the last float64 ulp (<= 1.2e-7 after the
         float32 cast), and the batched drop-in surface (Matching.forward_batch) asks for NumPy's so that it returns forward()'s tensors.
 
-        With n_streams > 1 the images are cut into contiguous groups that run as independent sub-batches on
-        separate HIP streams (forked from / joined back into the current stream).  The descriptor network of one
-        image never looks at another image, so this is exact.  Measured on MI355X (cfg3) it does NOT pay: in r01 one stream
-        took 4.44 ms/step, two 4.71, four 6.78; in r02 two sub-batches ran a 2.71 ms median step against 2.75 but stalled
-        ~1 ms on every fourth step (two hardware queues), 8.7 vs 9.2 M descriptors/s -- so the default is one stream.
+        pipeline_slot = (slot, n_slots): see describe() / DescribePipeline.
         Returns (TokenBatch, line_desc [N,256]) for the whole batch."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int32)
         B = len(offsets) - 1
         H, W = int(dense_score.shape[-2]), int(dense_score.shape[-1])
         kw = dict(remove_borders=remove_borders, min_length=min_length, max_keylines=max_keylines,
                   token_distance=token_distance, max_tokens=max_tokens)
-        G = max(1, min(int(n_streams), B // 4))
         if angles not in ("native", "numpy"):
             raise ValueError("angles must be 'native' or 'numpy'")
-        if G == 1:
-            recs, cu_k, cu_n = self.prefilter(lines6, H, W, offsets=offsets, **kw)
-            if angles == "numpy" and len(recs):
-                from .line_process import get_angles
-                recs["angle"] = get_angles(np.stack([recs["sp"], recs["ep"]], axis=1))     # (records live in the pinned upload slot)
-            return self.describe(recs, cu_k, cu_n, dense_desc, dense_score, token_distance=token_distance,
-                                 max_tokens=max_tokens, align_corners=align_corners, want_tokens=want_tokens,
-                                 dense_layout=dense_layout, pipeline_slot=pipeline_slot)
-        if pipeline_slot is not None:
-            raise ValueError("pipeline_slot and n_streams > 1 are two different schedules: pick one")
-        # contiguous image groups of (nearly) equal line count
-        target = offsets[-1] / G
-        cuts = [0] + [int(np.searchsorted(offsets, target * g)) for g in range(1, G)] + [B]
-        cuts = sorted(set(min(max(c, 0), B) for c in cuts))
-        streams = self.__dict__.setdefault("_streams", [])
-        while len(streams) < len(cuts) - 1:
-            streams.append(torch.cuda.Stream(device=self.device))
-        cur = torch.cuda.current_stream(self.device)
-        fork = torch.cuda.Event()
-        fork.record(cur)
-        parts = []
-        for g in range(len(cuts) - 1):
-            i0, i1 = cuts[g], cuts[g + 1]
-            st = streams[g]
-            st.wait_event(fork)
-            with torch.cuda.stream(st):
-                sub_off = offsets[i0:i1 + 1] - offsets[i0]
-                recs, cu_k, cu_n = self.prefilter(lines6[offsets[i0]:offsets[i1]], H, W, offsets=sub_off, **kw)
-                if angles == "numpy" and len(recs):
-                    from .line_process import get_angles
-                    recs["angle"] = get_angles(np.stack([recs["sp"], recs["ep"]], axis=1))
-                self._ws_tag = f"desc{g}"
-                tb, ld = self.describe(recs, cu_k, cu_n, dense_desc[i0:i1], dense_score[i0:i1],
-                                       token_distance=token_distance, max_tokens=max_tokens,
-                                       align_corners=align_corners, want_tokens=want_tokens, dense_layout=dense_layout)
-                self._ws_tag = None
-                done = torch.cuda.Event()
-                done.record(st)
-            parts.append((tb, ld, done))
-        for tb, ld, done in parts:
-            cur.wait_event(done)
-            for t in (ld, tb.klines, tb.sublines, tb.sub2line):
-                t.record_stream(cur)
-        return self._merge([p[0] for p in parts]), torch.cat([p[1] for p in parts])
-
-    @staticmethod
-    def _merge(tbs):
-        cu_k = np.concatenate([[0]] + [tb.cu_k[1:] + off for tb, off in zip(tbs, np.cumsum([0] + [t.K for t in tbs[:-1]]))])
-        cu_n = np.concatenate([[0]] + [tb.cu_n[1:] + off for tb, off in zip(tbs, np.cumsum([0] + [t.N for t in tbs[:-1]]))])
-        cat = lambda k: torch.cat([getattr(tb, k) for tb in tbs])
-        return TokenBatch(n_images=sum(tb.n_images for tb in tbs), max_tokens=tbs[0].max_tokens,
-                          cu_k=cu_k.astype(np.int32), cu_n=cu_n.astype(np.int32), recs=None, klines=cat("klines"),
-                          length=cat("length"), angles=cat("angles"), sublines=cat("sublines"), pnt=cat("pnt"),
-                          mask=cat("mask"), resp=cat("resp"), angle_sub=cat("angle_sub"), desc=cat("desc"),
-                          score=cat("score"), sub2line=cat("sub2line"))
+        recs, cu_k, cu_n = self.prefilter(lines6, H, W, offsets=offsets, **kw)
+        if angles == "numpy" and len(recs):
+            from .line_process import get_angles
+            recs["angle"] = get_angles(np.stack([recs["sp"], recs["ep"]], axis=1))     # (records live in the pinned upload slot)
+        return self.describe(recs, cu_k, cu_n, dense_desc, dense_score, token_distance=token_distance,
+                             max_tokens=max_tokens, align_corners=align_corners, want_tokens=want_tokens,
+                             dense_layout=dense_layout, pipeline_slot=pipeline_slot)
 
     def _upload_recs(self, recs, K, B, tb):
         """H2D of the line records (+ the sub-line prefix sums when they sit in the same pinned blob)."""

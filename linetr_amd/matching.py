@@ -10,7 +10,6 @@ or injected through the ``superpoint=`` / ``lsd=`` arguments.
 from __future__ import annotations
 
 import importlib
-import os
 
 import numpy as np
 import torch
@@ -156,7 +155,7 @@ class Matching(torch.nn.Module):
             # its contents on the slower path below
             s0, s1 = sub2line_of(mat0), sub2line_of(mat1)
             have_lines = K0 > 0 and K1 > 0 and s0 is not None and s1 is not None and ld0.is_cuda and ld1.is_cuda
-            if (have_lines or K0 == 0 or K1 == 0) and not os.environ.get("LINETR_NO_PAIR_TAIL"):     # (A/B switch: tools/ab_pair_tail.py)
+            if have_lines or K0 == 0 or K1 == 0:
                 tail = eng_m.pair_tail(d0, d1, float(np.float32(thr_p)), ld0[0].t() if have_lines else None, s0, K0,
                                        ld1[0].t() if have_lines else None, s1, K1, float(np.float32(thr_l)), True)
         if tail is not None:
@@ -166,14 +165,17 @@ class Matching(torch.nn.Module):
                 m_l, d_l = match01_to_matrix(m01_lh, K1), dk_h[None]
             else:           # a side without key-lines: the reference's matcher returns zeros (nn_matcher.py:9-10)
                 m_l, d_l = np.zeros((1, K0, K1)), np.zeros((1, K0, K1), dtype=np.float32)
-        else:   # edited / foreign matrices, host tensors: the surface functions one after the other
-            if on_dev:
+        else:   # edited / foreign matrices (read by their contents), matrices made under inference_mode, host tensors
+            ticket_p = None
+            if on_dev:     # the point matcher and its device -> host copies are queued FIRST and travel under the line branch
                 dist, m01 = eng_m.match_points(d0, d1, float(np.float32(thr_p)), True)
-                m01_h, dist_h = eng_m.to_host(m01, dist)
-                m_p, d_p = match01_to_matrix(m01_h, int(d1.shape[1])), dist_h[None]
+                ticket_p = eng_m.to_host_async(m01, dist)
             else:
                 m_p, d_p = nn_matcher(d0.cpu().numpy(), d1.cpu().numpy(), thr_p, is_mutual_NN=True)
-            m_l, d_l = self.match_lines(*line_args)
+            m_l, d_l = self.match_lines(*line_args)        # its own wait covers everything queued before it on the stream
+            if ticket_p is not None:
+                m01_h, dist_h = eng_m.collect(ticket_p)
+                m_p, d_p = match01_to_matrix(m01_h, int(d1.shape[1])), dist_h[None]
         pred["matches_p"] = torch.from_numpy(m_p)
         pred["matching_scores_p"] = torch.from_numpy(d_p)
         pred["matches_l"] = torch.from_numpy(m_l)

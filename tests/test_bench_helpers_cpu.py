@@ -67,3 +67,11 @@ def test_every_kernel_class_of_the_committed_step_has_its_counters(bench):
     dom = d["roofline"]
     assert dom["kernel"] in d["kernels"] and dom["traffic"] and dom["mfma_busy"]
     assert all(o["traffic"] for o in dom["other_kernels"])
+
+
+def test_socket_filling_cpu_baseline_adds_up_process_rates(bench):
+    """cpu_baseline_socket: N independent oracle processes at once (here 2 x 1 thread for a second each); the reported rate is the sum
+    of the processes' own rates and the record says how many processes and cores it used."""
+    r = bench.cpu_baseline_socket("cfg2", 1, 2, seconds=1.0)
+    assert r["processes"] == 2 and r["threads_per_process"] == 1 and r["cores"] == 2 and r["physical_cores"] == 2
+    assert r["value"] > 100 and r["unit"] == "line-descriptors/s"

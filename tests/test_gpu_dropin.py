@@ -215,6 +215,93 @@ def test_matching_pair_of_two_image_sizes_like_the_reference():
     assert np.abs(pred["matching_scores_l"].numpy() - g["matching_scores_l"]).max() < 1e-4
 
 
+class AssetSuperPoint(torch.nn.Module):
+    """Hands out the frozen outputs of the reference's SuperPoint on the asset pair (tests/golden/asset_pair.npz)."""
+    config = {"nn_threshold": 0.7}
+
+    def __init__(self, g):
+        super().__init__()
+        self.g, self.i = g, 0
+
+    def forward(self, data):
+        s = "01"[self.i % 2]
+        self.i += 1
+        dev = data["image"].device
+        t = lambda k: torch.from_numpy(self.g[k + s]).to(dev)
+        return {"keypoints": [t("keypoints")], "scores": [torch.ones(self.g["keypoints" + s].shape[0], device=dev)], "descriptors": [t("descriptors")],
+                "dense_descriptor": t("dense_descriptor"), "dense_score": t("dense_score")}
+
+
+def asset_margins(dk):
+    two = np.sort(dk, axis=1)[:, :2]
+    twoc = np.sort(dk, axis=0)[:2, :]
+    return np.concatenate([two[:, 1] - two[:, 0], twoc[1] - twoc[0]])
+
+
+def test_matching_on_the_reference_asset_pair_with_real_image_statistics():
+    """match_line_pairs.py:80-104 on assets/input_pairs.txt:1 (scannet_0a / scannet_0b) as far as this container can pin it: the
+    REFERENCE's SuperPoint (seeded weights) gave the dense maps and key-point descriptors, a deterministic edge-aligned line list stands
+    in for cv2's LSD, and the reference's LineTransformer + matching tail gave the expected outputs (tests/golden/make_golden_asset_pair.py).
+    Dense maps with real-image statistics (neighbouring descriptor cells at cosine 0.98): every token tensor bit for bit (angles: libm's
+    last ulp), sampled token descriptors <= 1e-6, line descriptors <= 1e-4, Dk <= 1e-4, line AND point matches identical by index."""
+    from models.matching import Matching
+    g = load("asset_pair")
+    mt = Matching({"auto_min_length": True, "superpoint": {"nn_threshold": 0.7}, "linetransformer": {**LT_CFG}},
+                  superpoint=AssetSuperPoint(g), lsd=FakeLSD([g["lines0"], g["lines1"]]))
+    mt.linetransformer.load_state_dict(synth.to_torch_state_dict(synth.calibrated_state_dict()))
+    mt = mt.eval().to("cuda")
+    img = torch.zeros(1, 1, 480, 640, device="cuda")
+    pred = mt({"image0": img, "image1": img.clone()})
+    worst = 0.0
+    for s in "01":
+        for k in TOK_KEYS:
+            want, have = g[k + s], pred[k + s].cpu().numpy()
+            assert have.shape == want.shape, (k, s)
+            assert np.abs(have - want).max() <= (1.2e-7 if "angle" in k else 0), (k, s)
+        err = float(np.abs(pred["line_desc" + s].cpu().numpy() - g["line_desc" + s]).max())
+        worst = max(worst, err)
+        assert err < 1e-4
+    assert np.array_equal(pred["matches_l"].numpy(), g["matches_l"]) and g["matches_l"].sum() >= 40
+    dk_err = float(np.abs(pred["matching_scores_l"].numpy() - g["matching_scores_l"]).max())
+    assert dk_err < 1e-4
+    mp = pred["matches_p"].numpy()[0]
+    assert np.array_equal(np.where(mp.sum(1) > 0, mp.argmax(1), -1), g["matches_p_index"]) and int(mp.sum()) == int(g["matches_p_count"])
+    assert np.abs(pred["matching_scores_p"].numpy()[0].min(1) - g["matching_scores_p_rowmin"]).max() < 1e-5
+    mg = asset_margins(g["matching_scores_l"][0])
+    print(f"asset pair: max |line_desc - reference| = {worst:.3e}, max |Dk - reference| = {dk_err:.3e}, smallest argmin margin {mg.min():.3e}, "
+          f"margins below 4 x the Dk error: {int((mg < 4 * dk_err).sum())} of {mg.size}")
+    assert int((mg < 4 * max(dk_err, 1e-7)).sum()) == 0          # no argmin of this pair rests on summation order
+
+
+def test_asset_pair_through_the_raw_tokeniser_and_the_batched_path():
+    """The same fixture through linetr_tokenize (the reference's dense desc_sublines: sampled token descriptors against frozen samples,
+    <= 1e-6 on correlated maps) and through the fused batched path the benchmark times (linetr_describe, NCHW- and NHWC-fed)."""
+    from linetr_amd.engine import Engine
+    g = load("asset_pair")
+    eng = Engine(synth.calibrated_state_dict(), "cuda:0")
+    dd = torch.cat([torch.from_numpy(g["dense_descriptor" + s]) for s in "01"]).cuda()
+    ds = torch.cat([torch.from_numpy(g["dense_score" + s]) for s in "01"]).cuda()
+    cfg = dict(remove_borders=8, min_length=16, max_keylines=-1, token_distance=8, max_tokens=21)
+    recs, cu_k, cu_n = eng.prefilter([g["lines0"], g["lines1"]], 480, 640, **cfg)
+    tb = eng.tokenize(recs, cu_k, cu_n, dd, ds, token_distance=8, max_tokens=21)
+    for i, s in enumerate("01"):
+        n0, n1 = tb.cu_n[i], tb.cu_n[i + 1]
+        desc = tb.desc[n0:n1].cpu().numpy()
+        ii, jj = g["desc_sample_idx" + s].T
+        assert np.abs(desc[ii, jj] - g["desc_sample" + s]).max() < 1e-6
+        assert np.abs(desc.astype(np.float64).sum(-1) - g["desc_checksum" + s]).max() < 1e-4
+        assert np.array_equal(tb.score[n0:n1].cpu().numpy()[..., None], g["score_sublines" + s][0])
+    lines = [g["lines0"], g["lines1"]]
+    off = np.array([0, len(lines[0]), len(lines[0]) + len(lines[1])], np.int32)
+    outs = []
+    for layout, feed in (("nchw", dd), ("nhwc", dd.permute(0, 2, 3, 1).contiguous())):
+        tb2, ld = eng.describe_lines(np.concatenate(lines), off, feed, ds, dense_layout=layout, **cfg)
+        for i, s in enumerate("01"):
+            assert np.abs(ld[tb2.cu_n[i]:tb2.cu_n[i + 1]].cpu().numpy().T - g["line_desc" + s][0]).max() < 1e-4
+        outs.append(ld)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_matching_forward_batch_equals_per_pair():
     """forward_batch (one fused describe + one match call for all pairs) vs forward() pair by pair."""
     from models.matching import Matching
@@ -504,6 +591,18 @@ def test_line_tokenizer_with_the_dataset_builders_swapped_image_shape():
     for k in TOK_KEYS:
         assert np.array_equal(out[k].cpu().numpy(), g[f"pseudo_tok_{k}"]), k
     assert out["klines"][0, :, 1, 0].max().item() <= 479.4 + 1e-4
+
+
+def test_training_handle_refuses_encoder_widths_beyond_its_statistics_scratch():
+    """the train-mode BatchNorm scratch holds 512 channels per layer; a keyline_encoder like [32, 64, 1024, 256] passed
+    linetr_create and would have written past it.  Such a handle is refused at creation (inference handles take any width)."""
+    from linetr_amd import _native as nat
+    from linetr_amd.engine import Engine
+    enc = (32, 64, 1024, 256)
+    sd = synth.make_state_dict(3, enc=enc)
+    with pytest.raises(nat.NativeError, match="training-mode handle"):
+        Engine(sd, "cuda:0", keyline_encoder=list(enc), bn_batch_stats=True)
+    Engine(sd, "cuda:0", keyline_encoder=list(enc))           # the inference handle of the same widths is fine
 
 
 def test_train_mode_forward_golden():

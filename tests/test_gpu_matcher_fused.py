@@ -1,6 +1,6 @@
 """GPU: the one-launch matcher of a single pair (pair_match_fused_kernel: distances + key-line pooling + mutual NN, column argmin
 by a 64-bit packed atomicMin, last-arriving block finishes) against the CPU oracle and against the three-launch path it replaces
-(LINETR_MATCH_THREE_LAUNCHES=1): models/line_process.py:198-201, models/line_transformer.py:277-282, models/nn_matcher.py:3-31."""
+(the same pair inside a batch of two): models/line_process.py:198-201, models/line_transformer.py:277-282, models/nn_matcher.py:3-31."""
 import numpy as np
 import pytest
 import torch
@@ -43,12 +43,23 @@ def run(eng, d0, s0, k0, d1, s1, k1, thr, mutual=True):
     return dk.cpu().numpy().reshape(k0, k1), m01.cpu().numpy()
 
 
+def run_in_a_batch_of_two(eng, d0, s0, k0, d1, s1, k1, thr, mutual=True):
+    """the same pair twice in ONE linetr_match call: a batch always takes the three launches (pair_dist / pair_pool / pair_final)"""
+    t = lambda a: torch.from_numpy(np.concatenate([a, a])).cuda()
+    dk, off, m01 = eng.match(t(d0), np.array([0, len(d0), 2 * len(d0)]), t(s0), np.array([0, k0, 2 * k0]),
+                             t(d1), np.array([0, len(d1), 2 * len(d1)]), t(s1), np.array([0, k1, 2 * k1]), thr, mutual)
+    torch.cuda.synchronize()
+    dk, m01 = dk.cpu().numpy(), m01.cpu().numpy()
+    assert np.array_equal(dk[:k0 * k1], dk[k0 * k1:]) and np.array_equal(m01[:k0], m01[k0:])
+    return dk[:k0 * k1].reshape(k0, k1), m01[:k0]
+
+
 @pytest.mark.parametrize("k0,k1,max_sub,seed", [(199, 199, 1, 0), (37, 53, 3, 1), (1, 7, 2, 2), (16, 16, 1, 3), (17, 300, 4, 4),
                                                  (600, 599, 2, 5), (130, 1, 1, 6), (250, 400, 1, 7),
                                                  (1024, 1024, 1, 8),      # the largest image 1 of the one-launch path: 64 column tiles over 8 blocks per row chunk
                                                  (1030, 1030, 1, 9),      # one past it: the three launches
                                                  (512, 700, 1, 10)])      # point-matcher shape (identity maps, n0 != n1)
-def test_fused_single_pair_matcher_vs_oracle_and_three_launches(eng, monkeypatch, k0, k1, max_sub, seed):
+def test_fused_single_pair_matcher_vs_oracle_and_three_launches(eng, k0, k1, max_sub, seed):
     rs = np.random.RandomState(seed)
     dup0 = [(0, min(3, k0 - 1))] if k0 > 3 else []     # two identical key-lines in image 0: a COLUMN-argmin tie -> first index
     dup1 = [(1, min(5, k1 - 1))] if k1 > 5 else []     # two identical key-lines in image 1: a ROW-argmin tie -> first index
@@ -63,9 +74,7 @@ def test_fused_single_pair_matcher_vs_oracle_and_three_launches(eng, monkeypatch
         got[np.nonzero(m01 >= 0)[0], m01[m01 >= 0]] = 1
         assert np.abs(dk - Dk[0]).max() < 5e-6
         assert np.array_equal(got, want), (thr, mutual)
-        monkeypatch.setenv("LINETR_MATCH_THREE_LAUNCHES", "1")
-        dk3, m3 = run(eng, d0, s0, k0, d1, s1, k1, thr, mutual)
-        monkeypatch.delenv("LINETR_MATCH_THREE_LAUNCHES")
+        dk3, m3 = run_in_a_batch_of_two(eng, d0, s0, k0, d1, s1, k1, thr, mutual)
         assert np.array_equal(m01, m3) and np.abs(dk - dk3).max() < 5e-6
     dk_a, m_a = run(eng, d0, s0, k0, d1, s1, k1, 0.8, True)
     for _ in range(25):                                 # deterministic to the bit, and the slot is left clean every time

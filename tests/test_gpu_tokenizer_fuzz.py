@@ -109,7 +109,8 @@ def test_tokenizer_fuzz_vs_oracle(engine, maps, td, T):
             else:
                 assert np.array_equal(have, ref), (k, td, T, i, np.abs(have - ref).max())
         err = (tb.desc[n0:n1].cpu() - want["desc_sublines"][0]).abs().max().item()
-        assert err <= 5e-6, err       # fp32 bilinear weights at cell coordinates up to 160 (the 480 x 640 goldens: <= 1e-6)
+        assert err <= 1e-6, err       # r06: the sampler follows the CPU grid_sampler's operation order (fused un-normalisation and tap sums):
+        #                               what is left on 960 x 1280 maps is the L2 norm's summation order (it was 5e-6 before)
     assert n_multi > 0 or T * td > 600, "the fuzz must exercise sub-line chaining"
 
 

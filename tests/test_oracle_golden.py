@@ -58,6 +58,38 @@ def test_mixed_size_pair_per_image_thresholds():
     assert np.array_equal(M, g["matches_l"]) and np.abs(Dk - g["matching_scores_l"]).max() < 1e-5
 
 
+def test_asset_pair_real_image_statistics():
+    """The first pair of the reference's demo list (assets/input_pairs.txt:1) through the REFERENCE's SuperPoint (seeded weights) and the
+    line branch of its Matching.forward (tests/golden/make_golden_asset_pair.py): dense maps with real-image statistics -- neighbouring
+    descriptor cells at cosine 0.98 -- instead of the i.i.d. maps of every other fixture.  The oracle must reproduce tokens bit for bit,
+    descriptors, Dk and both match sets."""
+    g = load("asset_pair")
+    sd = synth.to_torch_state_dict(synth.calibrated_state_dict())
+    dd0 = g["dense_descriptor0"][0]
+    assert float((dd0[:, :, 1:] * dd0[:, :, :-1]).sum(0).mean()) > 0.95         # this IS the correlated regime
+    outs = []
+    for s in "01":
+        out = oracle_image(sd, g["lines" + s], torch.from_numpy(g["dense_descriptor" + s]), torch.from_numpy(g["dense_score" + s]),
+                           (480, 640), BASE_CFG)
+        for k in TOK_KEYS:
+            assert np.array_equal(out[k].numpy(), g[k + s]), (k, s)
+        desc = out["desc_sublines"].numpy()[0]
+        ii, jj = g["desc_sample_idx" + s].T
+        assert np.array_equal(desc[ii, jj], g["desc_sample" + s])
+        assert np.abs(desc.astype(np.float64).sum(-1) - g["desc_checksum" + s]).max() == 0
+        assert np.abs(out["line_desc"].numpy() - g["line_desc" + s]).max() < DESC_TOL
+        outs.append(out)
+    assert outs[0]["sublines"].shape[1] > outs[0]["klines"].shape[1]             # lines longer than 168 px: several sub-lines per line
+    M, Dk = O.match_lines(outs[0]["line_desc"], outs[1]["line_desc"], outs[0]["mat_klines2sublines"][0],
+                          outs[1]["mat_klines2sublines"][0], 0.8)
+    assert np.array_equal(M, g["matches_l"]) and M.sum() >= 40
+    assert np.abs(Dk - g["matching_scores_l"]).max() < 1e-5
+    Mp, Dp = O.point_nn(g["descriptors0"], g["descriptors1"], 0.7, True)
+    idx = np.where(Mp[0].sum(1) > 0, Mp[0].argmax(1), -1)
+    assert np.array_equal(idx, g["matches_p_index"]) and int(Mp.sum()) == int(g["matches_p_count"])
+    assert np.abs(Dp[0].min(1) - g["matching_scores_p_rowmin"]).max() < 1e-5
+
+
 def test_jitter_pair_recovers_permutation():
     g = load("cfg2_jitter_pair")
     sd = synth.to_torch_state_dict(synth.calibrated_state_dict())

@@ -20,7 +20,7 @@ H, W, n_lines, lo, hi, T, pairs = bench.WORKLOADS[wl]
 dev = torch.device("cuda:0")
 eng = Engine(synth.calibrated_state_dict(), dev, image_shape=[H, W])
 lines, dd, nhwc, ds, hw, T = bench.make_inputs(wl, pairs, 0, dev, eng)
-pipe = bench.Pipeline(eng, lines, dd if wl == "cfg3" else nhwc, ds, hw, T, 1, pairs, 1, "nchw" if wl == "cfg3" else "nhwc", pipelined=depth)
+pipe = bench.Pipeline(eng, lines, dd if wl == "cfg3" else nhwc, ds, hw, T, 1, pairs, "nchw" if wl == "cfg3" else "nhwc", pipelined=depth)
 for _ in range(steps):
     pipe.step()
 pipe.drain()

@@ -7,7 +7,8 @@
 #
 #   bash tools/scale_sweep.sh [out_dir] [N ...]            # on a multi-GPU node:   N defaults to "1 2 4 8"
 #   LINETR_BENCH_ONE_DEVICE=1 LINETR_BENCH_BACKEND=gloo bash tools/scale_sweep.sh gpurun_out/sweep 1 2
-#       (one-device test mode: every rank on cuda:0, gloo carries the collective -- plumbing only, the times mean nothing)
+#       (one-device test mode: every rank on cuda:0, gloo carries the collective -- plumbing only, the times mean nothing;
+#        SWEEP_PAIRS=8 CFG4_PAIRS=64 keep an 8-rank rehearsal on one GPU short)
 # bench.py starts its own ranks (`python bench.py --gpus N` re-executes itself under torch.distributed.run).
 out=${1:-gpurun_out/scale_sweep}; shift
 ns=${*:-"1 2 4 8"}
@@ -15,9 +16,9 @@ cd "$(dirname "$0")/.." && mkdir -p "$out"
 export HSA_ENABLE_IPC_MODE_LEGACY=${HSA_ENABLE_IPC_MODE_LEGACY:-0}
 rc=0
 for n in $ns; do
-  timeout 900 python bench.py --gpus $n --steps 10 --warmup 3 --settle-s 1 --no-cpu-baseline --no-sub-workloads \
+  timeout 900 python bench.py --gpus $n ${SWEEP_PAIRS:+--pairs $SWEEP_PAIRS} --steps 10 --warmup 3 --settle-s 1 --no-cpu-baseline --no-sub-workloads \
       > "$out/cfg3_n$n.json" 2> "$out/cfg3_n$n.log" || { echo "cfg3 N=$n: bench.py failed (see $out/cfg3_n$n.log)"; rc=1; continue; }
-  timeout 900 python bench.py --gpus $n --workload cfg4 --pairs-total ${CFG4_PAIRS:-1024} --steps 3 --warmup 1 --settle-s 1 \
+  timeout 900 python bench.py --gpus $n --workload cfg4 --pairs-total ${CFG4_PAIRS:-1024} ${SWEEP_PAIRS:+--pairs $SWEEP_PAIRS} --steps 3 --warmup 1 --settle-s 1 \
       > "$out/cfg4_n$n.json" 2> "$out/cfg4_n$n.log" || { echo "cfg4 N=$n: bench.py failed (see $out/cfg4_n$n.log)"; rc=1; continue; }
 done
 python - "$out" $ns <<'PY' || rc=1
