@@ -44,7 +44,7 @@ from linetr_amd.engine import DescribePipeline, Engine  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA
 HBM_PEAK_GBS = 8000.0
-PROFILE_TAG = "r05"             # profiles/<tag>_<workload>_pmc_traffic.json, profiles/<tag>_<workload>_gemm_pmc.json
+PROFILE_TAG = "r06"             # profiles/<tag>_<workload>_pmc_traffic.json, profiles/<tag>_<workload>_gemm_pmc.json
 
 WORKLOADS = {
     # name: (H, W, lines/image, len_lo, len_hi, max_tokens, default pairs per GPU)
@@ -1082,7 +1082,7 @@ def main():
     ap.add_argument("--dense-layout", default="nchw", choices=["nhwc", "nchw"],
                     help="layout of the resident dense descriptor map: nchw = the reference's 'dense_descriptor' (models/superpoint.py:193; "
                          "the metric's input, SURVEY 8d), nhwc = what the repo's own producer emits (reported beside it as value_fed_nhwc)")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[0, 2, 3, 4],
+    ap.add_argument("--pipeline", type=int, default=3, choices=[0, 2, 3, 4],
                     help="batches in flight: 2-4 = consecutive steps as the software pipeline (linetr_describe_submit / _join: the front "
                          "of step i + 1 under the signature network of step i, full batch in every GEMM); 0: one step after the other on one stream")
     ap.add_argument("--settle-s", type=float, default=2.0, help="minimum seconds of load before anything is timed")
@@ -1288,6 +1288,8 @@ def main():
     # ---- per-kernel HIP-event profile of the same step (roofline of the dominant kernel) ----------------------
     for _ in range(3):
         pipe.step()                       # bring the clocks back up after the light matcher section
+    pipe.drain()
+    torch.cuda.synchronize()              # the profile below times every kernel ALONE (one stream): nothing of the pipeline may still run
     prof_steps = 3
     prof, tot_ms = profile_steps(eng, pipe.describe, prof_steps)
     roofline = roofline_of(prof[0], prof_steps, tot_ms, args.workload)

@@ -264,9 +264,28 @@ def test_matching_on_the_reference_asset_pair_with_real_image_statistics():
     assert np.array_equal(pred["matches_l"].numpy(), g["matches_l"]) and g["matches_l"].sum() >= 40
     dk_err = float(np.abs(pred["matching_scores_l"].numpy() - g["matching_scores_l"]).max())
     assert dk_err < 1e-4
+    # Point matches: SuperPoint descriptors of neighbouring key points on a real image are nearly equal, so some argmins of the
+    # 1024 x 1024 distance matrix have margins far below fp32 dot-product noise (smallest: 8e-9; 23 rows / columns under 1e-6) -- there the
+    # reference's own answer depends on its BLAS's summation order.  The contract (bench.py ARGMIN_CONTRACT): identical wherever every
+    # margin involved exceeds 4 x the measured distance error; a differing row must sit on such a near-tie (or on the threshold).
+    dp = pred["matching_scores_p"].numpy()[0]
+    p_err = max(float(np.abs(dp.min(1) - g["matching_scores_p_rowmin"]).max()), float(np.abs(dp.min(0) - g["matching_scores_p_colmin"]).max()))
+    assert p_err < 1e-5
     mp = pred["matches_p"].numpy()[0]
-    assert np.array_equal(np.where(mp.sum(1) > 0, mp.argmax(1), -1), g["matches_p_index"]) and int(mp.sum()) == int(g["matches_p_count"])
-    assert np.abs(pred["matching_scores_p"].numpy()[0].min(1) - g["matching_scores_p_rowmin"]).max() < 1e-5
+    got_idx, want_idx = np.where(mp.sum(1) > 0, mp.argmax(1), -1), g["matches_p_index"]
+    d64 = np.clip(2.0 - 2.0 * g["descriptors0"].astype(np.float64).T @ g["descriptors1"].astype(np.float64), 0, None)
+    r2, c2 = np.sort(d64, axis=1)[:, :2], np.sort(d64, axis=0)[:2, :]
+    row_m, col_m = r2[:, 1] - r2[:, 0], c2[1] - c2[0]
+    tol = 4 * max(p_err, 2.5e-7)
+    differing = np.nonzero(got_idx != want_idx)[0]
+    for i in differing:
+        js = [j for j in (got_idx[i], want_idx[i]) if j >= 0]
+        at_risk = row_m[i] < tol or any(col_m[j] < tol for j in js) or any(abs(d64[i, j] - 0.7) < tol for j in js)
+        assert at_risk, (i, got_idx[i], want_idx[i], row_m[i], [col_m[j] for j in js])
+    n_risk = int((row_m < tol).sum() + (col_m < tol).sum())
+    assert len(differing) <= n_risk and abs(int(mp.sum()) - int(g["matches_p_count"])) <= n_risk
+    print(f"asset pair, point matcher: max |distance - reference| = {p_err:.2e}; argmin margins below {tol:.1e}: {n_risk} of 2048 "
+          f"(smallest {min(row_m.min(), col_m.min()):.1e}); rows whose match differs from the reference's: {len(differing)}, all on such near-ties")
     mg = asset_margins(g["matching_scores_l"][0])
     print(f"asset pair: max |line_desc - reference| = {worst:.3e}, max |Dk - reference| = {dk_err:.3e}, smallest argmin margin {mg.min():.3e}, "
           f"margins below 4 x the Dk error: {int((mg < 4 * dk_err).sum())} of {mg.size}")

@@ -34,7 +34,7 @@ from linetr_amd.engine import Engine
 dev = torch.device("cuda:0")
 eng = Engine(synth.calibrated_state_dict(), dev, image_shape=[480, 640])
 lines, dd, nhwc, ds, hw, T = bench.make_inputs("cfg3", 64, 0, dev, eng)
-pipe = bench.Pipeline(eng, lines, nhwc, ds, hw, T, 1, 64)
+pipe = bench.Pipeline(eng, lines, nhwc, ds, hw, T, 1, 64)      # (one stream: the host side of a step, not the pipeline's waits)
 for _ in range(50):
     pipe.step()
 torch.cuda.synchronize()
@@ -60,15 +60,36 @@ pstats.Stats(pr).sort_stats("tottime").print_stats(16)
 PY
   grep -A26 "==== cfg2" ${O}_hostprof.txt | cut -c1-150
 fi
-if has prof; then     # rocprofv3 kernel stats, one run per workload
+if has prof; then     # rocprofv3 kernel stats, one run per workload.  --pipeline 0: every kernel ALONE on the chip, like the HIP-event profile
+  # bench.py's roofline block is made from (under the describe pipeline two or three kernels share the CUs and every duration stretches;
+  # that schedule has its own stage below: trace)
   for wl in cfg3 cfg2 cfg5; do
     timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$wl -o p -- \
-      python bench.py --workload $wl --steps 5 --warmup 2 --settle-s 0.5 --no-cpu-baseline --no-sub-workloads \
+      python bench.py --workload $wl --pipeline 0 --steps 5 --warmup 2 --settle-s 0.5 --no-cpu-baseline --no-sub-workloads \
       > ${O}_${wl}_bench_under_rocprof.json 2> ${O}_${wl}_prof.log
     f=$(ls gpurun_out/prof_${tag}_$wl/*kernel_stats.csv 2>/dev/null | head -1)
     [ -n "$f" ] && cp "$f" ${O}_${wl}_kernel_stats.csv && head -7 ${O}_${wl}_kernel_stats.csv | cut -c1-150
     rm -rf gpurun_out/prof_${tag}_$wl
   done
+fi
+if has trace; then    # the describe pipeline's steady state: which kernels execute concurrently (rocprofv3 --kernel-trace + tools/pipeline_overlap.py)
+  for spec in "cfg3 3" "cfg5 3" "cfg3 2"; do
+    set -- $spec; wl=$1; d=$2
+    rm -rf gpurun_out/trace_$wl
+    timeout 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_$wl -o p -- python tools/pipeline_trace_run.py $wl $d 400 > ${O}_${wl}_d${d}_trace.log 2>&1
+    f=$(find gpurun_out/trace_$wl -name "*kernel_trace.csv" | head -1)
+    [ -n "$f" ] && python tools/pipeline_overlap.py "$f" --last-ms 30 --timeline-ms 6 > ${O}_${wl}_pipeline_overlap_d${d}.txt && head -16 ${O}_${wl}_pipeline_overlap_d${d}.txt | cut -c1-170
+    rm -rf gpurun_out/trace_$wl
+  done
+fi
+if has sweep8; then   # bench.py --gpus {1,2,4,8} for both sharded workloads with every rank on THIS device and gloo as the collective: plumbing only
+  LINETR_BENCH_ONE_DEVICE=1 LINETR_BENCH_BACKEND=gloo SWEEP_PAIRS=8 CFG4_PAIRS=64 timeout 1500 bash tools/scale_sweep.sh gpurun_out/sweep_$tag 1 2 4 8 > ${O}_scale_sweep_one_device_gloo.txt 2>&1
+  echo "sweep8 rc=$?"; cat ${O}_scale_sweep_one_device_gloo.txt
+fi
+if has soak; then     # parity soaks against the oracle / the reference-made asset fixture
+  { timeout 900 python tools/parity_soak.py 96 cfg3; timeout 900 python tools/parity_soak.py 16 cfg5; timeout 300 python tools/parity_soak.py asset; } > ${O}_parity_soak.txt 2>/dev/null
+  cat ${O}_parity_soak.txt
+  timeout 900 python tools/tokenizer_fuzz_soak.py > ${O}_tokenizer_soak.txt 2>/dev/null; tail -1 ${O}_tokenizer_soak.txt
 fi
 if has pmc; then      # counters per workload: bench.py only attaches counters taken on the same workload
   for wl in cfg3 cfg2 cfg5; do bash tools/pmc_kernels.sh $tag $wl; done

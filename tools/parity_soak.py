@@ -1,6 +1,8 @@
 """Descriptor / match parity soak: P random pairs (random line counts, seeds, both dense layouts) described as ONE batch on the GPU and
 matched, against the CPU oracle pair by pair: max |descriptor - oracle|, line matches identical by index, smallest argmin margin.
-    python tools/parity_soak.py [pairs] [cfg3|cfg5]      (on the GPU box; cfg5 = the long-line workload's shape: 1280 x 960, 300-600 lines of 40-327 px, 41 tokens)"""
+    python tools/parity_soak.py [pairs] [cfg3|cfg5]      (on the GPU box; cfg5 = the long-line workload's shape: 1280 x 960, 300-600 lines of 40-327 px, 41 tokens)
+    python tools/parity_soak.py asset                    the fixture with real-image statistics (tests/golden/asset_pair.npz, made by the real reference):
+                                                         descriptor / Dk errors, line and point argmin margins, margins at risk"""
 import os
 import sys
 import time
@@ -15,7 +17,46 @@ from oracle import linetr_oracle as O  # noqa: E402
 from workloads import synth  # noqa: E402
 
 
+def asset_report():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "asset_pair.npz"))
+    torch.set_grad_enabled(False)
+    eng = Engine(synth.calibrated_state_dict(), "cuda:0")
+    dd = torch.cat([torch.from_numpy(g["dense_descriptor" + s]) for s in "01"]).cuda()
+    ds = torch.cat([torch.from_numpy(g["dense_score" + s]) for s in "01"]).cuda()
+    lines = [g["lines0"], g["lines1"]]
+    off = np.array([0, len(lines[0]), len(lines[0]) + len(lines[1])], np.int32)
+    tb, ld = eng.describe_lines(np.concatenate(lines), off, dd, ds, remove_borders=8, min_length=16, max_keylines=-1, token_distance=8, max_tokens=21)
+    n, k = np.diff(tb.cu_n), np.diff(tb.cu_k)
+    dk, _off, m01 = eng.match(ld[:n[0]], np.array([0, n[0]]), tb.sub2line[:n[0]], np.array([0, k[0]]), ld[n[0]:], np.array([0, n[1]]),
+                              tb.sub2line[n[0]:], np.array([0, k[1]]), 0.8, True)
+    dist, pm01 = eng.match_points(torch.from_numpy(g["descriptors0"]).cuda(), torch.from_numpy(g["descriptors1"]).cuda(), 0.7, True)
+    torch.cuda.synchronize()
+    ld_c = ld.cpu().numpy()
+    e_desc = max(float(np.abs(ld_c[tb.cu_n[i]:tb.cu_n[i + 1]].T - g["line_desc" + s][0]).max()) for i, s in enumerate("01"))
+    Dk = g["matching_scores_l"][0]
+    e_dk = float(np.abs(dk.cpu().numpy().reshape(Dk.shape) - Dk).max())
+    got = np.zeros_like(Dk, dtype=np.float64)
+    mm = m01.cpu().numpy()
+    got[np.nonzero(mm >= 0)[0], mm[mm >= 0]] = 1
+    marg = lambda d: np.concatenate([np.diff(np.sort(d, axis=1)[:, :2], axis=1)[:, 0], np.diff(np.sort(d, axis=0)[:2, :], axis=0)[0]])
+    ml = marg(Dk)
+    d64 = np.clip(2.0 - 2.0 * g["descriptors0"].astype(np.float64).T @ g["descriptors1"].astype(np.float64), 0, None)
+    mp = marg(d64)
+    dist_c = dist.cpu().numpy()
+    e_p = max(float(np.abs(dist_c.min(1) - g["matching_scores_p_rowmin"]).max()), float(np.abs(dist_c.min(0) - g["matching_scores_p_colmin"]).max()))
+    p_got, p_want = pm01.cpu().numpy(), g["matches_p_index"]
+    dd0 = g["dense_descriptor0"][0]
+    print(f"asset pair (scannet_0a / 0b through the reference's SuperPoint, seeded weights; neighbouring descriptor cells at cosine "
+          f"{float((dd0[:, :, 1:] * dd0[:, :, :-1]).sum(0).mean()):.3f}): {int(tb.K)} key-lines, {int(tb.N)} sub-lines")
+    print(f"  lines : max |desc - reference| = {e_desc:.2e}, max |Dk - reference| = {e_dk:.2e}, match matrix identical: {np.array_equal(got, g['matches_l'][0])} "
+          f"({int(got.sum())} matches); argmin margins: smallest {ml.min():.2e}, below 1e-5: {int((ml < 1e-5).sum())}, at risk (< 4 x Dk error): {int((ml < 4 * e_dk).sum())} of {ml.size}")
+    print(f"  points: max |distance - reference| = {e_p:.2e}, rows whose match differs from the reference's: {int((p_got != p_want).sum())} of {len(p_want)}; "
+          f"argmin margins: smallest {mp.min():.1e}, below 1e-6: {int((mp < 1e-6).sum())}, at risk (< 4 x max(error, 2.5e-7)): {int((mp < 4 * max(e_p, 2.5e-7)).sum())} of {mp.size}")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "asset":
+        return asset_report()
     P = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     big = len(sys.argv) > 2 and sys.argv[2] == "cfg5"
     torch.set_grad_enabled(False)
