@@ -540,7 +540,7 @@ def sub_workload(eng, name, device, settle_s, repeat=1, brief=False, pipelined=3
         elapsed, per_step, host_ms, last = timed_steps(pp.step, bar, steps, device)
         if depth:
             last = pp.last_joined
-            per_step = per_step[depth - 1:] if len(per_step) > depth else per_step
+            per_step = per_step[depth:] if len(per_step) > depth + 1 else per_step
         return pp, elapsed, per_step, host_ms, last
 
     main_depth = 0 if (pairs == 1 or not pipelined) else pipelined
@@ -1169,10 +1169,10 @@ def main():
     elapsed, per_step, host_ms, (tb, ld, _g) = timed_steps(pipe.step, barrier, args.steps, device)
     if args.pipeline:
         # the closing barrier joined the last batch; the first step of the region only submits (nothing in flight behind the opening
-        # barrier), so its event interval is empty and the last batch's completion falls behind the last event: the per-step
-        # statistics are taken over the K - depth + 1 completion-to-completion intervals in between
+        # barrier), so its event interval is empty, the first join's interval is the pipeline filling, and the last batches' completions
+        # fall behind the last event: the per-step statistics are taken over the K - depth completion-to-completion intervals in between
         tb, ld, _g = pipe.last_joined
-        per_step = per_step[args.pipeline - 1:] if len(per_step) > args.pipeline else per_step
+        per_step = per_step[args.pipeline:] if len(per_step) > args.pipeline + 1 else per_step
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
