@@ -394,7 +394,7 @@ int linetr_debug_gemm(LinetrHandle* h, const float* d_A, int32_t lda, const floa
                       int32_t act, int32_t cache_weights, void* stream);
 
 #ifdef LINETR_EXPERIMENTS
-/* ---- split-tile ("ST") operands (csrc/lt_gemm_st.h): experiments build only --------------------
+/* ---- split-tile ("ST") operands (csrc/lt_st_image.h; the GEMM on them: experiments/csrc/lt_gemm_st.h): experiments build only --------------------
  * (liblinetr_hip_experiments.so, `python -m linetr_amd.build --experiments`; measured and not shipped)
  * The signature network keeps its activations in HBM pre-split into three bf16 planes, in 512-byte chunks that are the
  * LDS image of a 16-row x 16-column block (K-step-major), so that a GEMM's K steps travel by LDS-DMA.  These three entry points expose

@@ -166,7 +166,7 @@ extern "C" int linetr_create(const LinetrModelConfig* cfg, int32_t n_tensors, co
   auto place = [&](const float** dst, const std::vector<double>& v) { fix.push_back({dst, ar.put(v)}); };
   struct GemmW { const float** dst; int64_t rows; int K; bool st; };
   std::vector<GemmW> gemm_w;
-  // st: the weight also gets a split-tile image (lt_gemm_st.h) -- the q/k/v projections, which the fused projection +
+  // st: the weight also gets a split-tile image (lt_st_image.h) -- the q/k/v projections, which the fused projection +
   // attention kernel streams by LDS-DMA (lt_attn_fused.h); in the experiments build every eligible weight gets one
   auto place_w = [&](const float** dst, const std::vector<double>& v, int64_t rows, int K, bool st = false) {
     place(dst, v);

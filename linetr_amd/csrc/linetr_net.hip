@@ -400,7 +400,7 @@ constexpr int SIG_FOLD_MAX_ROWS = 960;
 struct FwdWs {
   float *a1, *a2, *a3, *a4, *pooled, *att, *fc, *o, *f1, *f2, *l1, *l2, *l3, *l4, *lpos, *zA, *zB, *qkv, *msgp, *msg, *hid;
   float *zqA, *zqB;                                // [N][4D] = [x_out | q/k/v of the next layer] (single-pair sizes: SigLayer::Wnext)
-  unsigned char *zsA, *zsB, *qkvs, *msgs, *hids;   // split-tile images of the signature network's activations (lt_gemm_st.h)
+  unsigned char *zsA, *zsB, *qkvs, *msgs, *hids;   // split-tile images of the signature network's activations (experiments: lt_gemm_st.h)
   int* cu;
   char* pn;                                        // activations + arrival counters of the single-pair persistent network (lt_pairnet.h)
   int64_t total;

@@ -883,7 +883,7 @@ class Engine:
                                             int(act), int(cache_weights), self._stream()), self._L)
         return Y
 
-    # ------------------------------------------------------------------ split-tile operands (lt_gemm_st.h)
+    # ------------------------------------------------------------------ split-tile operands (csrc/lt_st_image.h; the GEMM on them: experiments/csrc/lt_gemm_st.h)
     def to_st(self, X):
         """fp32 [rows, K] -> ST image (uint8 tensor); K % 32 == 0."""
         X = self._f32(X)
