@@ -434,7 +434,13 @@ class Engine:
             nat.check(self._L.linetr_describe(*args, ws.data_ptr(), ws.numel(), self._stream()), self._L)
         else:
             slot, n_slots = (int(v) for v in pipeline_slot)
-            ws = self._workspace(f"desc_pipe{slot}", nbytes)      # one workspace per slot: n_slots batches are in flight
+            tag = f"desc_pipe{slot}"
+            old = self._ws.get(tag)
+            if old is not None and old.numel() < nbytes:
+                # the slot's workspace has to grow: its previous batch may still be running on the library's streams, which the caching
+                # allocator knows nothing about -- let the device drain before the old block goes back to the pool (rare: sizes settle)
+                torch.cuda.synchronize(self.device)
+            ws = self._workspace(tag, nbytes)      # one workspace per slot: n_slots batches are in flight
             tb.extra["dense"] = (dense_desc, dense_score)          # read by the stage streams after this call returns
             nat.check(self._L.linetr_describe_submit(*args, ws.data_ptr(), ws.numel(), slot, n_slots, self._stream()), self._L)
         return tb, ld
