@@ -243,6 +243,11 @@ def superpoint_state_dict(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
 
 
 # ----------------------------------------------------------------------------
+# NOTE ON PROVENANCE: `sample_homography` below follows the reference's sampler STEP FOR STEP -- same argument list, same order of
+# perspective -> scaling -> translation -> rotation, same validity rules -- because SURVEY.md (section 2 row 13, section 8(d) cfg4) prescribes
+# that recipe as the definition of the cfg4 workload.  It is WORKLOAD GENERATION for bench.py and the tests, runs outside every timed
+# region, and is not part of the product (`linetr_amd/`).  The RNG (a seeded RandomState instead of the global one), the truncated normal
+# (rejection instead of scipy.stats) and the DLT solve (instead of cv2.getPerspectiveTransform) are this repo's own.
 # cfg4: homography-augmented pairs.  Restates the recipe of the reference's dataset builder
 # (/root/reference/dataloaders/utils/homographies.py:12-141, called with the parameters of
 # /root/reference/dataloaders/confs/homography.yaml:31-46 on the normalised [-1,1]^2 square and rescaled to pixels as
