@@ -1286,10 +1286,10 @@ def main():
     pair_match_latency_ms = float(np.median(lat)) * 1e3
 
     # ---- per-kernel HIP-event profile of the same step (roofline of the dominant kernel) ----------------------
-    for _ in range(3):
-        pipe.step()                       # bring the clocks back up after the light matcher section
     pipe.drain()
-    torch.cuda.synchronize()              # the profile below times every kernel ALONE (one stream): nothing of the pipeline may still run
+    for _ in range(20):
+        pipe.describe()                   # one-stream steps: the clocks settle where a one-stream step runs (after the light matcher section
+    torch.cuda.synchronize()              # they are high, after pipelined steps ~8 % low: the package cap); nothing of the pipeline still runs
     prof_steps = 3
     prof, tot_ms = profile_steps(eng, pipe.describe, prof_steps)
     roofline = roofline_of(prof[0], prof_steps, tot_ms, args.workload)

@@ -81,7 +81,12 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
     } else {
       int row = (x - 18) * 16 + (lane >> 2);
       row = row < Ni ? row : Ni - 1;
-      const float* g = z + (int64_t)(n0 + row) * D + k * 16 + (lane & 3) * 4;
+      // LDS-DMA places lane l's 16 bytes at dst + 16 l: slot (lane & 3) of row (lane >> 2).  The four 16-byte quarters of a row are
+      // ROTATED by (row >> 2) & 3 inside its 64 bytes (this lane fetches quarter (slot - rotation) & 3): the 16 lanes of a ds_read_b128
+      // group -- 16 consecutive rows, same quarter -- then hit 16 distinct 4-bank groups of the 64-bank LDS ((row & 3) x 16 + 4 x slot)
+      // instead of four (r06: these reads were 40 % of the kernel's bank-conflict cycles).  Four adjacent lanes still fetch the 64
+      // contiguous bytes of one row.
+      const float* g = z + (int64_t)(n0 + row) * D + k * 16 + (((lane & 3) - ((lane >> 4) & 3)) & 3) * 4;
       LT_GLDS(g, dst, 0);
     }
   };
@@ -122,7 +127,10 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
   asm volatile("" ::: "memory");
 
   const int lfrag = ((lane >> 4) & 1) * ST_RB + (lane >> 5) * 256 + (lane & 15) * 16;
-  const int zoff = FQA_W_BYTES + (wave * 32 + lq) * 64 + h2 * 32;
+  // this lane's two quarters (8 fp32 = k 8 h2 .. + 8 of its row) at their rotated slots (issue_one)
+  const int zrot = (lq >> 2) & 3;
+  const int zoff0 = FQA_W_BYTES + (wave * 32 + lq) * 64 + ((2 * h2 + zrot) & 3) * 16;
+  const int zoff1 = FQA_W_BYTES + (wave * 32 + lq) * 64 + ((2 * h2 + 1 + zrot) & 3) * 16;
   constexpr int TW[6] = {2, 1, 0, 1, 0, 0}, TA[6] = {0, 1, 2, 0, 1, 0};     // smallest cross terms first
   // Fixed issue order (sched_barrier after every MFMA slot, as in the GEMMs): while n-tile i of step s multiplies, the weight
   // fragments of n-tile i+1 are fetched; the activations of step s+1 are fetched at the start of step s and split into their
@@ -145,8 +153,7 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
   };
   bf16x8 zfA[3], zfB[3], wfA[3], wfB[3];
   {
-    const unsigned char* zp = fq_smem + zoff;
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(zp), x1 = *reinterpret_cast<const f32x4*>(zp + 16);
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(fq_smem + zoff0), x1 = *reinterpret_cast<const f32x4*>(fq_smem + zoff1);
     split_z(x0, x1, zfA);
 #pragma unroll
     for (int p = 0; p < 3; ++p) read_w(0, 0, p, wfA);
@@ -164,8 +171,8 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
         if (i < 5) read_w(s, i + 1, t, wn);
         else read_w(s + 1, 0, t, wn);                      // (past the last step: reads a slot that is never used; harmless)
       }
-      if (m == 3) zr0 = *reinterpret_cast<const f32x4*>(fq_smem + ((s + 1) & 3) * FQA_SLOT + zoff);
-      if (m == 4) zr1 = *reinterpret_cast<const f32x4*>(fq_smem + ((s + 1) & 3) * FQA_SLOT + zoff + 16);
+      if (m == 3) zr0 = *reinterpret_cast<const f32x4*>(fq_smem + ((s + 1) & 3) * FQA_SLOT + zoff0);
+      if (m == 4) zr1 = *reinterpret_cast<const f32x4*>(fq_smem + ((s + 1) & 3) * FQA_SLOT + zoff1);
       if (m == 15) split_z(zr0, zr1, zn);
       if (m >= 18 && m < 23 && s >= 1 && s + 3 < NK) { if (m - 18 < n_dma) issue_one(m - 18, s + 3, (s + 3) & 3); }
       __builtin_amdgcn_sched_barrier(0);
