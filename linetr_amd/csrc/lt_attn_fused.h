@@ -83,9 +83,9 @@ __global__ __launch_bounds__(512) void sig_qkv_attn_kernel(const float* __restri
       row = row < Ni ? row : Ni - 1;
       // LDS-DMA places lane l's 16 bytes at dst + 16 l: slot (lane & 3) of row (lane >> 2).  The four 16-byte quarters of a row are
       // ROTATED by (row >> 2) & 3 inside its 64 bytes (this lane fetches quarter (slot - rotation) & 3): the 16 lanes of a ds_read_b128
-      // group -- 16 consecutive rows, same quarter -- then hit 16 distinct 4-bank groups of the 64-bank LDS ((row & 3) x 16 + 4 x slot)
-      // instead of four (r06: these reads were 40 % of the kernel's bank-conflict cycles).  Four adjacent lanes still fetch the 64
-      // contiguous bytes of one row.
+      // group (lanes {0-3, 12-15, 20-27} ...: four runs of 4 rows whose row >> 2 differ mod 4), all reading the same quarter, then hit
+      // 16 distinct 16-byte slots of the 64-bank row ((row & 3) x 16 + 4 x slot) instead of four (r06: these reads were 55 % of the
+      // kernel's bank-conflict cycles; the rest are the V staging stores).  Four adjacent lanes still fetch 64 contiguous bytes of one row.
       const float* g = z + (int64_t)(n0 + row) * D + k * 16 + (((lane & 3) - ((lane >> 4) & 3)) & 3) * 4;
       LT_GLDS(g, dst, 0);
     }
