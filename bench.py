@@ -246,10 +246,6 @@ def timed_steps(step_fn, barrier_fn, steps, device):
     host time spent inside each step call."""
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     host = np.zeros(steps)
-    if os.environ.get("LINETR_BENCH_NOGC"):      # experiment: is the Python garbage collector behind the slow steps?
-        import gc
-        gc.collect()
-        gc.disable()
     barrier_fn()
     evs[0].record()
     t0 = time.perf_counter()
@@ -1162,6 +1158,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Python's cyclic collector scans the whole start-up heap (torch, the engine, the inputs) on a full collection: an 8-10 ms pause of the
+    # HOST every few hundred steps (tools/pipeline_soak.py).  A one-stream step has a deep launch queue to absorb it; the describe pipeline
+    # keeps the host at most `depth` batches ahead and turns it into a bubble.  Everything alive now is set-up: park it in the permanent
+    # generation (the collector keeps running on what the steps allocate).
+    import gc
+    gc.collect()
+    gc.freeze()
     # ---- steady state, then the contract: W untimed warm-up steps, EXACTLY K timed steps between barriers ----------
     settle_hist = settle(pipe.step, barrier, min_s=args.settle_s, agree=make_agree(dist, world, device))
     for _ in range(args.warmup):
