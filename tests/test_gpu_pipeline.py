@@ -70,6 +70,30 @@ def test_pipelined_batches_equal_the_serial_calls(eng):
     same(serial[0], serial[-1])
 
 
+def test_pipelined_long_line_batches_equal_the_serial_calls():
+    """cfg5's shape (960 x 1280, 600 lines of 40-327 px, 41 tokens: images above 256 sub-lines take the q/k/v GEMM + flash attention pair
+    instead of the fused kernel, and the cut points fall between other launches) through the pipeline: bit-identical to the plain call."""
+    from linetr_amd.engine import DescribePipeline, Engine
+    hw = (960, 1280)
+    e = Engine(synth.calibrated_state_dict(), "cuda:0", image_shape=list(hw))
+    cfg = dict(remove_borders=8, min_length=16, max_keylines=-1, token_distance=8, max_tokens=41)
+    sets = []
+    for b, seed0 in ((4, 9700), (2, 9710), (6, 9720)):
+        lines = [synth.synth_lines(seed0 + i, 600 - 40 * i, hw[0], hw[1], 40.0, 327.0) for i in range(b)]
+        maps = [synth.synth_dense_maps(seed0 + i, *hw) for i in range(b)]
+        off = np.concatenate([[0], np.cumsum([len(l) for l in lines])]).astype(np.int32)
+        sets.append((np.concatenate(lines), off, torch.cat([m[0] for m in maps]).cuda().permute(0, 2, 3, 1).contiguous(), torch.cat([m[1] for m in maps]).cuda()))
+    serial = [e.describe_lines(*s, dense_layout="nhwc", **cfg) for s in sets]
+    torch.cuda.synchronize()
+    assert max(int(np.diff(tb.cu_n).max()) for tb, _ in serial) > 256
+    pipe = DescribePipeline(e, 3)
+    got = [r for r in (pipe.submit(*s, dense_layout="nhwc", **cfg) for s in sets + sets) if r is not None] + pipe.drain()
+    torch.cuda.synchronize()
+    assert len(got) == 6
+    for a, b in zip(got, serial + serial):
+        same(a, b)
+
+
 def test_pipeline_with_an_empty_batch_and_a_late_reader(eng):
     from linetr_amd.engine import DescribePipeline
     full = batch(16, 9500)
