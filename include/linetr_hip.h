@@ -14,6 +14,9 @@
  *     linetr_tokenize                         (device)                -> the tensors of `preprocess`
  *     linetr_forward                          (device)                -> line_desc
  *     linetr_match                            (device)                -> Dk, match indices
+ * or, for throughput:  linetr_prefilter_batch -> linetr_describe (tokenise + forward fused, var-len batch) -> linetr_match;
+ * streams of batches:  linetr_describe_submit / linetr_describe_join (the same call as a software pipeline over consecutive batches).
+ * ABI version 5 (r06): + linetr_describe_submit, linetr_describe_join, linetr_pipeline_max_slots.
  */
 #ifndef LINETR_HIP_H
 #define LINETR_HIP_H
