@@ -153,7 +153,9 @@ class Matching(torch.nn.Module):
         if on_dev:
             # maps made by this package's tokeniser ride along with their (unmodified) matrices; an edited or foreign matrix is read by
             # its contents on the slower path below
-            s0, s1 = sub2line_of(mat0), sub2line_of(mat1)
+            # (a matrix THIS call has just made cannot have been written to by anyone: its map is taken as it is -- also under
+            # torch.inference_mode(), where tensors keep no version counter to stamp; a matrix handed in by the caller goes by its stamp)
+            s0, s1 = (getattr(m, "_linetr_sub2line", None) if s in sides else sub2line_of(m) for s, m in (("0", mat0), ("1", mat1)))
             have_lines = K0 > 0 and K1 > 0 and s0 is not None and s1 is not None and ld0.is_cuda and ld1.is_cuda
             if have_lines or K0 == 0 or K1 == 0:
                 tail = eng_m.pair_tail(d0, d1, float(np.float32(thr_p)), ld0[0].t() if have_lines else None, s0, K0,

@@ -190,6 +190,32 @@ def test_matching_pipeline_outputs():
     assert out["klines0"].shape == (199, 2, 2) and out["matches_l"].shape == (199, 199)
 
 
+def test_matching_forward_under_inference_mode_takes_the_one_call_tail(monkeypatch):
+    """tensors made under torch.inference_mode() keep no version counter, so the sub-line maps riding along with the matrices
+    could not be stamped and Matching.forward fell back to the separate calls (contents path, two host waits).  The matrices a forward call
+    has just made itself are trusted as they are: the one-call tail (linetr_pair_tail) runs, and the results are those of the normal mode."""
+    from models.matching import Matching
+    from linetr_amd.engine import Engine
+    g = load("cfg2_pair")
+
+    def build():
+        mt = Matching({"auto_min_length": True, "superpoint": {}, "lsd": {}, "linetransformer": {**LT_CFG}},
+                      superpoint=FakeSuperPoint([int(g["a_seed"]), int(g["b_seed"])]), lsd=FakeLSD([g["a_lines"], g["b_lines"]]))
+        mt.linetransformer.load_state_dict(synth.to_torch_state_dict(synth.calibrated_state_dict()))
+        return mt.eval().to("cuda")
+    img = torch.zeros(1, 1, 480, 640, device="cuda")
+    ref = build()({"image0": img, "image1": img.clone()})
+    calls = []
+    real_tail = Engine.pair_tail
+    monkeypatch.setattr(Engine, "pair_tail", lambda self, *a, **k: (calls.append(1), real_tail(self, *a, **k))[1])
+    with torch.inference_mode():
+        pred = build()({"image0": img, "image1": img.clone()})
+    assert len(calls) == 1                                                     # not the fallback
+    for k in ("matches_l", "matches_p", "matching_scores_l", "matching_scores_p"):
+        assert torch.equal(pred[k], ref[k]), k
+    assert torch.equal(pred["line_desc0"], ref["line_desc0"])
+
+
 def test_matching_pair_of_two_image_sizes_like_the_reference():
     """models/matching.py:29-32 and :45-48: with auto_min_length, min_length / token_distance are recomputed for EACH image from that
     image's own shape.  A 480 x 640 + 960 x 1280 pair against a golden of the real reference (tests/golden/make_golden_mixed.py):
