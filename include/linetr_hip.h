@@ -249,7 +249,9 @@ int linetr_describe(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int
  *                           joined.  Host run-ahead is bounded: a submit first waits (on the host) for the batch previously submitted
  *                           to the same slot.
  *   linetr_describe_join    `stream` waits for the batch last submitted to `slot`; its outputs may be read on `stream` afterwards.
- * A caller pipelines by  submit(i, i mod n);  join(i - n + 1, (i - n + 1) mod n);  -- n - 1 batches of latency for the overlap. */
+ * A caller pipelines by  submit(i, i mod n);  join(i - n + 1, (i - n + 1) mod n);  -- n - 1 batches of latency for the overlap.
+ * Like every entry point that takes a handle, the pair is not re-entrant: one submitting thread per handle.  A failed submit leaves
+ * the library's streams idle and the slot free (nothing half-queued survives it). */
 int linetr_describe_submit(LinetrHandle* h, const LinetrLineRec* d_recs, int32_t K, int32_t N, int64_t n_real_tokens,
                            const int32_t* h_cu_sub, const int32_t* d_cu_sub, int32_t n_images, double token_distance,
                            int32_t max_tokens, const float* d_dense_desc, const float* d_dense_score, int32_t height,

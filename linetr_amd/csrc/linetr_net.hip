@@ -1121,7 +1121,7 @@ int pipe_ready(LinetrHandle* h) {
 
 // How a batch is cut into stages when the caller keeps `n_slots` batches in flight.
 struct PipePlan { int n_cuts = 0; int cut[LinetrHandle::PIPE_STREAMS - 1] = {0, 0, 0}; };
-PipePlan pipe_plan(const LinetrHandle* h, int n_slots, int n_images, int N, int64_t rows) {
+PipePlan pipe_plan(const LinetrHandle* h, int n_slots) {
   PipePlan pl;
   // measured on MI355X (profiles/r06_pipeline_sweep.txt): balanced stages win over "front | signature network" (the front is a third
   // of a batch), and three stages over two; a fourth slot only lets the host run one more batch ahead
@@ -1158,7 +1158,7 @@ extern "C" int linetr_describe_submit(LinetrHandle* h, const LinetrLineRec* d_re
   // host run-ahead is bounded to the batches in flight: the slot's previous batch (n_slots submits ago) must have left the GPU
   // before its workspace is handed to the device again
   if (p.submitted[slot]) LT_HIP(hipEventSynchronize(p.done[slot]));
-  const PipePlan plan = pipe_plan(h, n_slots, n_images, N, n_real + n_images);
+  const PipePlan plan = pipe_plan(h, n_slots);
   PipeStages stg;
   for (int i = 0; i < LinetrHandle::PIPE_STREAMS; ++i) stg.stream[i] = p.stream[i];
   stg.n_cuts = plan.n_cuts;
