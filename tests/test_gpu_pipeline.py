@@ -94,6 +94,23 @@ def test_pipelined_long_line_batches_equal_the_serial_calls():
         same(a, b)
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x3"])
+def test_pipelined_batches_in_the_other_precisions(mode):
+    """The cut points sit in forward_core, whatever kernels the arithmetic mode dispatches: exact-fp32 MFMA GEMMs + sig_attn_kernel (f32),
+    the two-plane tiles (bf16x3 / f16x3) -- pipelined results equal the plain call's bit for bit there too."""
+    from linetr_amd.engine import DescribePipeline, Engine
+    e = Engine(synth.calibrated_state_dict(), "cuda:0")
+    e.set_precision(mode)
+    sets = [batch(24, 9800), batch(2, 9810), batch(40, 9820)]
+    serial = [e.describe_lines(*s, **CFG) for s in sets]
+    torch.cuda.synchronize()
+    pipe = DescribePipeline(e, 3)
+    got = [r for r in (pipe.submit(*s, **CFG) for s in sets) if r is not None] + pipe.drain()
+    torch.cuda.synchronize()
+    for a, b in zip(got, serial):
+        same(a, b)
+
+
 def test_pipeline_with_an_empty_batch_and_a_late_reader(eng):
     from linetr_amd.engine import DescribePipeline
     full = batch(16, 9500)
