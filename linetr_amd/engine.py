@@ -964,3 +964,11 @@ class DescribePipeline:
         out = [self._join(e) for e in self.inflight]
         self.inflight = []
         return out
+
+    def __del__(self):
+        # a pipeline dropped with batches in flight: their output tensors go back to torch's caching allocator, which orders re-use on
+        # the CURRENT stream only -- join them first, so that whoever gets those blocks next is queued behind the library's streams
+        try:
+            self.drain()
+        except Exception:
+            pass
